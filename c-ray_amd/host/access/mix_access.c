@@ -1,0 +1,15 @@
+/* Wrapper TU: compiles the UNMODIFIED reference file nodes/shaders/mix.c and appends a describer (see describe.h). */
+#include "nodes/shaders/mix.c"
+#include "describe.h"
+
+bool crh_describe_mix(const void *node, struct crh_node_desc *d) {
+	const struct bsdfNode *base = node;
+	if (base->sample != sample) return false;
+	const struct mixBsdf *t = node;
+	(void)t;
+	d->kind = CRH_BSDF_MIX;
+	d->child[0] = t->A; d->cls[0] = CRH_CLS_BSDF;
+	d->child[1] = t->B; d->cls[1] = CRH_CLS_BSDF;
+	d->child[2] = t->factor; d->cls[2] = CRH_CLS_VALUE;
+	return true;
+}

@@ -1,0 +1,314 @@
+/*
+ * flatten.c — walks the reference's `struct world` after loadScene() and emits the POD arrays of
+ * crh_scene_desc (include/cray_hip.h). Host C, linked against the reference's own objects.
+ *
+ * What it reads (all produced by the UNTOUCHED reference loader, src/datatypes/scene.c:111-213):
+ *   r->scene->instances / topLevel / meshes / spheres / camera / background   (scene.h:14-39)
+ *   g_vertices / g_normals / g_textureCoords                                   (vertexbuffer.h:11-18)
+ * BVHs are the ones the reference's builder made (bvh.c:132-316), copied node-for-node, so node
+ * indices are bit-exact by construction. mesh->rayOffset / sphere->rayOffset are read here, i.e.
+ * AFTER the TLAS build wrote them (instance.c:106,227).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "includes.h"
+#include "datatypes/scene.h"
+#include "datatypes/camera.h"
+#include "datatypes/mesh.h"
+#include "datatypes/sphere.h"
+#include "datatypes/poly.h"
+#include "datatypes/instance.h"
+#include "datatypes/vertexbuffer.h"
+#include "datatypes/material.h"
+#include "datatypes/image/texture.h"
+#include "renderer/renderer.h"
+#include "nodes/bsdfnode.h"
+
+#include "flatten.h"
+#include "access/describe.h"
+
+_Static_assert(sizeof(struct poly) == sizeof(crh_poly), "crh_poly must mirror struct poly (40 B)");
+_Static_assert(sizeof(struct vector) == 12 && sizeof(struct coord) == 8, "vector/coord layout");
+
+/* ---- tiny growable arrays + pointer->index map --------------------------------------------- */
+struct ptrmap { const void **keys; uint32_t *vals; size_t cap, count; };
+
+static size_t ptrhash(const void *p) { uintptr_t x = (uintptr_t)p; x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; return (size_t)x; }
+
+static void ptrmap_grow(struct ptrmap *m) {
+	size_t ncap = m->cap ? m->cap * 2 : 256;
+	const void **nk = calloc(ncap, sizeof(*nk));
+	uint32_t *nv = calloc(ncap, sizeof(*nv));
+	for (size_t i = 0; i < m->cap; ++i) {
+		if (!m->keys[i]) continue;
+		size_t h = ptrhash(m->keys[i]) & (ncap - 1);
+		while (nk[h]) h = (h + 1) & (ncap - 1);
+		nk[h] = m->keys[i]; nv[h] = m->vals[i];
+	}
+	free(m->keys); free(m->vals);
+	m->keys = nk; m->vals = nv; m->cap = ncap;
+}
+
+static bool ptrmap_get(const struct ptrmap *m, const void *k, uint32_t *v) {
+	if (!m->cap) return false;
+	size_t h = ptrhash(k) & (m->cap - 1);
+	while (m->keys[h]) {
+		if (m->keys[h] == k) { *v = m->vals[h]; return true; }
+		h = (h + 1) & (m->cap - 1);
+	}
+	return false;
+}
+
+static void ptrmap_put(struct ptrmap *m, const void *k, uint32_t v) {
+	if ((m->count + 1) * 2 > m->cap) ptrmap_grow(m);
+	size_t h = ptrhash(k) & (m->cap - 1);
+	while (m->keys[h]) h = (h + 1) & (m->cap - 1);
+	m->keys[h] = k; m->vals[h] = v; m->count++;
+}
+
+struct flat {
+	crh_gnode *gnodes; size_t gnode_count, gnode_cap;
+	crh_texture *textures; size_t texture_count, texture_cap;
+	uint8_t *texdata; size_t texbytes, texcap;
+	struct ptrmap nodemap, texmap;
+	int error;
+};
+
+static uint32_t add_texture(struct flat *f, const struct texture *t) {
+	if (!t) return CRH_NODE_NONE;
+	uint32_t idx;
+	if (ptrmap_get(&f->texmap, t, &idx)) return idx;
+	if (f->texture_count == f->texture_cap) {
+		f->texture_cap = f->texture_cap ? f->texture_cap * 2 : 16;
+		f->textures = realloc(f->textures, f->texture_cap * sizeof(*f->textures));
+	}
+	size_t unit = t->precision == float_p ? sizeof(float) : 1;
+	size_t bytes = t->width * t->height * t->channels * unit;
+	size_t off = (f->texbytes + 15) & ~(size_t)15;
+	if (off + bytes > f->texcap) {
+		f->texcap = (off + bytes) * 2;
+		f->texdata = realloc(f->texdata, f->texcap);
+	}
+	memset(f->texdata + f->texbytes, 0, off - f->texbytes);
+	memcpy(f->texdata + off, t->data.byte_p, bytes);
+	f->texbytes = off + bytes;
+	idx = (uint32_t)f->texture_count++;
+	f->textures[idx] = (crh_texture){
+		.offset = off, .width = (uint32_t)t->width, .height = (uint32_t)t->height, .channels = (uint32_t)t->channels,
+		.is_float = t->precision == float_p, .has_alpha = t->hasAlpha ? 1u : 0u
+	};
+	ptrmap_put(&f->texmap, t, idx);
+	return idx;
+}
+
+static bool describe(const void *node, int cls, struct crh_node_desc *d) {
+	memset(d, 0, sizeof(*d));
+#define TRY(name) if (crh_describe_##name(node, d)) return true;
+	switch (cls) {
+		case CRH_CLS_BSDF:   CRH_DESCRIBERS_BSDF(TRY)   break;
+		case CRH_CLS_COLOR:  CRH_DESCRIBERS_COLOR(TRY)  break;
+		case CRH_CLS_VALUE:  CRH_DESCRIBERS_VALUE(TRY)  break;
+		case CRH_CLS_VECTOR: CRH_DESCRIBERS_VECTOR(TRY) break;
+		default: break;
+	}
+#undef TRY
+	return false;
+}
+
+/* Post-order: children first, so child indices are always smaller than their parent's. */
+static uint32_t add_node(struct flat *f, const void *node, int cls) {
+	if (!node) return CRH_NODE_NONE;
+	uint32_t idx;
+	if (ptrmap_get(&f->nodemap, node, &idx)) return idx;
+	struct crh_node_desc d;
+	if (!describe(node, cls, &d)) {
+		fprintf(stderr, "crh_flatten: unrecognised node %p of class %d\n", node, cls);
+		f->error = CRH_ERR_UNSUPPORTED;
+		return CRH_NODE_NONE;
+	}
+	crh_gnode g;
+	memset(&g, 0, sizeof(g));
+	g.kind = d.kind;
+	g.a = add_node(f, d.child[0], d.cls[0]);
+	g.b = add_node(f, d.child[1], d.cls[1]);
+	g.c = add_node(f, d.child[2], d.cls[2]);
+	memcpy(g.f, d.f, sizeof(g.f));
+	if (d.kind == CRH_COLOR_IMAGE) { g.a = add_texture(f, d.tex); g.b = d.u; }
+	if (d.kind == CRH_VALUE_MATH || d.kind == CRH_VEC_VECMATH) g.c = d.u;
+	if (f->gnode_count == f->gnode_cap) {
+		f->gnode_cap = f->gnode_cap ? f->gnode_cap * 2 : 64;
+		f->gnodes = realloc(f->gnodes, f->gnode_cap * sizeof(*f->gnodes));
+	}
+	idx = (uint32_t)f->gnode_count++;
+	f->gnodes[idx] = g;
+	ptrmap_put(&f->nodemap, node, idx);
+	return idx;
+}
+
+static void copy_rows(float dst[12], const struct matrix4x4 *m) {
+	for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) dst[r * 4 + c] = m->mtx[r][c];
+}
+
+static crh_material flat_material(struct flat *f, const struct material *m) {
+	crh_material out;
+	memset(&out, 0, sizeof(out));
+	out.emission[0] = m->emission.red; out.emission[1] = m->emission.green;
+	out.emission[2] = m->emission.blue; out.emission[3] = m->emission.alpha;
+	out.ior = m->IOR;
+	out.bsdf = add_node(f, m->bsdf, CRH_CLS_BSDF);
+	return out;
+}
+
+int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
+	if (!r || !r->scene || !out) return CRH_ERR_INVALID;
+	const struct world *w = r->scene;
+	struct flat f;
+	memset(&f, 0, sizeof(f));
+	memset(out, 0, sizeof(*out));
+	out->struct_size = sizeof(*out);
+	out->abi_version = CRH_ABI_VERSION;
+
+	/* --- BVHs: every BLAS, then the TLAS, concatenated --- */
+	size_t totalNodes = crh_access_bvh_node_count(w->topLevel), totalPrims = (size_t)w->instanceCount, totalPolys = 0, totalMats = (size_t)w->sphereCount;
+	for (int m = 0; m < w->meshCount; ++m) {
+		totalNodes += crh_access_bvh_node_count(w->meshes[m].bvh);
+		totalPrims += (size_t)w->meshes[m].polyCount;
+		totalPolys += (size_t)w->meshes[m].polyCount;
+		totalMats += (size_t)w->meshes[m].materialCount;
+	}
+	crh_bvh_node *nodes = calloc(totalNodes ? totalNodes : 1, sizeof(*nodes));
+	int32_t *prims = calloc(totalPrims ? totalPrims : 1, sizeof(*prims));
+	crh_poly *polys = calloc(totalPolys ? totalPolys : 1, sizeof(*polys));
+	crh_mesh *meshes = calloc(w->meshCount ? w->meshCount : 1, sizeof(*meshes));
+	crh_sphere *spheres = calloc(w->sphereCount ? w->sphereCount : 1, sizeof(*spheres));
+	crh_material *materials = calloc(totalMats ? totalMats : 1, sizeof(*materials));
+	crh_instance *instances = calloc(w->instanceCount ? w->instanceCount : 1, sizeof(*instances));
+
+	size_t nodeAt = 0, primAt = 0, polyAt = 0, matAt = 0;
+	for (int m = 0; m < w->meshCount; ++m) {
+		const struct mesh *mesh = &w->meshes[m];
+		unsigned nc = crh_access_bvh_node_count(mesh->bvh);
+		crh_mesh *fm = &meshes[m];
+		fm->node_base = (uint32_t)nodeAt; fm->node_count = nc;
+		fm->prim_base = (uint32_t)primAt;
+		fm->poly_base = (uint32_t)polyAt; fm->poly_count = (uint32_t)mesh->polyCount;
+		fm->material_base = (uint32_t)matAt; fm->material_count = (uint32_t)mesh->materialCount;
+		fm->texcoord_count = (uint32_t)mesh->textureCoordCount;
+		fm->ray_offset = mesh->rayOffset;
+		if (nc) {
+			memcpy(nodes + nodeAt, crh_access_bvh_nodes(mesh->bvh), nc * sizeof(*nodes));
+			memcpy(prims + primAt, crh_access_bvh_prims(mesh->bvh), (size_t)mesh->polyCount * sizeof(*prims));
+		}
+		if (mesh->polyCount) memcpy(polys + polyAt, mesh->polygons, (size_t)mesh->polyCount * sizeof(*polys));
+		for (int k = 0; k < mesh->materialCount; ++k) materials[matAt + k] = flat_material(&f, &mesh->materials[k]);
+		nodeAt += nc; primAt += (size_t)mesh->polyCount; polyAt += (size_t)mesh->polyCount; matAt += (size_t)mesh->materialCount;
+	}
+	/* bvhNode's padding bits (count_leaf bit 31) and poly's padding bits are indeterminate in the
+	 * reference; clear them so that blobs are reproducible. */
+	for (size_t i = 0; i < nodeAt; ++i) nodes[i].count_leaf &= 0x7FFFFFFFu;
+	for (size_t i = 0; i < polyAt; ++i) polys[i].bits &= 0xFF07FFFFu;
+
+	out->tlas_node_base = (uint32_t)nodeAt;
+	out->tlas_node_count = crh_access_bvh_node_count(w->topLevel);
+	out->tlas_prim_base = (uint32_t)primAt;
+	out->tlas_prim_count = out->tlas_node_count ? (uint32_t)w->instanceCount : 0;
+	if (out->tlas_node_count) {
+		memcpy(nodes + nodeAt, crh_access_bvh_nodes(w->topLevel), out->tlas_node_count * sizeof(*nodes));
+		memcpy(prims + primAt, crh_access_bvh_prims(w->topLevel), (size_t)w->instanceCount * sizeof(*prims));
+		for (size_t i = nodeAt; i < nodeAt + out->tlas_node_count; ++i) nodes[i].count_leaf &= 0x7FFFFFFFu;
+		nodeAt += out->tlas_node_count; primAt += (size_t)w->instanceCount;
+	}
+
+	for (int s = 0; s < w->sphereCount; ++s) {
+		spheres[s].radius = w->spheres[s].radius;
+		spheres[s].ray_offset = w->spheres[s].rayOffset;
+		spheres[s].material = (uint32_t)matAt;
+		materials[matAt++] = flat_material(&f, &w->spheres[s].material);
+	}
+
+	for (int i = 0; i < w->instanceCount; ++i) {
+		const struct instance *inst = &w->instances[i];
+		crh_instance *fi = &instances[i];
+		copy_rows(fi->Ainv, &inst->composite.Ainv);
+		copy_rows(fi->A, &inst->composite.A);
+		int kind = crh_access_instance_kind(inst);
+		if (kind == 0) {
+			fi->kind = CRH_INSTANCE_SPHERE;
+			fi->object = (uint32_t)((const struct sphere *)inst->object - w->spheres);
+		} else if (kind == 1) {
+			fi->kind = CRH_INSTANCE_MESH;
+			fi->object = (uint32_t)((const struct mesh *)inst->object - w->meshes);
+		} else {
+			/* volumes: no loader path constructs them */
+			fprintf(stderr, "crh_flatten: instance %d has unsupported kind %d (volume)\n", i, kind);
+			f.error = CRH_ERR_UNSUPPORTED;
+		}
+	}
+
+	out->background = add_node(&f, w->background, CRH_CLS_BSDF);
+
+	/* --- global vertex buffers; slots no polygon references are zeroed (the loader over-allocates:
+	 * wavefront.c:148 counts every line starting with 'v') so the blob is deterministic --- */
+	float *verts = calloc((size_t)(vertexCount > 0 ? vertexCount : 1) * 3, sizeof(float));
+	float *norms = calloc((size_t)(normalCount > 0 ? normalCount : 1) * 3, sizeof(float));
+	float *texs = calloc((size_t)(textureCount > 0 ? textureCount : 1) * 2, sizeof(float));
+	for (size_t p = 0; p < polyAt; ++p) {
+		for (int k = 0; k < 3; ++k) {
+			int vi = polys[p].v[k], ni = polys[p].n[k], ti = polys[p].t[k];
+			if (vi >= 0 && vi < vertexCount) memcpy(verts + 3 * (size_t)vi, &g_vertices[vi], 12);
+			if (ni >= 0 && ni < normalCount) memcpy(norms + 3 * (size_t)ni, &g_normals[ni], 12);
+			if (ti >= 0 && ti < textureCount) memcpy(texs + 2 * (size_t)ti, &g_textureCoords[ti], 8);
+		}
+	}
+
+	const struct camera *cam = w->camera;
+	crh_camera *fc = &out->camera;
+	fc->right[0] = cam->right.x; fc->right[1] = cam->right.y; fc->right[2] = cam->right.z;
+	fc->up[0] = cam->up.x; fc->up[1] = cam->up.y; fc->up[2] = cam->up.z;
+	fc->forward[0] = cam->forward.x; fc->forward[1] = cam->forward.y; fc->forward[2] = cam->forward.z;
+	fc->sensor[0] = cam->sensorSize.x; fc->sensor[1] = cam->sensorSize.y;
+	fc->aperture = cam->aperture;
+	fc->focal_distance = cam->focalDistance;
+	fc->width = cam->width; fc->height = cam->height;
+	copy_rows(fc->A, &cam->composite.A);
+
+	out->nodes = nodes;               out->node_count = nodeAt;
+	out->prim_indices = prims;        out->prim_index_count = primAt;
+	out->polys = polys;               out->poly_count = polyAt;
+	out->vertices = verts;            out->vertex_count = (uint64_t)(vertexCount > 0 ? vertexCount : 0);
+	out->normals = norms;             out->normal_count = (uint64_t)(normalCount > 0 ? normalCount : 0);
+	out->texcoords = texs;            out->texcoord_count = (uint64_t)(textureCount > 0 ? textureCount : 0);
+	out->instances = instances;       out->instance_count = (uint64_t)w->instanceCount;
+	out->meshes = meshes;             out->mesh_count = (uint64_t)w->meshCount;
+	out->spheres = spheres;           out->sphere_count = (uint64_t)w->sphereCount;
+	out->materials = materials;       out->material_count = matAt;
+	out->gnodes = f.gnodes;           out->gnode_count = f.gnode_count;
+	out->textures = f.textures;       out->texture_count = f.texture_count;
+	out->texture_data = f.texdata;    out->texture_bytes = f.texbytes;
+	free(f.nodemap.keys); free(f.nodemap.vals);
+	free(f.texmap.keys); free(f.texmap.vals);
+	if (f.error) { crh_flatten_free(out); return f.error; }
+	return CRH_OK;
+}
+
+void crh_flatten_free(crh_scene_desc *d) {
+	if (!d) return;
+	free((void *)d->nodes); free((void *)d->prim_indices); free((void *)d->polys);
+	free((void *)d->vertices); free((void *)d->normals); free((void *)d->texcoords);
+	free((void *)d->instances); free((void *)d->meshes); free((void *)d->spheres);
+	free((void *)d->materials); free((void *)d->gnodes); free((void *)d->textures);
+	free((void *)d->texture_data);
+	memset(d, 0, sizeof(*d));
+}
+
+crh_blob_prefs crh_flatten_prefs(const struct renderer *r) {
+	crh_blob_prefs p;
+	memset(&p, 0, sizeof(p));
+	p.image_width = (int32_t)r->prefs.imageWidth;   p.image_height = (int32_t)r->prefs.imageHeight;
+	p.sample_count = r->prefs.sampleCount;           p.bounces = r->prefs.bounces;
+	p.tile_width = (int32_t)r->prefs.tileWidth;      p.tile_height = (int32_t)r->prefs.tileHeight;
+	p.tile_order = (int32_t)r->prefs.tileOrder;
+	return p;
+}

@@ -1,0 +1,304 @@
+/*
+ * cray_hip.h — C-ABI of libcray_hip.so, the MI355X (gfx950) path-tracing backend for c-ray.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference renderer (VKoskiv/c-ray v0.6.3):
+ *   renderThread()          src/renderer/renderer.c:258-327   (pixel x pass loop, running mean)
+ *   pathTrace()             src/renderer/pathtrace.c:32-60    (bounce loop, Russian roulette)
+ *   traverseTopLevelBvh()   src/accelerators/bvh.c:488-496    (two-level BVH walk)
+ *   bsdfNode.sample()       src/nodes/...                     (node-graph shading)
+ * The reference has no FFI of its own: the call that a maintainer replaces is
+ *   struct texture *renderFrame(struct renderer *r)   (src/renderer/renderer.h:104),
+ * and the host-side replacement (c-ray_amd/host/renderer_hip.c) is a thin C file that flattens
+ * `struct world` into the POD arrays below and calls the functions declared here.
+ * INTEGRATION.md shows that binding.
+ *
+ * Conventions (mirroring the reference's C conventions):
+ *   - plain C, no C++ types, no exceptions; every call returns int: 0 = ok, negative = failure
+ *     (the reference returns 0 / -1 / -2: src/datatypes/scene.c:122-134, src/utils/platform/thread.c:38-50).
+ *   - host buffers are caller-owned; device memory is owned by the context unless the caller passes
+ *     its own device pointer (e.g. a torch tensor's data_ptr for the framebuffer).
+ *   - one crh_ctx per GPU; calls on one ctx must be serialised by the caller; different ctxs are independent.
+ *   - there is NO CPU fallback: every entry point that needs a device fails with CRH_ERR_NO_DEVICE if none exists.
+ */
+#ifndef CRAY_HIP_H
+#define CRAY_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRH_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define CRH_OK                0
+#define CRH_ERR_INVALID      -1   /* bad argument / malformed scene description            */
+#define CRH_ERR_NO_DEVICE    -2   /* no HIP device (there is no CPU fallback)               */
+#define CRH_ERR_HIP          -3   /* a HIP runtime call failed; see crh_last_error()        */
+#define CRH_ERR_UNSUPPORTED  -4   /* scene uses a construct the device VM does not implement */
+#define CRH_ERR_IO           -5   /* scene blob could not be read / written                 */
+#define CRH_ERR_NOMEM        -6
+
+/* ---- flattened scene records (all little-endian POD) --------------------------------------- */
+
+/* struct bvhNode verbatim (src/accelerators/bvh.c:37-42), 32 B.
+ * bounds = {minx,maxx,miny,maxy,minz,maxz}; count_leaf: primCount = bits 0..29, isLeaf = bit 30.
+ * Children of an inner node are nodes first, first+1 *relative to the owning BVH's node range*;
+ * a leaf indexes prim_indices[first .. first+primCount) relative to the owning BVH's prim range. */
+typedef struct crh_bvh_node {
+	float    bounds[6];
+	uint32_t first;
+	uint32_t count_leaf;
+} crh_bvh_node;
+#define CRH_NODE_PRIMCOUNT(n) ((n).count_leaf & 0x3FFFFFFFu)
+#define CRH_NODE_ISLEAF(n)    (((n).count_leaf >> 30) & 1u)
+
+/* struct poly verbatim (src/datatypes/poly.h:11-18), 40 B. Indices are ABSOLUTE indices into the
+ * global vertex / normal / texcoord arrays (src/utils/loaders/formats/wavefront/wavefront.c:110-126).
+ * bits: materialIndex = bits & 0xFFFF, vertexCount = (bits >> 16) & 7, hasNormals = (bits >> 24) & 0xFF. */
+typedef struct crh_poly {
+	int32_t  v[3];
+	int32_t  n[3];
+	int32_t  t[3];
+	uint32_t bits;
+} crh_poly;
+#define CRH_POLY_MATERIAL(p)   ((p).bits & 0xFFFFu)
+#define CRH_POLY_HASNORMALS(p) ((((p).bits >> 24) & 0xFFu) != 0)
+
+/* struct instance (src/datatypes/instance.h:23-28) reduced to what the path reads: rows 0..2 of
+ * composite.A / composite.Ainv (src/datatypes/transforms.c:76-116 never touch row 3). */
+#define CRH_INSTANCE_SPHERE 0u
+#define CRH_INSTANCE_MESH   1u
+typedef struct crh_instance {
+	float    Ainv[12];   /* row-major 3x4 */
+	float    A[12];      /* row-major 3x4 */
+	uint32_t kind;       /* CRH_INSTANCE_*                                   */
+	uint32_t object;     /* index into spheres[] or meshes[]                  */
+	uint32_t pad[6];
+} crh_instance;          /* 128 B */
+
+/* struct mesh (src/datatypes/mesh.h:20-46) as offsets into the concatenated arrays. */
+typedef struct crh_mesh {
+	uint32_t node_base;       /* first node of this BLAS in nodes[]                */
+	uint32_t node_count;      /* bvh->nodeCount (0 = empty BVH, bvh.c:362-365)      */
+	uint32_t prim_base;       /* first entry of this BLAS in prim_indices[]         */
+	uint32_t poly_base;       /* first polygon of this mesh in polys[]              */
+	uint32_t poly_count;
+	uint32_t material_base;   /* mesh->materials[0] in materials[]                  */
+	uint32_t material_count;
+	uint32_t texcoord_count;  /* mesh->textureCoordCount (instance.c:151)           */
+	float    ray_offset;      /* mesh->rayOffset, read AFTER the TLAS build (instance.c:227) */
+	uint32_t pad[3];
+} crh_mesh;               /* 48 B */
+
+typedef struct crh_sphere {
+	float    radius;
+	float    ray_offset;      /* sphere->rayOffset (instance.c:106) */
+	uint32_t material;        /* index into materials[] */
+	uint32_t pad;
+} crh_sphere;             /* 16 B */
+
+/* The three fields of struct material read at render time (pathtrace.c:44,46; plastic.c:68-77). */
+typedef struct crh_material {
+	float    emission[4];
+	float    ior;
+	uint32_t bsdf;            /* root node index in gnodes[] */
+	uint32_t pad[2];
+} crh_material;           /* 32 B */
+
+/* Node graph (src/nodes/...), hash-consed by the reference and flattened 1:1: one record per
+ * distinct reference node; a/b/c are child node indices (CRH_NODE_NONE if absent). */
+#define CRH_NODE_NONE 0xFFFFFFFFu
+enum crh_node_kind {
+	/* bsdf nodes: src/nodes/shaders/ *.c */
+	CRH_BSDF_DIFFUSE = 1,   /* a=color                                   diffuse.c:40-47   */
+	CRH_BSDF_METAL,         /* a=color b=roughness(value)                metal.c:40-55     */
+	CRH_BSDF_GLASS,         /* a=color b=roughness(value) c=IOR(value)   glass.c:41-87     */
+	CRH_BSDF_PLASTIC,       /* a=color b=roughness(color) c=diffuse bsdf plastic.c:42-87   */
+	CRH_BSDF_MIX,           /* a=A b=B c=factor(value)                   mix.c:42-50       */
+	CRH_BSDF_ADD,           /* a=A b=B                                   add.c:42-49       */
+	CRH_BSDF_TRANSPARENT,   /* a=color                                   transparent.c:40-44 */
+	CRH_BSDF_EMISSION,      /* a=color b=strength(value)                 emission.c:42-49  */
+	CRH_BSDF_ISOTROPIC,     /* a=color                                   isotropic.c:40-47 */
+	CRH_BSDF_BACKGROUND,    /* a=color b=strength(value) c=offset(value) background.c:39-66 */
+	/* color nodes: src/nodes/textures, src/nodes/converter */
+	CRH_COLOR_CONSTANT = 32,/* f[0..3]=rgba                              constant.c:39-42  */
+	CRH_COLOR_IMAGE,        /* a=texture index (NONE = NULL tex) b=options image.c:31-68   */
+	CRH_COLOR_CHECKER,      /* a=A b=B c=scale(value)                    checker.c:31-74   */
+	CRH_COLOR_GRADIENT,     /* f[0..3]=down f[4..7]=up                   gradient.c:40-45  */
+	CRH_COLOR_BLACKBODY,    /* a=temperature(value)                      blackbody.c:38-42 */
+	CRH_COLOR_COMBINE,      /* a=value                                   combine.c:38-43   */
+	CRH_COLOR_COMBINERGB,   /* a=R b=G c=B (values)                      combinergb.c:42-51*/
+	CRH_COLOR_VECTOCOLOR,   /* a=vector                                  vectocolor.c:38-43*/
+	/* value nodes */
+	CRH_VALUE_CONSTANT = 64,/* f[0]                                      valuenode.c:36-40 */
+	CRH_VALUE_ALPHA,        /* a=color                                   alpha.c:38-41     */
+	CRH_VALUE_GRAYSCALE,    /* a=color                                   grayscale.c:38-41 */
+	CRH_VALUE_MATH,         /* a=A b=B c=op (enum mathOp, math.h:11-27)  math.c:42-95      */
+	CRH_VALUE_FRESNEL,      /* a=IOR(value) b=normal(vector, unused)     fresnel.c:38-51   */
+	CRH_VALUE_RAYLENGTH,    /*                                            raylength.c:36-40 */
+	/* vector nodes */
+	CRH_VEC_CONSTANT = 96,  /* f[0..2]                                   vectornode.c:38-42*/
+	CRH_VEC_NORMAL,         /*                                            normal.c:37-41    */
+	CRH_VEC_VECMATH         /* a=A b=B c=op (enum vecOp, vecmath.h:11-22) vecmath.c:42-81   */
+};
+#define CRH_IMAGE_SRGB_TRANSFORM 0x01u  /* src/nodes/textures/image.h:12 */
+#define CRH_IMAGE_NO_BILINEAR    0x02u  /* src/nodes/textures/image.h:13 */
+
+typedef struct crh_gnode {
+	uint32_t kind;
+	uint32_t a, b, c;
+	float    f[8];
+} crh_gnode;              /* 48 B */
+
+/* struct texture (src/datatypes/image/texture.h:25-36); pixel data lives in texture_data[offset..]. */
+typedef struct crh_texture {
+	uint64_t offset;      /* byte offset into texture_data, 16-byte aligned */
+	uint32_t width, height, channels;
+	uint32_t is_float;    /* precision == float_p */
+	uint32_t has_alpha;
+	uint32_t pad;
+} crh_texture;            /* 32 B */
+
+/* struct camera (src/datatypes/camera.h:15-33), fields read by getCameraRay (camera.c:58-87). */
+typedef struct crh_camera {
+	float   right[3], up[3], forward[3];
+	float   sensor[2];
+	float   aperture;
+	float   focal_distance;
+	int32_t width, height;
+	float   A[12];        /* composite.A rows 0..2 */
+} crh_camera;
+
+/* Everything renderFrame() can see in struct world + the global vertex buffers, as POD. */
+typedef struct crh_scene_desc {
+	uint32_t struct_size;     /* sizeof(crh_scene_desc), checked by crh_scene_upload */
+	uint32_t abi_version;     /* CRH_ABI_VERSION */
+
+	const crh_bvh_node *nodes;        uint64_t node_count;        /* all BLAS then the TLAS */
+	const int32_t      *prim_indices; uint64_t prim_index_count;
+	uint32_t tlas_node_base, tlas_node_count;                     /* scene->topLevel */
+	uint32_t tlas_prim_base, tlas_prim_count;
+
+	const crh_poly     *polys;        uint64_t poly_count;
+	const float        *vertices;     uint64_t vertex_count;      /* g_vertices, xyz       */
+	const float        *normals;      uint64_t normal_count;      /* g_normals, xyz        */
+	const float        *texcoords;    uint64_t texcoord_count;    /* g_textureCoords, xy   */
+
+	const crh_instance *instances;    uint64_t instance_count;
+	const crh_mesh     *meshes;       uint64_t mesh_count;
+	const crh_sphere   *spheres;      uint64_t sphere_count;
+	const crh_material *materials;    uint64_t material_count;
+	const crh_gnode    *gnodes;       uint64_t gnode_count;
+	const crh_texture  *textures;     uint64_t texture_count;
+	const uint8_t      *texture_data; uint64_t texture_bytes;
+
+	crh_camera camera;
+	uint32_t   background;    /* scene->background root in gnodes[] */
+	uint32_t   pad;
+} crh_scene_desc;
+
+/* One dispatch of the hot path: passes [first_pass, first_pass+pass_count) of every pixel of the
+ * region [x0,x1) x [y0,y1) (reference tile coordinates: y counts from the BOTTOM of the image,
+ * renderer.c:277-280), folded into the running mean exactly like renderer.c:288-291. */
+typedef struct crh_render_params {
+	int32_t x0, y0, x1, y1;
+	int32_t image_width, image_height;
+	int32_t first_pass;       /* completedSamples-1 of the first pass to run        */
+	int32_t pass_count;
+	int32_t max_passes;       /* prefs.sampleCount: part of the seed (sampler.c:42) */
+	int32_t bounces;          /* prefs.bounces                                      */
+} crh_render_params;
+
+/* Counters kept by the kernels (the N_* of the algorithmic-bytes formula). */
+typedef struct crh_counters {
+	uint64_t paths;           /* camera rays started                                  */
+	uint64_t rays;            /* getClosestIsect calls (pathtrace.c:26,38)            */
+	uint64_t node_tests;      /* intersectNode calls (bvh.c:326), TLAS + BLAS         */
+	uint64_t tri_tests;       /* rayIntersectsWithPolygon calls (poly.c:17)           */
+	uint64_t inst_visits;     /* instance.intersectFn calls from TLAS leaves          */
+	uint64_t inst_hits;       /* ... that returned true                               */
+	uint64_t sphere_tests;    /* rayIntersectsWithSphere calls                        */
+	uint64_t tex_fetches;     /* textureGetPixelInternal calls                        */
+} crh_counters;
+
+/* Closest-hit record returned by crh_trace_rays (test/diagnostic entry; = struct hitRecord,
+ * src/datatypes/hitrecord.h:14-23, after getClosestIsect). */
+typedef struct crh_hit {
+	int32_t  inst;            /* instIndex, -1 = miss                                 */
+	int32_t  poly;            /* polygon index in polys[], -1 for spheres / miss      */
+	float    distance;
+	float    uv[2];           /* texture-mapped uv (instance.c:150-167, 33-43)        */
+	float    point[3];        /* hitPoint, world space                                */
+	float    normal[3];       /* surfaceNormal, world space                           */
+	uint32_t node_tests;      /* per-ray intersectNode count                          */
+	uint32_t tri_tests;       /* per-ray triangle test count                          */
+	uint32_t material;        /* index in materials[] of the hit material             */
+} crh_hit;
+
+typedef struct crh_ctx crh_ctx;
+
+/* ---- entry points -------------------------------------------------------------------------- */
+
+/* Number of HIP devices visible, 0 if none (never negative). */
+int crh_device_count(void);
+/* Human-readable text for the most recent failure on this thread. */
+const char *crh_last_error(void);
+/* ABI version of the loaded library (== CRH_ABI_VERSION of the header it was built from). */
+int crh_abi_version(void);
+
+/* Create / destroy the per-GPU context. `stream` may be NULL (the context then creates its own
+ * stream) or an existing hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream). */
+int crh_context_create(int device, void *stream, crh_ctx **out);
+int crh_context_destroy(crh_ctx *ctx);
+
+/* Replaces "the CPU reads struct world directly": copies the flattened scene to HBM, derives the
+ * device-side acceleration layout (leaf-ordered prepared triangles) and validates the node graph. */
+int crh_scene_upload(crh_ctx *ctx, const crh_scene_desc *scene);
+
+/* Device float-RGB framebuffer helpers (layout = state.renderBuffer: index (x + (H-1-y)*W)*3,
+ * src/datatypes/image/texture.c:24-28). The framebuffer may also be any caller-owned device pointer. */
+int crh_framebuffer_alloc(crh_ctx *ctx, int width, int height, float **dev_out);
+int crh_framebuffer_free(crh_ctx *ctx, float *dev_fb);
+int crh_framebuffer_clear(crh_ctx *ctx, float *dev_fb, int width, int height);
+int crh_framebuffer_download(crh_ctx *ctx, const float *dev_fb, int width, int height, float *host_rgb);
+/* colorToSRGB + setPixel's 8-bit truncation (color.h:60-84, texture.c:18-22) of the float buffer. */
+int crh_framebuffer_to_srgb8(crh_ctx *ctx, const float *dev_fb, int width, int height, uint8_t *host_rgb8);
+
+/* THE hot path: replaces the renderThread() pixel x pass loop for one region (renderer.c:275-301).
+ * dev_fb is the device running-mean buffer; asynchronous on the context's stream. */
+int crh_render_region(crh_ctx *ctx, const crh_render_params *params, float *dev_fb);
+/* Same, for a LIST of rectangles in one dispatch (x0..y1 of `params` are ignored): this is how one
+ * GPU takes "its" tiles of the reference's ordered tile list (struct renderTile, tile.h:28-37) without
+ * one launch per tile. Tiles must not overlap. */
+typedef struct crh_tile { int32_t x0, y0, x1, y1; } crh_tile;
+int crh_render_tiles(crh_ctx *ctx, const crh_render_params *params, const crh_tile *tiles, uint32_t tile_count, float *dev_fb);
+/* Block until everything queued on the context's stream has finished. */
+int crh_synchronize(crh_ctx *ctx);
+
+/* Counters accumulated since the last reset (synchronises the stream). */
+int crh_counters_get(crh_ctx *ctx, crh_counters *out);
+int crh_counters_reset(crh_ctx *ctx);
+/* Duration in milliseconds of the most recent crh_render_region's path-tracing kernel, measured
+ * with HIP events on the context's stream; also the launch count and total since the last reset. */
+int crh_kernel_time_ms(crh_ctx *ctx, float *last_ms, double *total_ms, uint64_t *launches);
+
+/* Diagnostic / parity entry: getClosestIsect (pathtrace.c:26-30) for n caller-supplied world-space
+ * rays (6 floats each: start xyz, direction xyz). Host in, host out. */
+int crh_trace_rays(crh_ctx *ctx, const float *rays_host, uint64_t n, crh_hit *hits_host);
+
+/* Scene blob I/O (c-ray_amd/host/scene_blob.c): a flat file holding one crh_scene_desc, written by
+ * the flattener so that tests/bench can run where the reference loader and assets are absent. */
+typedef struct crh_blob_prefs {        /* the struct prefs fields the path needs (renderer.h:58-87) */
+	int32_t image_width, image_height, sample_count, bounces, tile_width, tile_height, tile_order, pad;
+} crh_blob_prefs;
+int  crh_blob_save(const char *path, const crh_scene_desc *scene, const crh_blob_prefs *prefs);
+int  crh_blob_load(const char *path, crh_scene_desc **scene_out, crh_blob_prefs *prefs_out);
+void crh_blob_free(crh_scene_desc *scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAY_HIP_H */

@@ -1,0 +1,54 @@
+/*
+ * flatten_main.c — `crh-flatten`: scene JSON -> flat scene blob, using the reference's own loader.
+ *
+ * Same front half as the reference's main (src/main.c:14-31: crInitialize, crParseArgs, crInitRenderer,
+ * read JSON from a file argument or stdin, crLoadSceneFromBuf), then instead of rendering it runs the
+ * product's flattener (c-ray_amd/host/flatten.c) and writes the blob named by $CRH_DUMP_SCENE.
+ * CLI overrides of the reference apply as usual (-s spp, -d WxH, -t WxH; src/utils/args.c:95-209).
+ * Built only where /root/reference exists (oracle/Makefile); the binary travels with the repo.
+ */
+#include <stdlib.h>
+#include <stdbool.h>
+#include <stdio.h>
+
+#include "c-ray.h"
+#include "renderer/renderer.h"
+#include "flatten.h"
+
+extern struct renderer *g_renderer;
+
+int main(int argc, char *argv[]) {
+	const char *outPath = getenv("CRH_DUMP_SCENE");
+	if (!outPath) {
+		fprintf(stderr, "crh-flatten: set CRH_DUMP_SCENE=<output blob path>\n");
+		return 2;
+	}
+	crInitialize();
+	crParseArgs(argc, argv);
+	crInitRenderer();
+	size_t bytes = 0;
+	char *input = crOptionIsSet("inputFile") ? crReadFile(&bytes) : crReadStdin(&bytes);
+	if (!input) {
+		fprintf(stderr, "crh-flatten: no input JSON\n");
+		return 1;
+	}
+	if (crLoadSceneFromBuf(input) != 0) {
+		fprintf(stderr, "crh-flatten: scene load failed\n");
+		return 1;
+	}
+	free(input);
+
+	crh_scene_desc desc;
+	int rc = crh_flatten_world(g_renderer, &desc);
+	if (rc != CRH_OK) {
+		fprintf(stderr, "crh-flatten: flatten failed (%d)\n", rc);
+		return 1;
+	}
+	crh_blob_prefs prefs = crh_flatten_prefs(g_renderer);
+	rc = crh_blob_save(outPath, &desc, &prefs);
+	fprintf(stderr, "crh-flatten: %llu nodes, %llu polys, %llu instances, %llu gnodes, %llu textures (%llu B) -> %s (%d)\n",
+			(unsigned long long)desc.node_count, (unsigned long long)desc.poly_count, (unsigned long long)desc.instance_count,
+			(unsigned long long)desc.gnode_count, (unsigned long long)desc.texture_count, (unsigned long long)desc.texture_bytes, outPath, rc);
+	crh_flatten_free(&desc);
+	return rc == CRH_OK ? 0 : 1;
+}

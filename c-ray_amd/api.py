@@ -1,0 +1,188 @@
+"""api.py — thin ctypes binding of libcray_hip.so (include/cray_hip.h).
+
+Plumbing, not the product: everything that computes lives behind the C-ABI in c-ray_amd/csrc. There is
+no CPU fallback here either: `library()` raises if the HIP library has not been built, and every call
+raises `CrhError` on a non-zero return code (the reference's convention is 0 = ok, negative = failure,
+src/datatypes/scene.c:122-134).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_lib", "libcray_hip.so")
+
+
+class CrhError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where} failed with {code}: {detail}")
+
+
+_lib = None
+
+
+def library():
+    """Load libcray_hip.so (built by c-ray_amd/build.py). Raises loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing: run `python c-ray_amd/build.py` "
+                                "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    ctx = C.c_void_p
+    sig = {
+        "crh_device_count": (C.c_int, []),
+        "crh_last_error": (C.c_char_p, []),
+        "crh_abi_version": (C.c_int, []),
+        "crh_context_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(ctx)]),
+        "crh_context_destroy": (C.c_int, [ctx]),
+        "crh_set_option": (C.c_int, [ctx, C.c_int, C.c_int64]),
+        "crh_scene_upload": (C.c_int, [ctx, C.POINTER(abi.SceneDesc)]),
+        "crh_framebuffer_alloc": (C.c_int, [ctx, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+        "crh_framebuffer_free": (C.c_int, [ctx, C.c_void_p]),
+        "crh_framebuffer_clear": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int]),
+        "crh_framebuffer_download": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+        "crh_framebuffer_to_srgb8": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+        "crh_render_region": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.c_void_p]),
+        "crh_render_tiles": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.POINTER(abi.Tile), C.c_uint32, C.c_void_p]),
+        "crh_synchronize": (C.c_int, [ctx]),
+        "crh_counters_get": (C.c_int, [ctx, C.POINTER(abi.Counters)]),
+        "crh_counters_reset": (C.c_int, [ctx]),
+        "crh_kernel_time_ms": (C.c_int, [ctx, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "crh_trace_rays": (C.c_int, [ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
+        "crh_blob_save": (C.c_int, [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.BlobPrefs)]),
+        "crh_blob_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(abi.SceneDesc)), C.POINTER(abi.BlobPrefs)]),
+        "crh_blob_free": (None, [C.POINTER(abi.SceneDesc)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise CrhError(rc, where, (library().crh_last_error() or b"").decode(errors="replace"))
+
+
+def device_count():
+    return library().crh_device_count()
+
+
+class Scene:
+    """A flat scene blob (written by the flattener, c-ray_amd/host/flatten.c) loaded through the library."""
+
+    def __init__(self, path):
+        self.path = path
+        self.ptr = C.POINTER(abi.SceneDesc)()
+        self.prefs = abi.BlobPrefs()
+        rc = library().crh_blob_load(os.fsencode(path), C.byref(self.ptr), C.byref(self.prefs))
+        if rc != 0:
+            raise CrhError(rc, f"crh_blob_load({path})")
+
+    @property
+    def desc(self):
+        return self.ptr.contents
+
+    def close(self):
+        if self.ptr:
+            library().crh_blob_free(self.ptr)
+            self.ptr = C.POINTER(abi.SceneDesc)()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One crh_ctx = one GPU. `stream` may be a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = library()
+        self.h = C.c_void_p()
+        _check(self.L.crh_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)),
+               "crh_context_create")
+        self._owned_fbs = []
+
+    def close(self):
+        if self.h:
+            for fb in self._owned_fbs:
+                self.L.crh_framebuffer_free(self.h, fb)
+            self._owned_fbs = []
+            self.L.crh_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option, value):
+        _check(self.L.crh_set_option(self.h, int(option), int(value)), "crh_set_option")
+
+    def upload(self, scene):
+        desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)
+        _check(self.L.crh_scene_upload(self.h, desc), "crh_scene_upload")
+
+    def framebuffer(self, width, height):
+        p = C.c_void_p()
+        _check(self.L.crh_framebuffer_alloc(self.h, width, height, C.byref(p)), "crh_framebuffer_alloc")
+        self._owned_fbs.append(p)
+        return p
+
+    def clear(self, fb, width, height):
+        _check(self.L.crh_framebuffer_clear(self.h, fb, width, height), "crh_framebuffer_clear")
+
+    def render_region(self, fb, width, height, samples, bounces, region=None, first_pass=0, pass_count=None):
+        x0, y0, x1, y1 = region if region else (0, 0, width, height)
+        p = abi.RenderParams(x0, y0, x1, y1, width, height, first_pass,
+                             samples - first_pass if pass_count is None else pass_count, samples, bounces)
+        _check(self.L.crh_render_region(self.h, C.byref(p), fb), "crh_render_region")
+
+    def render_tiles(self, fb, width, height, samples, bounces, tiles, first_pass=0, pass_count=None):
+        p = abi.RenderParams(0, 0, 0, 0, width, height, first_pass,
+                             samples - first_pass if pass_count is None else pass_count, samples, bounces)
+        arr = (abi.Tile * len(tiles))(*[abi.Tile(*t) for t in tiles])
+        _check(self.L.crh_render_tiles(self.h, C.byref(p), arr, len(tiles), fb), "crh_render_tiles")
+
+    def synchronize(self):
+        _check(self.L.crh_synchronize(self.h), "crh_synchronize")
+
+    def download(self, fb, width, height):
+        out = np.empty((height, width, 3), dtype=np.float32)
+        _check(self.L.crh_framebuffer_download(self.h, fb, width, height, out.ctypes.data), "crh_framebuffer_download")
+        return out
+
+    def to_srgb8(self, fb, width, height):
+        out = np.empty((height, width, 3), dtype=np.uint8)
+        _check(self.L.crh_framebuffer_to_srgb8(self.h, fb, width, height, out.ctypes.data), "crh_framebuffer_to_srgb8")
+        return out
+
+    def counters(self):
+        c = abi.Counters()
+        _check(self.L.crh_counters_get(self.h, C.byref(c)), "crh_counters_get")
+        return c.as_dict()
+
+    def reset_counters(self):
+        _check(self.L.crh_counters_reset(self.h), "crh_counters_reset")
+
+    def kernel_time_ms(self):
+        last, total, n = C.c_float(), C.c_double(), C.c_uint64()
+        _check(self.L.crh_kernel_time_ms(self.h, C.byref(last), C.byref(total), C.byref(n)), "crh_kernel_time_ms")
+        return last.value, total.value, n.value
+
+    def trace_rays(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        hits = np.zeros(len(rays), dtype=abi.HIT_DTYPE)
+        _check(self.L.crh_trace_rays(self.h, rays.ctypes.data, len(rays), hits.ctypes.data), "crh_trace_rays")
+        return hits

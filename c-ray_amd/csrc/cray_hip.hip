@@ -1,0 +1,537 @@
+/*
+ * cray_hip.hip — libcray_hip.so: the C-ABI of include/cray_hip.h and the gfx950 kernels behind it.
+ *
+ * Kernels (all hand-written for CDNA4, wave = 64):
+ *   k_pathtrace<LEVEL>   persistent-thread path tracer: one ray per lane, a lane owns a pixel for all of
+ *                        its passes (running mean folded in pass order, renderer.c:288-291) and pulls the
+ *                        next pixel from a global work counter with ONE atomic per wave (__ballot +
+ *                        readfirstlane), so lanes whose path ended are refilled in the same loop iteration
+ *                        instead of idling. Traversal stack in LDS (entry-major, conflict-free), deep
+ *                        stacks spill to a per-lane global slab.
+ *   k_trace_rays         getClosestIsect for caller rays (diagnostic / parity entry).
+ *   k_to_srgb8           colorToSRGB + setPixel truncation.
+ * No CPU fallback: every entry point fails with CRH_ERR_NO_DEVICE when there is no GPU.
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see c-ray_amd/build.py).
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "cray_hip.h"
+#include "pt_device.h"
+#include "scene_compile.h"
+
+using namespace crh;
+
+/* ---- tunables ---------------------------------------------------------------------------------- */
+#define CRH_BLOCK 256            /* 4 waves of 64 */
+#define CRH_STACK_LDS 24         /* traversal stack entries kept in LDS per lane (24 KB per block) */
+
+/* ---- error plumbing ---------------------------------------------------------------------------- */
+static thread_local std::string t_err;
+static int fail(int code, const std::string &msg) { t_err = msg; return code; }
+#define HIP_TRY(expr)                                                                               \
+	do {                                                                                            \
+		hipError_t e_ = (expr);                                                                     \
+		if (e_ != hipSuccess) return fail(CRH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+/* ---- device-side helpers ------------------------------------------------------------------------ */
+struct LdsStack {
+	uint32_t *lds;       /* &s_stack[threadIdx.x]; entry i at lds[i * CRH_BLOCK]: bank = lane % 32, conflict-free */
+	uint32_t *spill;     /* &spill[global thread]; entry j at spill[j * stride] (coalesced across lanes) */
+	uint32_t stride;
+	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
+		if (i < CRH_STACK_LDS) lds[i * CRH_BLOCK] = v;
+		else spill[(size_t)(i - CRH_STACK_LDS) * stride] = v;
+	}
+	__device__ __forceinline__ uint32_t pop(uint32_t i) {
+		if (i < CRH_STACK_LDS) return lds[i * CRH_BLOCK];
+		return spill[(size_t)(i - CRH_STACK_LDS) * stride];
+	}
+};
+
+/* Work queue over the pixels of a tile list. Item numbering: tiles in list order, inside a tile 8x8 pixel
+ * blocks in row-major order, 64 consecutive items = one block (so one wave-wide fetch = one 8x8 patch of
+ * coherent primary rays); items that fall outside a ragged tile edge are skipped. */
+struct TileWork {
+	const crh_tile *tiles;
+	const uint32_t *start;     /* start[t] = first item of tile t; start[ntiles] = total */
+	uint32_t ntiles, total;
+	uint32_t *counter;
+	__device__ __forceinline__ bool next(int &x, int &y) {
+		for (;;) {
+			/* wave-aggregated fetch: the lanes that need work are exactly the active ones here */
+			const unsigned long long mask = __ballot(1);
+			const uint32_t lane = __lane_id();
+			const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+			uint32_t base = 0;
+			if (rank == 0) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+			base = __builtin_amdgcn_readfirstlane(base);
+			const uint32_t item = base + rank;
+			if (item >= total) return false;
+			uint32_t lo = 0, hi = ntiles;           /* largest t with start[t] <= item */
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (start[mid] <= item) lo = mid; else hi = mid; }
+			const crh_tile t = tiles[lo];
+			const uint32_t local = item - start[lo];
+			const uint32_t w = (uint32_t)(t.x1 - t.x0), h = (uint32_t)(t.y1 - t.y0);
+			const uint32_t bw = (w + 7u) >> 3;
+			const uint32_t blk = local >> 6, in = local & 63u;
+			const uint32_t px = (blk % bw) * 8u + (in & 7u), py = (blk / bw) * 8u + (in >> 3);
+			if (px < w && py < h) { x = t.x0 + (int)px; y = t.y0 + (int)py; return true; }
+		}
+	}
+};
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v) {
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+	return v;
+}
+
+template <int LEVEL> struct CountersFor;
+template <> struct CountersFor<2> { typedef Counters type; };
+template <> struct CountersFor<1> { typedef LiteCounters type; };
+
+template <int LEVEL>
+__global__ __launch_bounds__(CRH_BLOCK) void k_pathtrace(const DScene S, const crh_render_params P, TileWork W, float *fb,
+														   unsigned long long *counters, uint32_t *spill, uint32_t spillStride) {
+	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	LdsStack stk;
+	stk.lds = &s_stack[threadIdx.x];
+	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
+	stk.stride = spillStride;
+	typename CountersFor<LEVEL>::type cnt;
+	memset(&cnt, 0, sizeof(cnt));
+	renderLane(S, P, stk, W, fb, cnt);
+	/* one atomic per wave and counter */
+	const bool lead = (__lane_id() == 0);
+	uint32_t v;
+	v = waveSum(cnt.paths); if (lead && v) atomicAdd(&counters[0], (unsigned long long)v);
+	v = waveSum(cnt.rays); if (lead && v) atomicAdd(&counters[1], (unsigned long long)v);
+	if constexpr (LEVEL >= 2) {
+		v = waveSum(cnt.node_tests); if (lead && v) atomicAdd(&counters[2], (unsigned long long)v);
+		v = waveSum(cnt.tri_tests); if (lead && v) atomicAdd(&counters[3], (unsigned long long)v);
+		v = waveSum(cnt.inst_visits); if (lead && v) atomicAdd(&counters[4], (unsigned long long)v);
+		v = waveSum(cnt.inst_hits); if (lead && v) atomicAdd(&counters[5], (unsigned long long)v);
+		v = waveSum(cnt.sphere_tests); if (lead && v) atomicAdd(&counters[6], (unsigned long long)v);
+		v = waveSum(cnt.tex_fetches); if (lead && v) atomicAdd(&counters[7], (unsigned long long)v);
+	}
+}
+
+__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene S, const float *rays, uint64_t n, crh_hit *hits, uint32_t *spill, uint32_t spillStride) {
+	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	LdsStack stk;
+	stk.lds = &s_stack[threadIdx.x];
+	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
+	stk.stride = spillStride;
+	for (uint64_t i = (uint64_t)blockIdx.x * CRH_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CRH_BLOCK) {
+		Counters cnt;
+		memset(&cnt, 0, sizeof(cnt));
+		const v3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+		TravHit h;
+		traverse(S, stk, o, d, h, cnt);
+		crh_hit out;
+		memset(&out, 0, sizeof(out));
+		out.inst = h.inst; out.distance = h.t; out.node_tests = cnt.node_tests; out.tri_tests = cnt.tri_tests;
+		if (h.inst < 0) {
+			out.poly = -1; out.material = CRH_NODE_NONE;
+		} else {
+			const HitInfo hi = finishHit(S, o, d, h);
+			out.poly = hi.poly; out.uv[0] = hi.uv.x; out.uv[1] = hi.uv.y;
+			out.point[0] = hi.point.x; out.point[1] = hi.point.y; out.point[2] = hi.point.z;
+			out.normal[0] = hi.normal.x; out.normal[1] = hi.normal.y; out.normal[2] = hi.normal.z;
+			out.material = hi.material;
+		}
+		hits[i] = out;
+	}
+}
+
+/* color.h:60-84 + texture.c:18-22 */
+__global__ void k_to_srgb8(const float *fb, size_t n, uint8_t *out) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const float v = linearToSRGB(fb[i]);
+		out[i] = (unsigned char)rmin(v * 255.0f, 255.0f);
+	}
+}
+
+/* ---- context ------------------------------------------------------------------------------------ */
+struct crh_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	int cuCount = 0;
+	int blocksPerCU = 4;
+	int counterLevel = 2;
+	bool haveScene = false;
+	DScene d;                              /* device pointers */
+	std::vector<void *> sceneAllocs;
+	uint32_t maxStack = 0;
+	unsigned long long *dCounters = nullptr;
+	uint32_t *dWork = nullptr;             /* ring of work counters, one per in-flight launch */
+	uint32_t workSlot = 0;
+	uint32_t *dSpill = nullptr;
+	size_t spillEntries = 0;
+	std::vector<void *> deferredFrees;     /* per-launch tile lists: freed once the stream has drained */
+	struct Timed { hipEvent_t a, b; };
+	std::vector<Timed> pendingTimes;
+	std::vector<Timed> eventPool;
+	float lastMs = 0.0f;
+	double totalMs = 0.0;
+	uint64_t launches = 0;
+};
+#define CRH_WORK_SLOTS 64
+
+static int setDevice(crh_ctx *c) {
+	HIP_TRY(hipSetDevice(c->device));
+	return CRH_OK;
+}
+
+static void freeScene(crh_ctx *c) {
+	for (void *p : c->sceneAllocs) (void)hipFree(p);
+	c->sceneAllocs.clear();
+	c->haveScene = false;
+}
+
+static int resolveTimes(crh_ctx *c, bool wait) {
+	size_t done = 0;
+	for (auto &t : c->pendingTimes) {
+		if (wait) HIP_TRY(hipEventSynchronize(t.b));
+		else if (hipEventQuery(t.b) != hipSuccess) break;
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+		c->lastMs = ms;
+		c->totalMs += ms;
+		c->eventPool.push_back(t);
+		++done;
+	}
+	c->pendingTimes.erase(c->pendingTimes.begin(), c->pendingTimes.begin() + done);
+	return CRH_OK;
+}
+
+template <class T>
+static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
+	void *p = nullptr;
+	const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+	HIP_TRY(hipMalloc(&p, bytes));
+	c->sceneAllocs.push_back(p);
+	if (count) HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+	else HIP_TRY(hipMemset(p, 0, bytes));
+	*dev = (const T *)p;
+	return CRH_OK;
+}
+
+extern "C" {
+
+int crh_abi_version(void) { return CRH_ABI_VERSION; }
+const char *crh_last_error(void) { return t_err.c_str(); }
+
+int crh_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n < 0 ? 0 : n;
+}
+
+int crh_context_create(int device, void *stream, crh_ctx **out) {
+	if (!out) return fail(CRH_ERR_INVALID, "crh_context_create: out is NULL");
+	*out = nullptr;
+	const int n = crh_device_count();
+	if (n <= 0) return fail(CRH_ERR_NO_DEVICE, "no HIP device visible (libcray_hip has no CPU fallback)");
+	if (device < 0 || device >= n) return fail(CRH_ERR_INVALID, "device index out of range");
+	crh_ctx *c = new (std::nothrow) crh_ctx();
+	if (!c) return fail(CRH_ERR_NOMEM, "out of host memory");
+	c->device = device;
+	hipError_t e = hipSetDevice(device);
+	hipDeviceProp_t prop;
+	if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+	if (e == hipSuccess) {
+		c->cuCount = prop.multiProcessorCount;
+		if (stream) c->stream = (hipStream_t)stream;
+		else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->ownStream = (e == hipSuccess); }
+	}
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
+	if (e != hipSuccess) {
+		const std::string msg = std::string("crh_context_create: ") + hipGetErrorString(e);
+		crh_context_destroy(c);
+		return fail(CRH_ERR_HIP, msg);
+	}
+	const char *env = getenv("CRH_BLOCKS_PER_CU");
+	if (env && atoi(env) > 0) c->blocksPerCU = atoi(env);
+	*out = c;
+	return CRH_OK;
+}
+
+int crh_context_destroy(crh_ctx *c) {
+	if (!c) return CRH_OK;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	freeScene(c);
+	for (void *p : c->deferredFrees) (void)hipFree(p);
+	for (auto &t : c->pendingTimes) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	for (auto &t : c->eventPool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	if (c->dCounters) (void)hipFree(c->dCounters);
+	if (c->dWork) (void)hipFree(c->dWork);
+	if (c->dSpill) (void)hipFree(c->dSpill);
+	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+	return CRH_OK;
+}
+
+int crh_set_option(crh_ctx *c, int option, int64_t value) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_set_option: ctx is NULL");
+	switch (option) {
+		case CRH_OPT_COUNTER_LEVEL:
+			if (value < 1 || value > 2) return fail(CRH_ERR_INVALID, "counter level must be 1 or 2");
+			c->counterLevel = (int)value; return CRH_OK;
+		case CRH_OPT_BLOCKS_PER_CU:
+			if (value < 1 || value > 8) return fail(CRH_ERR_INVALID, "blocks per CU must be 1..8");
+			c->blocksPerCU = (int)value; return CRH_OK;
+		default: return fail(CRH_ERR_INVALID, "unknown option");
+	}
+}
+
+int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
+	if (!c || !scene) return fail(CRH_ERR_INVALID, "crh_scene_upload: NULL argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	CompiledScene cs;
+	std::string err;
+	rc = compile_scene(scene, cs, err);
+	if (rc != CRH_OK) return fail(rc, "crh_scene_upload: " + err);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	freeScene(c);
+	DScene d;
+	memset(&d, 0, sizeof(d));
+#define UP(field, ptr, count) do { rc = upload(c, ptr, count, &d.field); if (rc) { freeScene(c); return rc; } } while (0)
+	UP(nodes, cs.nodes.data(), cs.nodes.size());
+	UP(tris, cs.tris.data(), cs.tris.size());
+	UP(prims, scene->prim_indices, (size_t)scene->prim_index_count);
+	UP(polys, scene->polys, (size_t)scene->poly_count);
+	UP(vertices, scene->vertices, (size_t)scene->vertex_count * 3);
+	UP(normals, scene->normals, (size_t)scene->normal_count * 3);
+	UP(texcoords, scene->texcoords, (size_t)scene->texcoord_count * 2);
+	UP(instances, cs.instances.data(), cs.instances.size());
+	UP(meshes, scene->meshes, (size_t)scene->mesh_count);
+	UP(materials, scene->materials, (size_t)scene->material_count);
+	UP(bsdfs, cs.bsdfs.data(), cs.bsdfs.size());
+	UP(consts, cs.consts.data(), cs.consts.size());
+	UP(images, cs.images.data(), cs.images.size());
+	UP(prog, cs.prog.data(), cs.prog.size());
+	UP(textures, scene->textures, (size_t)scene->texture_count);
+	UP(texdata, scene->texture_data, (size_t)scene->texture_bytes);
+#undef UP
+	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base;
+	d.background = cs.background; d.camera = cs.camera;
+	c->d = d;
+	c->maxStack = cs.max_stack;
+	c->haveScene = true;
+	return CRH_OK;
+}
+
+int crh_framebuffer_alloc(crh_ctx *c, int width, int height, float **dev_out) {
+	if (!c || !dev_out || width <= 0 || height <= 0) return fail(CRH_ERR_INVALID, "crh_framebuffer_alloc: bad argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	void *p = nullptr;
+	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	HIP_TRY(hipMalloc(&p, bytes));
+	HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));
+	*dev_out = (float *)p;
+	return CRH_OK;
+}
+
+int crh_framebuffer_free(crh_ctx *c, float *dev_fb) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_framebuffer_free: ctx is NULL");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (dev_fb) HIP_TRY(hipFree(dev_fb));
+	return CRH_OK;
+}
+
+int crh_framebuffer_clear(crh_ctx *c, float *dev_fb, int width, int height) {
+	if (!c || !dev_fb || width <= 0 || height <= 0) return fail(CRH_ERR_INVALID, "crh_framebuffer_clear: bad argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(dev_fb, 0, (size_t)width * height * 3 * sizeof(float), c->stream));
+	return CRH_OK;
+}
+
+int crh_framebuffer_download(crh_ctx *c, const float *dev_fb, int width, int height, float *host_rgb) {
+	if (!c || !dev_fb || !host_rgb || width <= 0 || height <= 0) return fail(CRH_ERR_INVALID, "crh_framebuffer_download: bad argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(host_rgb, dev_fb, (size_t)width * height * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return CRH_OK;
+}
+
+int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int height, uint8_t *host_rgb8) {
+	if (!c || !dev_fb || !host_rgb8 || width <= 0 || height <= 0) return fail(CRH_ERR_INVALID, "crh_framebuffer_to_srgb8: bad argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	const size_t n = (size_t)width * height * 3;
+	uint8_t *tmp = nullptr;
+	HIP_TRY(hipMalloc((void **)&tmp, n));
+	const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+	hipLaunchKernelGGL(k_to_srgb8, dim3(grid), dim3(256), 0, c->stream, dev_fb, n, tmp);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(host_rgb8, tmp, n, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void)hipFree(tmp);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_framebuffer_to_srgb8: ") + hipGetErrorString(e));
+	return CRH_OK;
+}
+
+static int ensureSpill(crh_ctx *c, uint32_t threads) {
+	const size_t extra = c->maxStack > CRH_STACK_LDS ? (size_t)(c->maxStack - CRH_STACK_LDS) : 0;
+	const size_t need = std::max<size_t>(extra * threads, 1);
+	if (need <= c->spillEntries) return CRH_OK;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (c->dSpill) HIP_TRY(hipFree(c->dSpill));
+	c->dSpill = nullptr; c->spillEntries = 0;
+	HIP_TRY(hipMalloc((void **)&c->dSpill, need * sizeof(uint32_t)));
+	c->spillEntries = need;
+	return CRH_OK;
+}
+
+int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, float *dev_fb) {
+	if (!c || !P || !dev_fb || (!tiles && tile_count)) return fail(CRH_ERR_INVALID, "crh_render_tiles: NULL argument");
+	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_render_tiles: no scene uploaded");
+	if (P->image_width <= 0 || P->image_height <= 0 || P->pass_count < 0 || P->first_pass < 0 || P->max_passes < P->first_pass + P->pass_count)
+		return fail(CRH_ERR_INVALID, "crh_render_tiles: bad render parameters");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	(void)resolveTimes(c, false);
+	if (c->pendingTimes.empty()) { for (void *p : c->deferredFrees) (void)hipFree(p); c->deferredFrees.clear(); }
+	std::vector<uint32_t> start(tile_count + 1, 0);
+	uint64_t total = 0;
+	for (uint32_t t = 0; t < tile_count; ++t) {
+		const crh_tile &r = tiles[t];
+		if (r.x0 < 0 || r.y0 < 0 || r.x1 > P->image_width || r.y1 > P->image_height || r.x0 > r.x1 || r.y0 > r.y1)
+			return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
+		start[t] = (uint32_t)total;
+		total += (uint64_t)((r.x1 - r.x0 + 7) / 8) * ((r.y1 - r.y0 + 7) / 8) * 64u;
+		if (total > 0xFFFFFFF0ull) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: more than 2^32 work items in one dispatch");
+	}
+	start[tile_count] = (uint32_t)total;
+	if (total == 0 || P->pass_count == 0) return CRH_OK;
+
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (total + CRH_BLOCK - 1) / CRH_BLOCK);
+	rc = ensureSpill(c, grid * CRH_BLOCK);
+	if (rc) return rc;
+
+	/* per-launch tile list in HBM (freed once the stream has drained) */
+	void *dTiles = nullptr;
+	const size_t tileBytes = tile_count * sizeof(crh_tile), startBytes = (tile_count + 1) * sizeof(uint32_t);
+	HIP_TRY(hipMalloc(&dTiles, tileBytes + startBytes));
+	c->deferredFrees.push_back(dTiles);
+	HIP_TRY(hipMemcpy(dTiles, tiles, tileBytes, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy((char *)dTiles + tileBytes, start.data(), startBytes, hipMemcpyHostToDevice));
+
+	TileWork W;
+	W.tiles = (const crh_tile *)dTiles;
+	W.start = (const uint32_t *)((char *)dTiles + tileBytes);
+	W.ntiles = tile_count;
+	W.total = (uint32_t)total;
+	W.counter = c->dWork + (c->workSlot++ % CRH_WORK_SLOTS);
+	HIP_TRY(hipMemsetAsync(W.counter, 0, sizeof(uint32_t), c->stream));
+
+	crh_ctx::Timed ev;
+	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
+	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
+	HIP_TRY(hipEventRecord(ev.a, c->stream));
+	if (c->counterLevel >= 2)
+		hipLaunchKernelGGL(k_pathtrace<2>, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, W, dev_fb, c->dCounters, c->dSpill, grid * CRH_BLOCK);
+	else
+		hipLaunchKernelGGL(k_pathtrace<1>, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, W, dev_fb, c->dCounters, c->dSpill, grid * CRH_BLOCK);
+	hipError_t e = hipGetLastError();
+	HIP_TRY(hipEventRecord(ev.b, c->stream));
+	c->pendingTimes.push_back(ev);
+	c->launches++;
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_pathtrace launch: ") + hipGetErrorString(e));
+	return CRH_OK;
+}
+
+int crh_render_region(crh_ctx *c, const crh_render_params *P, float *dev_fb) {
+	if (!P) return fail(CRH_ERR_INVALID, "crh_render_region: params is NULL");
+	const crh_tile t{P->x0, P->y0, P->x1, P->y1};
+	return crh_render_tiles(c, P, &t, 1, dev_fb);
+}
+
+int crh_synchronize(crh_ctx *c) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_synchronize: ctx is NULL");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	rc = resolveTimes(c, true);
+	for (void *p : c->deferredFrees) (void)hipFree(p);
+	c->deferredFrees.clear();
+	return rc;
+}
+
+int crh_counters_get(crh_ctx *c, crh_counters *out) {
+	if (!c || !out) return fail(CRH_ERR_INVALID, "crh_counters_get: NULL argument");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	unsigned long long h[8];
+	HIP_TRY(hipMemcpy(h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
+	out->paths = h[0]; out->rays = h[1]; out->node_tests = h[2]; out->tri_tests = h[3];
+	out->inst_visits = h[4]; out->inst_hits = h[5]; out->sphere_tests = h[6]; out->tex_fetches = h[7];
+	return CRH_OK;
+}
+
+int crh_counters_reset(crh_ctx *c) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_counters_reset: ctx is NULL");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	HIP_TRY(hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long)));
+	c->lastMs = 0.0f; c->totalMs = 0.0; c->launches = 0;
+	return CRH_OK;
+}
+
+int crh_kernel_time_ms(crh_ctx *c, float *last_ms, double *total_ms, uint64_t *launches) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_kernel_time_ms: ctx is NULL");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	rc = resolveTimes(c, true);
+	if (rc) return rc;
+	if (last_ms) *last_ms = c->lastMs;
+	if (total_ms) *total_ms = c->totalMs;
+	if (launches) *launches = c->launches;
+	return CRH_OK;
+}
+
+int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits_host) {
+	if (!c || (!rays_host && n) || (!hits_host && n)) return fail(CRH_ERR_INVALID, "crh_trace_rays: NULL argument");
+	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_trace_rays: no scene uploaded");
+	if (n == 0) return CRH_OK;
+	int rc = setDevice(c);
+	if (rc) return rc;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (n + CRH_BLOCK - 1) / CRH_BLOCK);
+	rc = ensureSpill(c, grid * CRH_BLOCK);
+	if (rc) return rc;
+	float *dRays = nullptr;
+	crh_hit *dHits = nullptr;
+	hipError_t e = hipMalloc((void **)&dRays, n * 6 * sizeof(float));
+	if (e == hipSuccess) e = hipMalloc((void **)&dHits, n * sizeof(crh_hit));
+	if (e == hipSuccess) e = hipMemcpyAsync(dRays, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, dRays, n, dHits, c->dSpill, grid * CRH_BLOCK);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(hits_host, dHits, n * sizeof(crh_hit), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (dRays) (void)hipFree(dRays);
+	if (dHits) (void)hipFree(dHits);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_trace_rays: ") + hipGetErrorString(e));
+	return CRH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,942 @@
+/*
+ * pt_device.h — lane-level logic of the MI355X path-tracing kernels (one ray per lane).
+ *
+ * Everything here is written from scratch for the flattened scene (include/cray_hip.h); each block
+ * cites the reference function (file:line under /root/reference/src) whose RESULT it must reproduce.
+ * The float expressions keep the reference's operand order; the translation unit is compiled with
+ * -ffp-contract=off so that only the explicit fmaf() of the slab test fuses (bvh.c:318-324, where
+ * FP_FAST_FMAF is defined for the reference build), and with correctly rounded fp32 divide/sqrt.
+ *
+ * The same header compiles for the device (hipcc, the product: csrc/cray_hip.hip) and for the host
+ * (g++, tests/emu/ only: a lane-by-lane emulation that lets the CPU-only test tier check the kernel
+ * logic bit-for-bit against the oracle). The host build is never linked into libcray_hip.so.
+ */
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+#include "cray_hip.h"
+
+#if defined(__HIPCC__)
+#define CRH_DEV __device__ __forceinline__
+#define CRH_DEV_NOINLINE __device__ __noinline__
+#else
+#define CRH_DEV static inline __attribute__((always_inline))
+#define CRH_DEV_NOINLINE static __attribute__((noinline))
+#endif
+
+namespace crh {
+
+#define CRH_PI 3.141592653589793238462643383279502f        /* includes.h:13 */
+#define CRH_NONE 0xFFFFFFFFu
+
+struct alignas(16) f4 { float x, y, z, w; };
+struct v3 { float x, y, z; };
+struct v2 { float x, y; };
+struct rgba { float r, g, b, a; };
+
+/* ---- device-side scene ----------------------------------------------------------------------- */
+
+/* One instance visit reads exactly this 128-B record (N_instVisit). */
+struct alignas(16) DInstance {
+	float Ainv[12];
+	float A[12];
+	uint32_t kind;        /* CRH_INSTANCE_* */
+	uint32_t object;      /* mesh / sphere index */
+	uint32_t root;        /* mesh: device index of the BLAS root's child pair (or of the root leaf if node_count == 1) */
+	uint32_t node_count;  /* mesh: bvh->nodeCount                                            */
+	float    ray_offset;  /* mesh->rayOffset / sphere->rayOffset                             */
+	float    radius;      /* sphere                                                          */
+	uint32_t material;    /* sphere: material index; mesh: material_base                     */
+	uint32_t poly_base;   /* mesh: first polygon in polys[]                                  */
+};
+
+/* pure-node operand reference (compiled at upload, see cray_hip.hip: compile_operand) */
+#define CRH_OPR_CONST   0u   /* index into consts[] (f4)                       */
+#define CRH_OPR_IMAGE   1u   /* index into images[]                            */
+#define CRH_OPR_PROGRAM 2u   /* offset into prog[]                             */
+#define CRH_OPR(kind, idx) (((uint32_t)(kind) << 30) | (uint32_t)(idx))
+#define CRH_OPR_KIND(r) ((r) >> 30)
+#define CRH_OPR_IDX(r)  ((r) & 0x3FFFFFFFu)
+
+struct DImage { uint32_t tex; uint32_t options; };
+
+/* postfix program op: dst = op(src...) over a small operand file of f4 slots */
+struct alignas(16) DOp {
+	uint16_t kind;        /* enum crh_node_kind of the pure node, or CRH_OP_END */
+	uint8_t  dst, s0, s1, s2;
+	uint16_t pad;
+	uint32_t u;           /* image index / math op / vec op */
+	uint32_t cidx;        /* constants: index into consts[] */
+};
+#define CRH_OP_END 0xFFFFu
+#define CRH_PROG_SLOTS 8
+
+/* bsdf node compiled 1:1 from crh_gnode: a/b/c are bsdf indices or operand refs depending on kind */
+struct alignas(16) DBsdf { uint32_t kind, a, b, c; };
+
+struct DScene {
+	const f4 *nodes;            /* 2 x f4 per node; node i of a BVH lives at device index base+1+i (child pairs 64-B aligned) */
+	const f4 *tris;             /* 3 x f4 per BLAS prim slot: v0, e1, e2, n (poly.c:20-22 precomputed with the same fp32 ops) */
+	const int32_t *prims;       /* prim_indices verbatim: TLAS slots -> instance index, BLAS slots -> polygon index in mesh */
+	const crh_poly *polys;
+	const float *vertices, *normals, *texcoords;
+	const DInstance *instances;
+	const crh_mesh *meshes;
+	const crh_material *materials;
+	const DBsdf *bsdfs;         /* indexed by gnode index (only bsdf-kind entries are meaningful) */
+	const f4 *consts;
+	const DImage *images;
+	const DOp *prog;
+	const crh_texture *textures;
+	const uint8_t *texdata;
+	uint32_t tlas_root;         /* device index of the TLAS root's child pair (or of the root leaf if tlas_node_count == 1) */
+	uint32_t tlas_node_count;
+	uint32_t tlas_prim_base;
+	uint32_t background;        /* gnode index of the background bsdf */
+	crh_camera camera;
+};
+
+/* Counter levels: 0 none, 1 rays + paths only (timed runs), 2 everything (parity / roofline runs). */
+struct Counters {
+	static constexpr int level = 2;
+	uint32_t rays, node_tests, tri_tests, inst_visits, inst_hits, sphere_tests, tex_fetches, paths;
+};
+struct LiteCounters {
+	static constexpr int level = 1;
+	uint32_t rays, paths;
+};
+struct NoCounters { static constexpr int level = 0; };
+template <class T> struct cnt_traits { static constexpr int level = T::level; };
+template <class T> struct cnt_traits<T &> { static constexpr int level = T::level; };
+/* CRH_COUNT: detailed counters (level 2); CRH_COUNT1: rays / paths (level >= 1) */
+#define CRH_COUNT(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 2) (c).field += (n); } while (0)
+#define CRH_COUNT1(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 1) (c).field += (n); } while (0)
+
+/* ---- vector.h / color.h ---------------------------------------------------------------------- */
+CRH_DEV v3 vadd(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+CRH_DEV v3 vsub(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+CRH_DEV v3 vmul(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+CRH_DEV float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+CRH_DEV v3 vscale(v3 v, float c) { return v3{v.x * c, v.y * c, v.z * c}; }
+CRH_DEV v3 vcross(v3 a, v3 b) { return v3{(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)}; }
+CRH_DEV float vlen(v3 v) { return sqrtf(vdot(v, v)); }
+CRH_DEV v3 vnorm(v3 v) { float l = vlen(v); return v3{v.x / l, v.y / l, v.z / l}; }
+CRH_DEV v3 vneg(v3 v) { return v3{-v.x, -v.y, -v.z}; }
+CRH_DEV v3 vreflect(v3 I, v3 N) { return vsub(I, vscale(N, vdot(N, I) * 2.0f)); }
+CRH_DEV float wrapMax(float x, float mx) { return fmodf(mx + fmodf(x, mx), mx); }
+CRH_DEV float wrapMinMax(float x, float mn, float mx) { return mn + wrapMax(x - mn, mx - mn); }
+CRH_DEV float rmin(float a, float b) { return a < b ? a : b; }     /* includes.h:20 */
+CRH_DEV float rmax(float a, float b) { return a > b ? a : b; }     /* includes.h:21 */
+
+CRH_DEV rgba cmul(rgba a, rgba b) { return rgba{a.r * b.r, a.g * b.g, a.b * b.b, a.a * b.a}; }
+CRH_DEV rgba cadd(rgba a, rgba b) { return rgba{a.r + b.r, a.g + b.g, a.b + b.b, a.a + b.a}; }
+CRH_DEV rgba ccoef(float c, rgba a) { return rgba{a.r * c, a.g * c, a.b * c, a.a * c}; }
+CRH_DEV rgba cmix(rgba c1, rgba c2, float k) { return cadd(ccoef(1.0f - k, c1), ccoef(k, c2)); }   /* color.h:46 */
+CRH_DEV float linearToSRGB(float c) {                                                               /* color.h:51 */
+	if (c <= 0.0031308f) return 12.92f * c;
+	return (1.055f * powf(c, 0.4166666667f)) - 0.055f;
+}
+CRH_DEV float SRGBToLinear(float c) {                                                               /* color.h:59 */
+	if (c <= 0.04045f) return c / 12.92f;
+	return powf(((c + 0.055f) / 1.055f), 2.4f);
+}
+/* color.h:37-40: 0.587 is a double constant, so the sum is carried in double */
+CRH_DEV float grayscaleOf(rgba c) {
+	return sqrtf((float)(0.299f * powf(c.r, 2.0f) + 0.587 * (double)powf(c.g, 2.0f) + (double)(0.114f * powf(c.b, 2.0f))));
+}
+/* color.c:27-70 */
+CRH_DEV rgba colorForKelvin(float kelvin) {
+	float r, g, b;
+	float temp = kelvin >= 40000.0f ? 40000.0f : kelvin;
+	temp = temp / 100.0f;
+	if (temp <= 66.0f) {
+		r = 255.0f;
+	} else {
+		r = temp - 60.0f;
+		r = 329.698727446f * powf(r, -0.1332047592f);
+		r = r < 0.0f ? 0.0f : r;
+		r = r > 255.0f ? 255.0f : r;
+	}
+	if (temp <= 66.0f) {
+		g = temp;
+		g = 99.4708025861f * logf(g) - 161.1195681661f;
+	} else {
+		g = temp - 60.0f;
+		g = 288.1221695283f * powf(g, -0.0755148492f);
+	}
+	g = g < 0.0f ? 0.0f : g;
+	g = g > 255.0f ? 255.0f : g;
+	if (temp >= 66.0f) {
+		b = 255.0f;
+	} else if (temp <= 19.0f) {
+		b = 0.0f;
+	} else {
+		b = temp - 10.0f;
+		b = 138.5177312231f * logf(b) - 305.0447927307f;
+		b = b < 0.0f ? 0.0f : b;
+		b = b > 255.0f ? 255.0f : b;
+	}
+	return rgba{r / 255.0f, g / 255.0f, b / 255.0f, 0.0f};
+}
+
+/* ---- sampler: pcg_basic.c:42-68, samplers/common.h:22-27, sampler.c:41-44, random.c:12-21 ----- */
+struct Rng { uint64_t state; };   /* inc is always 1 (stream 0) */
+CRH_DEV uint32_t pcg32_next(Rng &r) {
+	uint64_t old = r.state;
+	r.state = old * 6364136223846793005ULL + 1ULL;
+	uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+	uint32_t rot = (uint32_t)(old >> 59u);
+	return (xs >> rot) | (xs << ((0u - rot) & 31u));
+}
+CRH_DEV uint64_t hash64(uint64_t x) {
+	x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+	x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+	x = x ^ (x >> 31);
+	return x;
+}
+CRH_DEV void initSampler(Rng &r, int pass, int maxPasses, uint32_t pixelIndex) {
+	uint32_t key = pixelIndex * (uint32_t)maxPasses + (uint32_t)pass;   /* 32-bit wrap: sampler.c:42 */
+	r.state = 0u;
+	pcg32_next(r);
+	r.state += hash64((uint64_t)key);
+	pcg32_next(r);
+}
+CRH_DEV float getDimension(Rng &r) { return (1.0f / 4294967296.0f) * (float)pcg32_next(r); }
+
+/* vector.h:190-198 */
+CRH_DEV v2 randomCoordOnUnitDisc(Rng &rng) {
+	float r = sqrtf(getDimension(rng));
+	float theta = ((getDimension(rng)) * ((2.0f * CRH_PI) - 0.0f)) + 0.0f;
+	return v2{r * cosf(theta), r * sinf(theta)};
+}
+/* vector.h:243-249 */
+CRH_DEV v3 randomOnUnitSphere(Rng &rng) {
+	const float sample_x = getDimension(rng);
+	const float sample_y = getDimension(rng);
+	const float a = sample_x * (2.0f * CRH_PI);
+	const float s = 2.0f * sqrtf(rmax(0.0f, sample_y * (1.0f - sample_y)));
+	return v3{cosf(a) * s, sinf(a) * s, 1.0f - 2.0f * sample_y};
+}
+/* vector.h:251-266 */
+CRH_DEV bool refract(v3 in, v3 normal, float niOverNt, v3 &refracted) {
+	const v3 uv = vnorm(in);
+	const float dt = vdot(uv, normal);
+	const float discriminant = 1.0f - niOverNt * niOverNt * (1.0f - dt * dt);
+	if (discriminant > 0.0f) {
+		const v3 A = vscale(normal, dt);
+		const v3 B = vsub(uv, A);
+		const v3 C = vscale(B, niOverNt);
+		const v3 D = vscale(normal, sqrtf(discriminant));
+		refracted = vsub(C, D);
+		return true;
+	}
+	return false;
+}
+/* vector.h:268-272 */
+CRH_DEV float schlick(float cosine, float IOR) {
+	float r0 = (1.0f - IOR) / (1.0f + IOR);
+	r0 = r0 * r0;
+	return r0 + (1.0f - r0) * powf((1.0f - cosine), 5.0f);
+}
+
+/* ---- transforms.c:76-116 on 3x4 row-major matrices --------------------------------------------- */
+CRH_DEV v3 xfPoint(v3 v, const float *m) {
+	return v3{(m[0] * v.x) + (m[1] * v.y) + (m[2] * v.z) + m[3],
+			  (m[4] * v.x) + (m[5] * v.y) + (m[6] * v.z) + m[7],
+			  (m[8] * v.x) + (m[9] * v.y) + (m[10] * v.z) + m[11]};
+}
+CRH_DEV v3 xfVector(v3 v, const float *m) {
+	return v3{(m[0] * v.x) + (m[1] * v.y) + (m[2] * v.z),
+			  (m[4] * v.x) + (m[5] * v.y) + (m[6] * v.z),
+			  (m[8] * v.x) + (m[9] * v.y) + (m[10] * v.z)};
+}
+CRH_DEV v3 xfVectorT(v3 v, const float *m) {
+	return v3{(m[0] * v.x) + (m[4] * v.y) + (m[8] * v.z),
+			  (m[1] * v.x) + (m[5] * v.y) + (m[9] * v.z),
+			  (m[2] * v.x) + (m[6] * v.y) + (m[10] * v.z)};
+}
+CRH_DEV v3 alongRay(v3 o, v3 d, float t) { return vadd(o, vscale(d, t)); }   /* lightray.h:31 */
+
+/* ---- camera.c:46-87 ---------------------------------------------------------------------------- */
+CRH_DEV float triangleDistribution(float v) {
+	const float orig = v * 2.0f - 1.0f;
+	v = orig / sqrtf(fabsf(orig));
+	v = rmin(rmax(v, -1.0f), 1.0f);          /* clamp(): vector.h:55 = min(max(value, min), max) */
+	v = v - ((orig >= 0.0f) ? 1.0f : -1.0f);
+	return v;
+}
+CRH_DEV void getCameraRay(const crh_camera &cam, Rng &rng, int x, int y, v3 &ro, v3 &rd) {
+	const v3 right = v3{cam.right[0], cam.right[1], cam.right[2]};
+	const v3 up = v3{cam.up[0], cam.up[1], cam.up[2]};
+	const v3 forward = v3{cam.forward[0], cam.forward[1], cam.forward[2]};
+	v3 start = v3{0.0f, 0.0f, 0.0f};
+	const float jitterX = triangleDistribution(getDimension(rng));
+	const float jitterY = triangleDistribution(getDimension(rng));
+	v3 pixX = vscale(right, (cam.sensor[0] / (float)cam.width));
+	v3 pixY = vscale(up, (cam.sensor[1] / (float)cam.height));
+	v3 pixV = vadd(forward, vadd(vscale(pixX, (float)x - (float)cam.width * 0.5f + jitterX + 0.5f),
+								 vscale(pixY, (float)y - (float)cam.height * 0.5f + jitterY + 0.5f)));
+	v3 dir = vnorm(pixV);
+	if (cam.aperture > 0.0f) {
+		float ft = cam.focal_distance / vdot(dir, forward);
+		v3 focusPoint = alongRay(start, dir, ft);
+		v2 disc = randomCoordOnUnitDisc(rng);
+		v2 lensPoint = v2{disc.x * cam.aperture, disc.y * cam.aperture};
+		start = vadd(start, vadd(vscale(right, lensPoint.x), vscale(up, lensPoint.y)));
+		dir = vnorm(vsub(focusPoint, start));
+	}
+	ro = xfPoint(start, cam.A);
+	rd = xfVector(dir, cam.A);
+}
+
+/* ---- textures: texture.c:32-79 ----------------------------------------------------------------- */
+/* (size_t)i % W for a possibly negative int i (sign-extended to 64 bits like the reference's cast) */
+CRH_DEV uint32_t wrapIndex(int i, uint32_t W) {
+	if (i >= 0) return (uint32_t)i % W;
+	return (uint32_t)((uint64_t)(int64_t)i % (uint64_t)W);
+}
+template <class Cnt>
+CRH_DEV rgba texel(const DScene &S, const crh_texture &t, uint32_t x, uint32_t y, Cnt &cnt) {
+	CRH_COUNT(cnt, tex_fetches, 1);
+	const uint8_t *bytes = S.texdata + t.offset;
+	const float *floats = (const float *)bytes;
+	const uint32_t W = t.width, H = t.height, C = t.channels;
+	const size_t base = ((size_t)x + (size_t)((H - 1u) - y) * (size_t)W) * (size_t)C;
+	rgba o;
+	if (C == 1u) {
+		o.r = t.is_float ? floats[base] : (float)bytes[base] / 255.0f;
+		o.g = o.r; o.b = o.r; o.a = 1.0f;
+	} else if (t.is_float) {
+		o.r = floats[base + 0]; o.g = floats[base + 1]; o.b = floats[base + 2];
+		o.a = t.has_alpha ? floats[base + 3] : 1.0f;
+	} else {
+		o.r = (float)bytes[base + 0] / 255.0f; o.g = (float)bytes[base + 1] / 255.0f; o.b = (float)bytes[base + 2] / 255.0f;
+		o.a = t.has_alpha ? (float)bytes[base + 3] / 255.0f : 1.0f;
+	}
+	return o;
+}
+template <class Cnt>
+CRH_DEV rgba textureGetPixelFiltered(const DScene &S, const crh_texture &t, float x, float y, Cnt &cnt) {
+	x = x * (float)t.width;
+	y = y * (float)t.height;
+	float xcopy = x - 0.5f;
+	float ycopy = y - 0.5f;
+	int xint = (int)xcopy;
+	int yint = (int)ycopy;
+	const uint32_t x0 = wrapIndex(xint, t.width), x1 = wrapIndex(xint + 1, t.width);
+	const uint32_t y0 = wrapIndex(yint, t.height), y1 = wrapIndex(yint + 1, t.height);
+	rgba topleft = texel(S, t, x0, y0, cnt);
+	rgba topright = texel(S, t, x1, y0, cnt);
+	rgba botleft = texel(S, t, x0, y1, cnt);
+	rgba botright = texel(S, t, x1, y1, cnt);
+	const float fx = xcopy - (float)xint, fy = ycopy - (float)yint;
+	return cmix(cmix(topleft, topright, fx), cmix(botleft, botright, fx), fy);
+}
+/* image.c:31-48 */
+template <class Cnt>
+CRH_DEV rgba evalImage(const DScene &S, const DImage &im, v2 uv, Cnt &cnt) {
+	if (im.tex == CRH_NONE) return rgba{1.0f, 0.0f, 0.5f, 1.0f};   /* warningMaterial().diffuse, material.c:38 */
+	const crh_texture t = S.textures[im.tex];
+	rgba out;
+	if (im.options & CRH_IMAGE_NO_BILINEAR) {
+		float x = uv.x * (float)t.width;
+		float y = uv.y * (float)t.height;
+		out = texel(S, t, (uint32_t)((unsigned long long)x % t.width), (uint32_t)((unsigned long long)y % t.height), cnt);
+	} else {
+		out = textureGetPixelFiltered(S, t, uv.x, uv.y, cnt);
+	}
+	if (im.options & CRH_IMAGE_SRGB_TRANSFORM) out = rgba{SRGBToLinear(out.r), SRGBToLinear(out.g), SRGBToLinear(out.b), out.a};
+	return out;
+}
+
+/* ---- shading record (struct hitRecord, hitrecord.h:14-23, as the nodes read it) --------------- */
+struct ShadeRec {
+	v3 dir;        /* incident.direction */
+	v3 point;      /* hitPoint           */
+	v3 normal;     /* surfaceNormal      */
+	v2 uv;
+	float distance;
+	float ior;     /* material.IOR       */
+};
+
+/* ---- pure nodes (colour / value / vector): postfix programs compiled at upload ---------------- */
+template <class Cnt>
+CRH_DEV_NOINLINE f4 runProgram(const DScene &S, uint32_t pc, const ShadeRec &rec, Cnt &cnt) {
+	f4 slot[CRH_PROG_SLOTS];
+	for (;;) {
+		const DOp op = S.prog[pc++];
+		if (op.kind == CRH_OP_END) return slot[op.s0];
+		const f4 a = slot[op.s0], b = slot[op.s1], c = slot[op.s2];
+		f4 r = f4{0.0f, 0.0f, 0.0f, 0.0f};
+		switch (op.kind) {
+			case CRH_COLOR_CONSTANT: case CRH_VALUE_CONSTANT: case CRH_VEC_CONSTANT:
+				r = S.consts[op.cidx]; break;
+			case CRH_COLOR_IMAGE: {
+				rgba o = evalImage(S, S.images[op.u], rec.uv, cnt);
+				r = f4{o.r, o.g, o.b, o.a}; break;
+			}
+			case CRH_COLOR_CHECKER: {          /* checker.c:31-54; a=A b=B c=scale (all already evaluated: pure) */
+				const float coef = c.x;
+				float sines;
+				if (rec.uv.x >= 0.0f) sines = sinf(coef * rec.uv.x) * sinf(coef * rec.uv.y);
+				else sines = sinf(coef * rec.point.x) * sinf(coef * rec.point.y) * sinf(coef * rec.point.z);
+				r = sines < 0.0f ? a : b; break;
+			}
+			case CRH_COLOR_GRADIENT: {         /* gradient.c:40-45; consts[cidx]=down, consts[cidx+1]=up */
+				v3 unitDir = vnorm(rec.dir);
+				float t = 0.5f * (unitDir.y + 1.0f);
+				const f4 dn = S.consts[op.cidx], up = S.consts[op.cidx + 1];
+				rgba o = cadd(ccoef(1.0f - t, rgba{dn.x, dn.y, dn.z, dn.w}), ccoef(t, rgba{up.x, up.y, up.z, up.w}));
+				r = f4{o.r, o.g, o.b, o.a}; break;
+			}
+			case CRH_COLOR_BLACKBODY: { rgba o = colorForKelvin(a.x); r = f4{o.r, o.g, o.b, o.a}; break; }
+			case CRH_COLOR_COMBINE: r = f4{a.x, a.x, a.x, 1.0f}; break;
+			case CRH_COLOR_COMBINERGB: r = f4{a.x, b.x, c.x, 1.0f}; break;
+			case CRH_COLOR_VECTOCOLOR: r = f4{a.x, a.y, a.z, 0.0f}; break;
+			case CRH_VALUE_ALPHA: r.x = a.w; break;
+			case CRH_VALUE_GRAYSCALE: r.x = grayscaleOf(rgba{a.x, a.y, a.z, a.w}); break;
+			case CRH_VALUE_RAYLENGTH: r.x = rec.distance; break;
+			case CRH_VALUE_FRESNEL: {          /* fresnel.c:38-51 */
+				const float IOR = a.x;
+				float cosine;
+				if (vdot(rec.dir, rec.normal) > 0.0f) cosine = IOR * vdot(rec.dir, rec.normal) / vlen(rec.dir);
+				else cosine = -(vdot(rec.dir, rec.normal) / vlen(rec.dir));
+				r.x = schlick(cosine, IOR); break;
+			}
+			case CRH_VALUE_MATH: {             /* math.c:42-95 */
+				const float x = a.x, y = b.x;
+				switch (op.u) {
+					case 0: r.x = x + y; break;
+					case 1: r.x = x - y; break;
+					case 2: r.x = x * y; break;
+					case 3: r.x = x / y; break;
+					case 4: r.x = powf(x, y); break;
+					case 5: r.x = log10f(x); break;
+					case 6: r.x = sqrtf(x); break;
+					case 7: r.x = fabsf(x); break;
+					case 8: r.x = rmin(x, y); break;
+					case 9: r.x = rmax(x, y); break;
+					case 10: r.x = sinf(x); break;
+					case 11: r.x = cosf(x); break;
+					case 12: r.x = tanf(x); break;
+					case 13: r.x = (x * CRH_PI) / 180.0f; break;
+					case 14: r.x = x * (180.0f / CRH_PI); break;
+					default: break;
+				}
+				break;
+			}
+			case CRH_VEC_NORMAL: r = f4{rec.normal.x, rec.normal.y, rec.normal.z, 0.0f}; break;
+			case CRH_VEC_VECMATH: {            /* vecmath.c:42-81 (dot / length return their float in .f, the vector is zero) */
+				const v3 x = v3{a.x, a.y, a.z}, y = v3{b.x, b.y, b.z};
+				v3 o = v3{0.0f, 0.0f, 0.0f};
+				switch (op.u) {
+					case 0: o = vadd(x, y); break;
+					case 1: o = vsub(x, y); break;
+					case 2: o = vmul(x, y); break;
+					case 3: o = vscale(vadd(x, y), 0.5f); break;
+					case 5: o = vcross(x, y); break;
+					case 6: o = vnorm(x); break;
+					case 7: o = vreflect(x, y); break;
+					case 9: o = v3{fabsf(x.x), fabsf(x.y), fabsf(x.z)}; break;
+					default: break;
+				}
+				r = f4{o.x, o.y, o.z, 0.0f}; break;
+			}
+			default: break;
+		}
+		slot[op.dst] = r;
+	}
+}
+
+template <class Cnt>
+CRH_DEV rgba evalColor(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
+	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
+	if (k == CRH_OPR_CONST) { const f4 c = S.consts[i]; return rgba{c.x, c.y, c.z, c.w}; }
+	if (k == CRH_OPR_IMAGE) return evalImage(S, S.images[i], rec.uv, cnt);
+	const f4 c = runProgram(S, i, rec, cnt);
+	return rgba{c.x, c.y, c.z, c.w};
+}
+template <class Cnt>
+CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
+	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
+	if (k == CRH_OPR_CONST) return S.consts[i].x;
+	return runProgram(S, i, rec, cnt).x;
+}
+
+/* ---- bsdf nodes: src/nodes/shaders ----------------------------------------------------------- */
+struct BsdfSample { v3 out; float r, g, b; };   /* bsdfnode.h:19-23; colour alpha never reaches RGB (pathtrace.c:51-57) */
+#define CRH_ADD_DEPTH 4
+
+template <class Cnt>
+CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &rec, Rng &rng, Cnt &cnt) {
+	uint32_t addStack[CRH_ADD_DEPTH];      /* pending add.c frames: gnode index | (A done ? 1<<31 : 0) */
+	BsdfSample resStack[CRH_ADD_DEPTH];
+	int asp = 0, rsp = 0;
+	uint32_t cur = root;
+	for (;;) {
+		const DBsdf n = S.bsdfs[cur];
+		BsdfSample res;
+		rgba col = rgba{0.0f, 0.0f, 0.0f, 0.0f};
+		res.out = v3{0.0f, 0.0f, 0.0f};
+		switch (n.kind) {
+			case CRH_BSDF_MIX: {          /* mix.c:42-50 */
+				const float lerp = evalValue(S, n.c, rec, cnt);
+				cur = (getDimension(rng) > lerp) ? n.a : n.b;
+				continue;
+			}
+			case CRH_BSDF_ADD: {          /* add.c:42-49: A fully, then B fully */
+				if (asp < CRH_ADD_DEPTH) addStack[asp++] = cur;
+				cur = n.a;
+				continue;
+			}
+			case CRH_BSDF_PLASTIC: {      /* plastic.c:42-87 */
+				v3 outwardNormal;
+				float niOverNt, reflectionProbability, cosine;
+				v3 refracted;
+				if (vdot(rec.dir, rec.normal) > 0.0f) {
+					outwardNormal = vneg(rec.normal);
+					niOverNt = rec.ior;
+					cosine = rec.ior * vdot(rec.dir, rec.normal) / vlen(rec.dir);
+				} else {
+					outwardNormal = rec.normal;
+					niOverNt = 1.0f / rec.ior;
+					cosine = -(vdot(rec.dir, rec.normal) / vlen(rec.dir));
+				}
+				if (refract(rec.dir, outwardNormal, niOverNt, refracted)) reflectionProbability = schlick(cosine, rec.ior);
+				else reflectionProbability = 1.0f;
+				if (getDimension(rng) < reflectionProbability) {
+					v3 reflected = vreflect(rec.dir, rec.normal);
+					float roughness = evalColor(S, n.b, rec, cnt).r;
+					if (roughness > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), roughness));
+					res.out = reflected;
+					col = rgba{1.0f, 1.0f, 1.0f, 1.0f};
+					break;
+				}
+				cur = n.c;
+				continue;
+			}
+			case CRH_BSDF_DIFFUSE:        /* diffuse.c:40-47 */
+				res.out = vnorm(vadd(rec.normal, randomOnUnitSphere(rng)));
+				col = evalColor(S, n.a, rec, cnt);
+				break;
+			case CRH_BSDF_METAL: {        /* metal.c:40-55 */
+				v3 reflected = vreflect(vnorm(rec.dir), rec.normal);
+				float roughness = evalValue(S, n.b, rec, cnt);
+				if (roughness > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), roughness));
+				res.out = reflected;
+				col = evalColor(S, n.a, rec, cnt);
+				break;
+			}
+			case CRH_BSDF_GLASS: {        /* glass.c:41-87 */
+				v3 outwardNormal;
+				v3 reflected = vreflect(rec.dir, rec.normal);
+				float niOverNt, reflectionProbability, cosine;
+				v3 refracted = v3{0.0f, 0.0f, 0.0f};
+				const float IOR = evalValue(S, n.c, rec, cnt);
+				if (vdot(rec.dir, rec.normal) > 0.0f) {
+					outwardNormal = vneg(rec.normal);
+					niOverNt = IOR;
+					cosine = IOR * vdot(rec.dir, rec.normal) / vlen(rec.dir);
+				} else {
+					outwardNormal = rec.normal;
+					niOverNt = 1.0f / IOR;
+					cosine = -(vdot(rec.dir, rec.normal) / vlen(rec.dir));
+				}
+				if (refract(rec.dir, outwardNormal, niOverNt, refracted)) reflectionProbability = schlick(cosine, IOR);
+				else reflectionProbability = 1.0f;
+				const float roughness = evalValue(S, n.b, rec, cnt);
+				if (roughness > 0.0f) {
+					v3 fuzz = vscale(randomOnUnitSphere(rng), roughness);
+					reflected = vadd(reflected, fuzz);
+					refracted = vadd(refracted, fuzz);
+				}
+				res.out = (getDimension(rng) < reflectionProbability) ? reflected : refracted;
+				col = evalColor(S, n.a, rec, cnt);
+				break;
+			}
+			case CRH_BSDF_TRANSPARENT:    /* transparent.c:40-44 */
+				res.out = rec.dir;
+				col = evalColor(S, n.a, rec, cnt);
+				break;
+			case CRH_BSDF_EMISSION:       /* emission.c:42-49 */
+				res.out = vnorm(vadd(rec.normal, randomOnUnitSphere(rng)));
+				col = ccoef(evalValue(S, n.b, rec, cnt), evalColor(S, n.a, rec, cnt));
+				break;
+			case CRH_BSDF_ISOTROPIC:      /* isotropic.c:40-47 */
+				res.out = vnorm(randomOnUnitSphere(rng));
+				col = evalColor(S, n.a, rec, cnt);
+				break;
+			default:                      /* background as a surface bsdf never happens; unknown kinds are rejected at upload */
+				break;
+		}
+		res.r = col.r; res.g = col.g; res.b = col.b;
+		/* unwind pending add frames */
+		for (;;) {
+			if (asp == 0) return res;
+			const uint32_t top = addStack[asp - 1];
+			if (!(top & 0x80000000u)) {
+				resStack[rsp++] = res;
+				addStack[asp - 1] = top | 0x80000000u;
+				cur = S.bsdfs[top].b;
+				break;
+			}
+			const BsdfSample A = resStack[--rsp];
+			res.out = vadd(A.out, res.out);
+			res.r = A.r + res.r; res.g = A.g + res.g; res.b = A.b + res.b;
+			--asp;
+		}
+	}
+}
+
+/* background.c:39-66 (on a miss): rec.dir = incident direction, everything else zero */
+template <class Cnt>
+CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
+	const DBsdf n = S.bsdfs[S.background];
+	v3 ud = vnorm(rec.dir);
+	float phi = (atan2f(ud.z, ud.x) / 4.0f) + evalValue(S, n.c, rec, cnt);
+	float theta = acosf((-ud.y / 1.0f));
+	float u = theta / CRH_PI;
+	float v = (phi / (CRH_PI / 2.0f));
+	u = wrapMinMax(u, 0.0f, 1.0f);
+	v = wrapMinMax(v, 0.0f, 1.0f);
+	rec.uv = v2{v, u};
+	float strength = evalValue(S, n.b, rec, cnt);
+	return ccoef(strength, evalColor(S, n.a, rec, cnt));
+}
+
+/* ---- intersection ------------------------------------------------------------------------------ */
+struct RayK { v3 o, d, inv, ss; uint32_t oct; };
+CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
+	RayK k;
+	k.o = o; k.d = d;
+	k.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u);
+	k.inv = v3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+	k.ss = vscale(vmul(o, k.inv), -1.0f);
+	return k;
+}
+/* bvh.c:326-352; n0 = {minx,maxx,miny,maxy}, n1 = {minz,maxz,first,countLeaf} */
+CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDist, float &tEntry) {
+	const bool ox = k.oct & 1u, oy = k.oct & 2u, oz = k.oct & 4u;
+	float tMinX = __builtin_fmaf(ox ? n0.y : n0.x, k.inv.x, k.ss.x);
+	float tMaxX = __builtin_fmaf(ox ? n0.x : n0.y, k.inv.x, k.ss.x);
+	float tMinY = __builtin_fmaf(oy ? n0.w : n0.z, k.inv.y, k.ss.y);
+	float tMaxY = __builtin_fmaf(oy ? n0.z : n0.w, k.inv.y, k.ss.y);
+	float tMinZ = __builtin_fmaf(oz ? n1.y : n1.x, k.inv.z, k.ss.z);
+	float tMaxZ = __builtin_fmaf(oz ? n1.x : n1.y, k.inv.z, k.ss.z);
+	float tMin = tMinX > tMinY ? tMinX : tMinY;
+	float tMax = tMaxX < tMaxY ? tMaxX : tMaxY;
+	tMin = tMin > tMinZ ? tMin : tMinZ;
+	tMax = tMax < tMaxZ ? tMax : tMaxZ;
+	tMin = tMin > 0.0f ? tMin : 0.0f;
+	tMax = tMax < maxDist ? tMax : maxDist;
+	tEntry = tMin;
+	return tMin <= tMax;
+}
+CRH_DEV uint32_t asU32(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+CRH_DEV float asF32(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+#define CRH_DNODE_FIRST(n1) asU32((n1).z)
+#define CRH_DNODE_COUNT(n1) (asU32((n1).w) & 0x3FFFFFFFu)
+#define CRH_DNODE_ISLEAF(n1) ((asU32((n1).w) >> 30) & 1u)
+
+struct TravHit {
+	float t;           /* isect->distance */
+	float u, v;        /* barycentrics of the closest triangle (isect->uv before getTexMapMesh) */
+	int32_t slot;      /* BLAS prim slot of the closest triangle, -1 for spheres / miss */
+	int32_t inst;      /* isect->instIndex */
+};
+
+/*
+ * getClosestIsect (pathtrace.c:26-30) -> traverseTopLevelBvh (bvh.c:488-496) as ONE loop per lane:
+ * the TLAS walk, the per-instance ray transform (instance.c:45-60,169-185) and the BLAS walk
+ * (bvh.c:354-441) share the node-step code so that lanes at different levels stay in the same
+ * instruction stream. Order of every box / triangle / instance test is the reference's: both children
+ * tested with the old maxDist, leaf children intersected left then right before descending, nearer
+ * inner child first (bvh.c:397-436). Hit attributes are derived after the walk (finishHit).
+ *
+ * Stack: LDS-resident (device) / local array (host emulation); entries are device node indices, plus
+ * the saved TLAS state (resume node + pending instance ranges) while a lane is inside a BLAS.
+ */
+template <class Stack, class Cnt>
+CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 wo, const v3 wd, TravHit &hit, Cnt &cnt) {
+	hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.slot = -1; hit.inst = -1;
+	CRH_COUNT1(cnt, rays, 1);
+	if (S.tlas_node_count < 1u) return;                                   /* bvh.c:362-365 */
+	RayK k = makeRayK(wo, wd);
+	uint32_t node = CRH_NONE;         /* device index of the child PAIR tested next (children are adjacent: bvh.c:393-394) */
+	uint32_t pA = 0, pAe = 0, pB = 0, pBe = 0;   /* pending leaf prim ranges [p, pe) at the current level: left leaf, right leaf */
+	uint32_t sp = 0, spBase = 0;
+	bool inBlas = false, instFound = false;
+	int32_t curInst = -1;
+
+	if (S.tlas_node_count == 1u) {                                          /* bvh.c:382-387 */
+		const f4 n0 = S.nodes[2u * S.tlas_root], n1 = S.nodes[2u * S.tlas_root + 1u];
+		float tE;
+		CRH_COUNT(cnt, node_tests, 1);
+		if (intersectNode(n0, n1, k, hit.t, tE)) { pA = CRH_DNODE_FIRST(n1); pAe = pA + CRH_DNODE_COUNT(n1); }
+	} else {
+		node = S.tlas_root;
+	}
+
+	for (;;) {
+		if (pA != pAe && inBlas) {
+			/* ---- triangle test: poly.c:17-53 on the prepared record ---- */
+			const uint32_t slot = pA++;
+			if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
+			const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
+			const v3 v0 = v3{q0.x, q0.y, q0.z}, e1 = v3{q0.w, q1.x, q1.y}, e2 = v3{q1.z, q1.w, q2.x}, n = v3{q2.y, q2.z, q2.w};
+			CRH_COUNT(cnt, tri_tests, 1);
+			const v3 c = vsub(v0, k.o);
+			const v3 r = vcross(k.d, c);
+			const float invDet = 1.0f / vdot(n, k.d);
+			const float u = vdot(r, e2) * invDet;
+			const float v = vdot(r, e1) * invDet;
+			if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
+				const float t = vdot(n, c) * invDet;
+				if (t >= 0.0f && t < hit.t) { hit.t = t; hit.u = u; hit.v = v; hit.slot = (int32_t)slot; instFound = true; }
+			}
+			continue;
+		}
+		if (pA == pAe && node != CRH_NONE) {
+			/* ---- node step: bvh.c:391-436 (only once the pending leaf prims of the previous step are done) ---- */
+			const uint32_t c0 = node;
+			const f4 l0 = S.nodes[2u * c0], l1 = S.nodes[2u * c0 + 1u], r0 = S.nodes[2u * c0 + 2u], r1 = S.nodes[2u * c0 + 3u];
+			float tL, tR;
+			CRH_COUNT(cnt, node_tests, 2);
+			const bool hitL = intersectNode(l0, l1, k, hit.t, tL);
+			const bool hitR = intersectNode(r0, r1, k, hit.t, tR);
+			const bool leafL = CRH_DNODE_ISLEAF(l1), leafR = CRH_DNODE_ISLEAF(r1);
+			pA = pAe = pB = pBe = 0;
+			if (hitL && leafL) { pA = CRH_DNODE_FIRST(l1); pAe = pA + CRH_DNODE_COUNT(l1); }
+			if (hitR && leafR) {
+				const uint32_t f = CRH_DNODE_FIRST(r1), e = f + CRH_DNODE_COUNT(r1);
+				if (pA != pAe) { pB = f; pBe = e; } else { pA = f; pAe = e; }
+			}
+			const bool inL = hitL && !leafL, inR = hitR && !leafR;
+			const uint32_t cl = CRH_DNODE_FIRST(l1), cr = CRH_DNODE_FIRST(r1);
+			if (inL && inR) {
+				const bool swap = tL > tR;
+				node = swap ? cr : cl;
+				stk.push(sp++, swap ? cl : cr);
+			} else if (inL || inR) {
+				node = inL ? cl : cr;
+			} else {
+				node = CRH_NONE;
+			}
+			continue;
+		}
+		if (inBlas) {
+			if (sp > spBase) { node = stk.pop(--sp); continue; }
+			/* ---- BLAS exhausted: back to the TLAS (bvh.c:468-486 loop body tail) ---- */
+			if (instFound) { hit.inst = curInst; CRH_COUNT(cnt, inst_hits, 1); }
+			inBlas = false;
+			pBe = stk.pop(--sp); pB = stk.pop(--sp); pAe = stk.pop(--sp); pA = stk.pop(--sp); node = stk.pop(--sp);
+			k = makeRayK(wo, wd);
+			continue;
+		}
+		if (pA != pAe) {
+			/* ---- TLAS leaf: next instance (bvh.c:472-484) ---- */
+			const uint32_t slot = pA++;
+			if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
+			const int32_t idx = S.prims[slot];       /* leaf.first is already an absolute prim slot */
+			const DInstance *inst = &S.instances[idx];
+			CRH_COUNT(cnt, inst_visits, 1);
+			/* transformRay(Ainv) + offset: instance.c:46-50 / 170-174 */
+			v3 o = xfPoint(wo, inst->Ainv);
+			const v3 d = xfVector(wd, inst->Ainv);
+			o = vadd(o, vscale(d, inst->ray_offset));
+			if (inst->kind == CRH_INSTANCE_SPHERE) {
+				/* sphere.c:20-50 */
+				CRH_COUNT(cnt, sphere_tests, 1);
+				const float A = vdot(d, d);
+				const float B = 2.0f * vdot(d, o);
+				const float C = vdot(o, o) - (inst->radius * inst->radius);
+				const float disc = B * B - 4.0f * A * C;
+				if (!(disc < 0.0f)) {
+					const float sq = sqrtf(disc);
+					float t0 = (-B + sq) / 2.0f;
+					const float t1 = (-B - sq) / 2.0f;
+					if (t0 > t1 && t1 > 0.0f) t0 = t1;
+					if (!(t0 < 0.00001f || t0 > hit.t)) {
+						hit.t = t0; hit.slot = -1; hit.inst = idx;
+						CRH_COUNT(cnt, inst_hits, 1);
+					}
+				}
+				continue;
+			}
+			if (inst->node_count < 1u) { hit.inst = -1; continue; }             /* bvh.c:362-365 via instance.c:175 */
+			const RayK ko = makeRayK(o, d);
+			if (inst->node_count == 1u) {                                         /* bvh.c:382-387 */
+				const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
+				float tE;
+				CRH_COUNT(cnt, node_tests, 1);
+				if (!intersectNode(n0, n1, ko, hit.t, tE)) continue;
+				stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
+				node = CRH_NONE;
+				pA = CRH_DNODE_FIRST(n1); pAe = pA + CRH_DNODE_COUNT(n1); pB = pBe = 0;
+			} else {
+				stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
+				node = inst->root;
+				pA = pAe = pB = pBe = 0;
+			}
+			spBase = sp; inBlas = true; instFound = false; curInst = idx; k = ko;
+			continue;
+		}
+		if (sp > 0u) { node = stk.pop(--sp); continue; }
+		break;
+	}
+}
+
+/* Hit attributes after the walk: exactly what instance.c:45-60 / 169-185 + poly.c:37-48 leave in the record. */
+struct HitInfo {
+	v3 point, normal;
+	v2 uv;
+	uint32_t material;
+	int32_t poly;       /* index into polys[], -1 for spheres */
+};
+CRH_DEV v3 loadV3(const float *base, int64_t i) { const float *p = base + 3 * i; return v3{p[0], p[1], p[2]}; }
+CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravHit &hit) {
+	HitInfo h;
+	const DInstance *inst = &S.instances[hit.inst];
+	v3 o = xfPoint(wo, inst->Ainv);
+	const v3 d = xfVector(wd, inst->Ainv);
+	o = vadd(o, vscale(d, inst->ray_offset));
+	const v3 objPoint = alongRay(o, d, hit.t);
+	if (inst->kind == CRH_INSTANCE_SPHERE) {
+		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
+		/* getTexMapSphere: instance.c:33-43 (object-space normal) */
+		float phi = atan2f(n.z, n.x);
+		float theta = asinf(n.y);
+		float v = (theta + CRH_PI / 2.0f) / CRH_PI;
+		float u = 1.0f - (phi + CRH_PI) / (CRH_PI * 2.0f);
+		u = wrapMinMax(u, 0.0f, 1.0f);
+		v = wrapMinMax(v, 0.0f, 1.0f);
+		h.uv = v2{u, v};
+		h.poly = -1;
+		h.material = inst->material;
+		h.point = xfPoint(objPoint, inst->A);
+		h.normal = xfVectorT(n, inst->Ainv);                      /* not renormalised: instance.c:56 */
+		return h;
+	}
+	const int32_t p = (int32_t)inst->poly_base + S.prims[hit.slot];
+	const crh_poly poly = S.polys[p];
+	const float u = hit.u, v = hit.v;
+	const float w = 1.0f - u - v;
+	v3 n;
+	if (CRH_POLY_HASNORMALS(poly)) {                              /* poly.c:40-44 */
+		const v3 upcomp = vscale(loadV3(S.normals, poly.n[1]), u);
+		const v3 vpcomp = vscale(loadV3(S.normals, poly.n[2]), v);
+		const v3 wpcomp = vscale(loadV3(S.normals, poly.n[0]), w);
+		n = vadd(vadd(upcomp, vpcomp), wpcomp);
+	} else {                                                      /* poly.c:45-47: un-normalised e1 x e2 */
+		const f4 q2 = S.tris[3u * (uint32_t)hit.slot + 2u];
+		n = v3{q2.y, q2.z, q2.w};
+	}
+	/* getTexMapMesh: instance.c:150-167 */
+	const crh_mesh *mesh = &S.meshes[inst->object];
+	if (mesh->texcoord_count == 0u || poly.t[0] == -1) {
+		h.uv = v2{-1.0f, -1.0f};
+	} else {
+		const float *T = S.texcoords;
+		const v2 t1 = v2{T[2 * (int64_t)poly.t[1]], T[2 * (int64_t)poly.t[1] + 1]};
+		const v2 t2 = v2{T[2 * (int64_t)poly.t[2]], T[2 * (int64_t)poly.t[2] + 1]};
+		const v2 t0 = v2{T[2 * (int64_t)poly.t[0]], T[2 * (int64_t)poly.t[0] + 1]};
+		h.uv = v2{((t1.x * u) + (t2.x * v)) + (t0.x * w), ((t1.y * u) + (t2.y * v)) + (t0.y * w)};
+	}
+	h.poly = p;
+	h.material = inst->material + CRH_POLY_MATERIAL(poly);
+	h.point = xfPoint(objPoint, inst->A);
+	h.normal = vnorm(xfVectorT(n, inst->Ainv));                   /* instance.c:180-181 */
+	return h;
+}
+
+/* ---- one path: pathtrace.c:32-60, flattened to one bounce per call ------------------------------ */
+struct PathState {
+	v3 ro, rd;
+	float wr, wg, wb;      /* weight (alpha never reaches RGB) */
+	float fr, fg, fb;      /* finalColor                        */
+	int depth;
+	Rng rng;
+};
+
+/* One iteration of the pathTrace() loop body. Returns true when the path is complete. */
+template <class Stack, class Cnt>
+CRH_DEV bool bounceStep(const DScene &S, Stack &stk, PathState &p, int maxDepth, Cnt &cnt) {
+	TravHit hit;
+	traverse(S, stk, p.ro, p.rd, hit, cnt);
+	ShadeRec rec;
+	rec.dir = p.rd;
+	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */
+		rec.point = v3{0.0f, 0.0f, 0.0f}; rec.normal = v3{0.0f, 0.0f, 0.0f}; rec.uv = v2{0.0f, 0.0f};
+		rec.distance = hit.t; rec.ior = 0.0f;
+		const rgba bg = sampleBackground(S, rec, cnt);
+		p.fr = p.fr + (p.wr * bg.r); p.fg = p.fg + (p.wg * bg.g); p.fb = p.fb + (p.wb * bg.b);
+		return true;
+	}
+	const HitInfo h = finishHit(S, p.ro, p.rd, hit);
+	const crh_material mat = S.materials[h.material];
+	p.fr = p.fr + (p.wr * mat.emission[0]); p.fg = p.fg + (p.wg * mat.emission[1]); p.fb = p.fb + (p.wb * mat.emission[2]);   /* :44 */
+	rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = hit.t; rec.ior = mat.ior;
+	const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, p.rng, cnt);   /* :46 */
+	p.ro = h.point; p.rd = s.out;                                    /* :47 */
+	float probability = 1.0f;
+	if (p.depth >= 4) {                                              /* :51-55 */
+		probability = rmax(s.r, rmax(s.g, s.b));
+		if (getDimension(p.rng) > probability) return true;
+	}
+	const float ip = 1.0f / probability;                             /* :57 */
+	p.wr = (s.r * p.wr) * ip; p.wg = (s.g * p.wg) * ip; p.wb = (s.b * p.wb) * ip;
+	p.depth++;
+	return p.depth >= maxDepth;
+}
+
+/* running mean: renderer.c:288-291 */
+CRH_DEV void foldSample(float *px, float r, float g, float b, int completedSamples) {
+	const float n1 = (float)(completedSamples - 1);
+	const float t = 1.0f / (float)completedSamples;
+	px[0] = ((px[0] * n1) + r) * t;
+	px[1] = ((px[1] * n1) + g) * t;
+	px[2] = ((px[2] * n1) + b) * t;
+}
+
+/*
+ * The renderThread() pixel x pass loop (renderer.c:275-301) for ONE lane, flattened so that every
+ * iteration is one bounce: a lane whose path ended starts its pixel's next pass (or pulls the next
+ * pixel from `work`) at the top of the same loop instead of idling until the rest of the wave is done.
+ * A lane owns its pixel for all passes, so the running mean is folded in pass order exactly like the
+ * reference. `work.next(x, y)` hands out pixels (reference coordinates: y from the bottom).
+ */
+template <class Stack, class Work, class Cnt>
+CRH_DEV void renderLane(const DScene &S, const crh_render_params &P, Stack &stk, Work &work, float *fb, Cnt &cnt) {
+	const int passEnd = P.first_pass + P.pass_count;
+	int x = 0, y = 0, pass = passEnd;
+	bool havePath = false;
+	PathState p;
+	p.depth = 0; p.rng.state = 0;
+	p.ro = p.rd = v3{0.0f, 0.0f, 0.0f};
+	p.wr = p.wg = p.wb = p.fr = p.fg = p.fb = 0.0f;
+	for (;;) {
+		if (!havePath) {
+			if (pass >= passEnd) {
+				if (!work.next(x, y)) break;
+				pass = P.first_pass;
+				if (pass >= passEnd) continue;
+			}
+			const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
+			initSampler(p.rng, pass, P.max_passes, pixIdx);                       /* :281 */
+			getCameraRay(S.camera, p.rng, x, y, p.ro, p.rd);                      /* :284 */
+			p.wr = p.wg = p.wb = 1.0f; p.fr = p.fg = p.fb = 0.0f; p.depth = 0;
+			CRH_COUNT1(cnt, paths, 1);
+			havePath = true;
+		}
+		const bool done = (P.bounces <= 0) ? true : bounceStep(S, stk, p, P.bounces, cnt);
+		if (done) {
+			float *px = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;   /* texture.c:24-28 */
+			foldSample(px, p.fr, p.fg, p.fb, pass + 1);
+			++pass;
+			havePath = false;
+		}
+	}
+}
+
+}  // namespace crh

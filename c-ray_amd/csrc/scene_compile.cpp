@@ -1,0 +1,331 @@
+/*
+ * scene_compile.cpp — see scene_compile.h. Host C++; must be built with -ffp-contract=off (the prepared
+ * triangles restate poly.c:20-22 and have to come out bit-identical to the reference's per-test values).
+ */
+#include "scene_compile.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace crh {
+
+namespace {
+
+struct Fail {
+	int code;
+	std::string msg;
+};
+
+#define CHECK(cond, code, ...)                                 \
+	do {                                                       \
+		if (!(cond)) {                                         \
+			char buf_[256];                                    \
+			snprintf(buf_, sizeof(buf_), __VA_ARGS__);         \
+			throw Fail{code, buf_};                            \
+		}                                                      \
+	} while (0)
+
+inline bool isBsdfKind(uint32_t k) { return k >= CRH_BSDF_DIFFUSE && k <= CRH_BSDF_BACKGROUND; }
+inline bool isColorKind(uint32_t k) { return k >= CRH_COLOR_CONSTANT && k <= CRH_COLOR_VECTOCOLOR; }
+inline bool isValueKind(uint32_t k) { return k >= CRH_VALUE_CONSTANT && k <= CRH_VALUE_RAYLENGTH; }
+inline bool isVectorKind(uint32_t k) { return k >= CRH_VEC_CONSTANT && k <= CRH_VEC_VECMATH; }
+enum Cls { COLOR, VALUE, VECTOR };
+
+struct Compiler {
+	const crh_scene_desc *s;
+	CompiledScene &out;
+	std::map<uint32_t, uint32_t> oprMemo;
+
+	Compiler(const crh_scene_desc *scene, CompiledScene &o) : s(scene), out(o) {}
+
+	/* ---- BVHs ---- */
+	/* root = device index of the root's child pair (node_count > 1) or of the root leaf itself (node_count == 1) */
+	struct BvhInfo { uint32_t dev_base; uint32_t depth; uint32_t root; };
+
+	BvhInfo relayoutBvh(uint32_t node_base, uint32_t node_count, uint32_t prim_base, uint32_t prim_count, const char *what) {
+		BvhInfo info{0, 0, 0};
+		if (out.nodes.size() % 4) out.nodes.resize(out.nodes.size() + 2);   /* even device node index */
+		const uint32_t dev_base = (uint32_t)(out.nodes.size() / 2);
+		info.dev_base = dev_base;
+		info.root = dev_base + 1;
+		if (node_count == 0) return info;
+		CHECK((uint64_t)node_base + node_count <= s->node_count, CRH_ERR_INVALID, "%s: node range out of bounds", what);
+		CHECK((uint64_t)prim_base + prim_count <= s->prim_index_count, CRH_ERR_INVALID, "%s: prim range out of bounds", what);
+		out.nodes.resize((size_t)(dev_base + 1 + node_count) * 2, f4{0, 0, 0, 0});
+		std::vector<uint32_t> depth(node_count, 0);
+		for (uint32_t i = 0; i < node_count; ++i) {
+			const crh_bvh_node &n = s->nodes[node_base + i];
+			const uint32_t count = CRH_NODE_PRIMCOUNT(n);
+			const bool leaf = CRH_NODE_ISLEAF(n);
+			uint32_t first;
+			if (leaf) {
+				CHECK((uint64_t)n.first + count <= prim_count, CRH_ERR_INVALID, "%s: leaf %u prim range out of bounds", what, i);
+				first = prim_base + n.first;
+			} else {
+				/* children are allocated after their parent, as an (odd, even) pair: bvh.c:221-223 */
+				CHECK(n.first > i && (uint64_t)n.first + 1 < node_count && (n.first & 1u), CRH_ERR_INVALID,
+					  "%s: inner node %u has child index %u (count %u)", what, i, n.first, node_count);
+				first = dev_base + 1 + n.first;
+				const uint32_t d = depth[i] + 1;
+				depth[n.first] = std::max(depth[n.first], d);
+				depth[n.first + 1] = std::max(depth[n.first + 1], d);
+				info.depth = std::max(info.depth, d);
+			}
+			f4 a{n.bounds[0], n.bounds[1], n.bounds[2], n.bounds[3]};
+			f4 b{n.bounds[4], n.bounds[5], asF32(first), asF32((count & 0x3FFFFFFFu) | (leaf ? 0x40000000u : 0u))};
+			out.nodes[(size_t)(dev_base + 1 + i) * 2] = a;
+			out.nodes[(size_t)(dev_base + 1 + i) * 2 + 1] = b;
+		}
+		if (node_count > 1) {
+			CHECK(!CRH_NODE_ISLEAF(s->nodes[node_base]), CRH_ERR_INVALID, "%s: multi-node BVH with a leaf root", what);
+			info.root = dev_base + 1 + s->nodes[node_base].first;
+		}
+		return info;
+	}
+
+	/* ---- node graph ---- */
+	uint32_t addConst(float x, float y, float z, float w) {
+		out.consts.push_back(f4{x, y, z, w});
+		return (uint32_t)out.consts.size() - 1;
+	}
+	uint32_t addImage(const crh_gnode &g) {
+		if (g.a != CRH_NODE_NONE) CHECK(g.a < s->texture_count, CRH_ERR_INVALID, "image node references texture %u of %llu", g.a, (unsigned long long)s->texture_count);
+		out.images.push_back(DImage{g.a, g.b});
+		return (uint32_t)out.images.size() - 1;
+	}
+	const crh_gnode &gnode(uint32_t g, uint32_t parent, Cls cls) {
+		CHECK(g != CRH_NODE_NONE, CRH_ERR_INVALID, "node %u has a missing operand", parent);
+		CHECK(g < s->gnode_count && (parent == CRH_NODE_NONE || g < parent), CRH_ERR_INVALID, "node %u references node %u (graph must be post-ordered)", parent, g);
+		const crh_gnode &n = s->gnodes[g];
+		const bool ok = cls == COLOR ? isColorKind(n.kind) : cls == VALUE ? isValueKind(n.kind) : isVectorKind(n.kind);
+		CHECK(ok, CRH_ERR_UNSUPPORTED, "node %u (kind %u) is not of the class node %u expects", g, n.kind, parent);
+		return n;
+	}
+
+	struct Slots {
+		uint32_t used = 0;
+		int alloc() {
+			for (int i = 0; i < CRH_PROG_SLOTS; ++i) if (!(used & (1u << i))) { used |= 1u << i; return i; }
+			throw Fail{CRH_ERR_UNSUPPORTED, "node program needs more than CRH_PROG_SLOTS operand slots"};
+		}
+		void release(int i) { used &= ~(1u << i); }
+	};
+
+	int emit(uint32_t g, uint32_t parent, Cls cls, Slots &sl) {
+		const crh_gnode &n = gnode(g, parent, cls);
+		DOp op;
+		memset(&op, 0, sizeof(op));
+		op.kind = (uint16_t)n.kind;
+		int a = -1, b = -1, c = -1;
+		switch (n.kind) {
+			case CRH_COLOR_CONSTANT: op.cidx = addConst(n.f[0], n.f[1], n.f[2], n.f[3]); break;
+			case CRH_VALUE_CONSTANT: op.cidx = addConst(n.f[0], 0, 0, 0); break;
+			case CRH_VEC_CONSTANT: op.cidx = addConst(n.f[0], n.f[1], n.f[2], 0); break;
+			case CRH_COLOR_IMAGE: op.u = addImage(n); break;
+			case CRH_COLOR_GRADIENT: op.cidx = addConst(n.f[0], n.f[1], n.f[2], n.f[3]); addConst(n.f[4], n.f[5], n.f[6], n.f[7]); break;
+			case CRH_COLOR_CHECKER: a = emit(n.a, g, COLOR, sl); b = emit(n.b, g, COLOR, sl); c = emit(n.c, g, VALUE, sl); break;
+			case CRH_COLOR_BLACKBODY: case CRH_COLOR_COMBINE: a = emit(n.a, g, VALUE, sl); break;
+			case CRH_COLOR_COMBINERGB: a = emit(n.a, g, VALUE, sl); b = emit(n.b, g, VALUE, sl); c = emit(n.c, g, VALUE, sl); break;
+			case CRH_COLOR_VECTOCOLOR: a = emit(n.a, g, VECTOR, sl); break;
+			case CRH_VALUE_ALPHA: case CRH_VALUE_GRAYSCALE: a = emit(n.a, g, COLOR, sl); break;
+			case CRH_VALUE_MATH: a = emit(n.a, g, VALUE, sl); b = emit(n.b, g, VALUE, sl); op.u = n.c; break;
+			case CRH_VALUE_FRESNEL: a = emit(n.a, g, VALUE, sl); break;
+			case CRH_VALUE_RAYLENGTH: case CRH_VEC_NORMAL: break;
+			case CRH_VEC_VECMATH: a = emit(n.a, g, VECTOR, sl); b = emit(n.b, g, VECTOR, sl); op.u = n.c; break;
+			default: throw Fail{CRH_ERR_UNSUPPORTED, "unknown pure node kind " + std::to_string(n.kind)};
+		}
+		if (a >= 0) { op.s0 = (uint8_t)a; sl.release(a); }
+		if (b >= 0) { op.s1 = (uint8_t)b; sl.release(b); }
+		if (c >= 0) { op.s2 = (uint8_t)c; sl.release(c); }
+		const int dst = sl.alloc();
+		op.dst = (uint8_t)dst;
+		out.prog.push_back(op);
+		return dst;
+	}
+
+	uint32_t operand(uint32_t g, uint32_t parent, Cls cls) {
+		const crh_gnode &n = gnode(g, parent, cls);
+		auto it = oprMemo.find(g);
+		if (it != oprMemo.end()) return it->second;
+		uint32_t r;
+		if (n.kind == CRH_COLOR_CONSTANT) r = CRH_OPR(CRH_OPR_CONST, addConst(n.f[0], n.f[1], n.f[2], n.f[3]));
+		else if (n.kind == CRH_VALUE_CONSTANT) r = CRH_OPR(CRH_OPR_CONST, addConst(n.f[0], 0, 0, 0));
+		else if (n.kind == CRH_VEC_CONSTANT) r = CRH_OPR(CRH_OPR_CONST, addConst(n.f[0], n.f[1], n.f[2], 0));
+		else if (n.kind == CRH_COLOR_IMAGE) r = CRH_OPR(CRH_OPR_IMAGE, addImage(n));
+		else {
+			const uint32_t pc = (uint32_t)out.prog.size();
+			Slots sl;
+			const int res = emit(g, parent, cls, sl);
+			DOp end;
+			memset(&end, 0, sizeof(end));
+			end.kind = CRH_OP_END;
+			end.s0 = (uint8_t)res;
+			out.prog.push_back(end);
+			r = CRH_OPR(CRH_OPR_PROGRAM, pc);
+		}
+		oprMemo[g] = r;
+		return r;
+	}
+
+	uint32_t bsdfChild(uint32_t g, uint32_t parent) {
+		CHECK(g != CRH_NODE_NONE && g < s->gnode_count && g < parent, CRH_ERR_INVALID, "bsdf node %u references node %u", parent, g);
+		CHECK(isBsdfKind(s->gnodes[g].kind) && s->gnodes[g].kind != CRH_BSDF_BACKGROUND, CRH_ERR_UNSUPPORTED, "bsdf node %u: child %u is not a surface bsdf", parent, g);
+		return g;
+	}
+
+	void compileGraph() {
+		const uint32_t N = (uint32_t)s->gnode_count;
+		out.bsdfs.assign(N ? N : 1, DBsdf{0, CRH_NONE, CRH_NONE, CRH_NONE});
+		std::vector<uint32_t> addDepth(N, 0);
+		for (uint32_t g = 0; g < N; ++g) {
+			const crh_gnode &n = s->gnodes[g];
+			if (!isBsdfKind(n.kind)) continue;
+			DBsdf d{n.kind, CRH_NONE, CRH_NONE, CRH_NONE};
+			switch (n.kind) {
+				case CRH_BSDF_DIFFUSE: case CRH_BSDF_TRANSPARENT: case CRH_BSDF_ISOTROPIC:
+					d.a = operand(n.a, g, COLOR); break;
+				case CRH_BSDF_METAL: d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, VALUE); break;
+				case CRH_BSDF_GLASS: d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, VALUE); d.c = operand(n.c, g, VALUE); break;
+				case CRH_BSDF_PLASTIC:
+					d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, COLOR); d.c = bsdfChild(n.c, g);
+					addDepth[g] = addDepth[n.c]; break;
+				case CRH_BSDF_MIX:
+					d.a = bsdfChild(n.a, g); d.b = bsdfChild(n.b, g); d.c = operand(n.c, g, VALUE);
+					addDepth[g] = std::max(addDepth[n.a], addDepth[n.b]); break;
+				case CRH_BSDF_ADD:
+					d.a = bsdfChild(n.a, g); d.b = bsdfChild(n.b, g);
+					addDepth[g] = 1 + std::max(addDepth[n.a], addDepth[n.b]); break;
+				case CRH_BSDF_EMISSION: d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, VALUE); break;
+				case CRH_BSDF_BACKGROUND: d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, VALUE); d.c = operand(n.c, g, VALUE); break;
+				default: break;
+			}
+			CHECK(addDepth[g] <= CRH_ADD_DEPTH, CRH_ERR_UNSUPPORTED, "bsdf node %u nests add nodes %u deep (device limit %d)", g, addDepth[g], CRH_ADD_DEPTH);
+			out.max_add_depth = std::max(out.max_add_depth, addDepth[g]);
+			out.bsdfs[g] = d;
+		}
+		if (out.consts.empty()) addConst(0, 0, 0, 0);
+		if (out.images.empty()) out.images.push_back(DImage{CRH_NONE, 0});
+		if (out.prog.empty()) { DOp end; memset(&end, 0, sizeof(end)); end.kind = CRH_OP_END; out.prog.push_back(end); }
+	}
+
+	void run() {
+		CHECK(s->struct_size == sizeof(crh_scene_desc), CRH_ERR_INVALID, "crh_scene_desc.struct_size %u != %zu", s->struct_size, sizeof(crh_scene_desc));
+		CHECK(s->abi_version == CRH_ABI_VERSION, CRH_ERR_INVALID, "ABI version %u != %d", s->abi_version, CRH_ABI_VERSION);
+		CHECK(s->node_count < 0x3FFFFFFFull && s->prim_index_count < 0x3FFFFFFFull && s->poly_count < 0x7FFFFFFFull, CRH_ERR_UNSUPPORTED, "scene too large for 32-bit device indices");
+		CHECK(s->camera.width > 0 && s->camera.height > 0, CRH_ERR_INVALID, "camera has no image size");
+		out.camera = s->camera;
+
+		for (uint64_t t = 0; t < s->texture_count; ++t) {
+			const crh_texture &tx = s->textures[t];
+			CHECK(tx.width > 0 && tx.height > 0 && tx.channels >= 1 && tx.channels <= 4, CRH_ERR_INVALID, "texture %llu has a bad shape", (unsigned long long)t);
+			const uint64_t bytes = (uint64_t)tx.width * tx.height * tx.channels * (tx.is_float ? 4u : 1u);
+			CHECK(tx.offset % 4 == 0 && tx.offset + bytes <= s->texture_bytes, CRH_ERR_INVALID, "texture %llu data out of bounds", (unsigned long long)t);
+			CHECK(!tx.has_alpha || tx.channels == 4, CRH_ERR_INVALID, "texture %llu: has_alpha needs 4 channels", (unsigned long long)t);
+		}
+
+		compileGraph();
+		CHECK(s->background < s->gnode_count && s->gnodes[s->background].kind == CRH_BSDF_BACKGROUND, CRH_ERR_INVALID, "scene.background is not a background node");
+		out.background = s->background;
+		for (uint64_t m = 0; m < s->material_count; ++m) {
+			const uint32_t b = s->materials[m].bsdf;
+			CHECK(b < s->gnode_count && isBsdfKind(s->gnodes[b].kind) && s->gnodes[b].kind != CRH_BSDF_BACKGROUND, CRH_ERR_INVALID, "material %llu has no surface bsdf", (unsigned long long)m);
+		}
+
+		/* BLAS per mesh, prepared triangles */
+		out.tris.assign((size_t)std::max<uint64_t>(s->prim_index_count, 1) * 3, f4{0, 0, 0, 0});
+		std::vector<BvhInfo> meshBvh(s->mesh_count);
+		uint32_t maxBlasDepth = 0;
+		for (uint64_t m = 0; m < s->mesh_count; ++m) {
+			const crh_mesh &mesh = s->meshes[m];
+			CHECK((uint64_t)mesh.poly_base + mesh.poly_count <= s->poly_count, CRH_ERR_INVALID, "mesh %llu: polygon range out of bounds", (unsigned long long)m);
+			CHECK((uint64_t)mesh.material_base + mesh.material_count <= s->material_count && mesh.material_count > 0, CRH_ERR_INVALID, "mesh %llu: material range out of bounds", (unsigned long long)m);
+			meshBvh[m] = relayoutBvh(mesh.node_base, mesh.node_count, mesh.prim_base, mesh.node_count ? mesh.poly_count : 0, "BLAS");
+			maxBlasDepth = std::max(maxBlasDepth, meshBvh[m].depth);
+			if (!mesh.node_count) continue;
+			for (uint32_t k = 0; k < mesh.poly_count; ++k) {
+				const int32_t pi = s->prim_indices[mesh.prim_base + k];
+				CHECK(pi >= 0 && (uint32_t)pi < mesh.poly_count, CRH_ERR_INVALID, "mesh %llu: prim index %d out of range", (unsigned long long)m, pi);
+				const crh_poly &p = s->polys[mesh.poly_base + pi];
+				for (int j = 0; j < 3; ++j) {
+					CHECK(p.v[j] >= 0 && (uint64_t)p.v[j] < s->vertex_count, CRH_ERR_INVALID, "polygon %u: vertex index out of range", mesh.poly_base + pi);
+					if (CRH_POLY_HASNORMALS(p)) CHECK(p.n[j] >= 0 && (uint64_t)p.n[j] < s->normal_count, CRH_ERR_INVALID, "polygon %u: normal index out of range", mesh.poly_base + pi);
+					if (mesh.texcoord_count && p.t[0] != -1) CHECK(p.t[j] >= 0 && (uint64_t)p.t[j] < s->texcoord_count, CRH_ERR_INVALID, "polygon %u: texcoord index out of range", mesh.poly_base + pi);
+				}
+				CHECK(CRH_POLY_MATERIAL(p) < mesh.material_count, CRH_ERR_INVALID, "polygon %u: material index out of range", mesh.poly_base + pi);
+				const float *V = s->vertices;
+				const v3 v0{V[3 * (size_t)p.v[0]], V[3 * (size_t)p.v[0] + 1], V[3 * (size_t)p.v[0] + 2]};
+				const v3 v1{V[3 * (size_t)p.v[1]], V[3 * (size_t)p.v[1] + 1], V[3 * (size_t)p.v[1] + 2]};
+				const v3 v2{V[3 * (size_t)p.v[2]], V[3 * (size_t)p.v[2] + 1], V[3 * (size_t)p.v[2] + 2]};
+				const v3 e1 = vsub(v0, v1);          /* poly.c:20 */
+				const v3 e2 = vsub(v2, v0);          /* poly.c:21 */
+				const v3 n = vcross(e1, e2);         /* poly.c:22 */
+				f4 *q = &out.tris[(size_t)(mesh.prim_base + k) * 3];
+				q[0] = f4{v0.x, v0.y, v0.z, e1.x};
+				q[1] = f4{e1.y, e1.z, e2.x, e2.y};
+				q[2] = f4{e2.z, n.x, n.y, n.z};
+			}
+		}
+
+		/* TLAS */
+		CHECK(s->tlas_prim_count == (s->tlas_node_count ? s->instance_count : 0), CRH_ERR_INVALID, "TLAS prim count does not match the instance count");
+		const BvhInfo tlas = relayoutBvh(s->tlas_node_base, s->tlas_node_count, s->tlas_prim_base, s->tlas_prim_count, "TLAS");
+		out.tlas_root = tlas.root;
+		out.tlas_node_count = s->tlas_node_count;
+		out.tlas_prim_base = s->tlas_prim_base;
+		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {
+			const int32_t ii = s->prim_indices[s->tlas_prim_base + k];
+			CHECK(ii >= 0 && (uint64_t)ii < s->instance_count, CRH_ERR_INVALID, "TLAS prim %u: instance index out of range", k);
+		}
+		out.max_stack = tlas.depth + 5 + maxBlasDepth + 1;
+
+		out.instances.resize(std::max<uint64_t>(s->instance_count, 1));
+		for (uint64_t i = 0; i < s->instance_count; ++i) {
+			const crh_instance &in = s->instances[i];
+			DInstance d;
+			memset(&d, 0, sizeof(d));
+			memcpy(d.Ainv, in.Ainv, sizeof(d.Ainv));
+			memcpy(d.A, in.A, sizeof(d.A));
+			d.kind = in.kind;
+			d.object = in.object;
+			if (in.kind == CRH_INSTANCE_SPHERE) {
+				CHECK(in.object < s->sphere_count, CRH_ERR_INVALID, "instance %llu: sphere index out of range", (unsigned long long)i);
+				const crh_sphere &sp = s->spheres[in.object];
+				CHECK(sp.material < s->material_count, CRH_ERR_INVALID, "sphere %u: material out of range", in.object);
+				d.radius = sp.radius; d.ray_offset = sp.ray_offset; d.material = sp.material;
+			} else if (in.kind == CRH_INSTANCE_MESH) {
+				CHECK(in.object < s->mesh_count, CRH_ERR_INVALID, "instance %llu: mesh index out of range", (unsigned long long)i);
+				const crh_mesh &mesh = s->meshes[in.object];
+				d.root = meshBvh[in.object].root;
+				d.node_count = mesh.node_count;
+				d.ray_offset = mesh.ray_offset;
+				d.material = mesh.material_base;
+				d.poly_base = mesh.poly_base;
+			} else {
+				throw Fail{CRH_ERR_UNSUPPORTED, "instance kind " + std::to_string(in.kind) + " (volumes) is not supported"};
+			}
+			out.instances[i] = d;
+		}
+		if (out.nodes.empty()) out.nodes.resize(4, f4{0, 0, 0, 0});
+	}
+};
+
+}  // namespace
+
+int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &err) {
+	if (!scene) { err = "null scene"; return CRH_ERR_INVALID; }
+	try {
+		Compiler c(scene, out);
+		c.run();
+	} catch (const Fail &f) {
+		err = f.msg;
+		return f.code;
+	} catch (const std::bad_alloc &) {
+		err = "out of host memory";
+		return CRH_ERR_NOMEM;
+	}
+	return CRH_OK;
+}
+
+}  // namespace crh

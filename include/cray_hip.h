@@ -254,6 +254,11 @@ int crh_abi_version(void);
 int crh_context_create(int device, void *stream, crh_ctx **out);
 int crh_context_destroy(crh_ctx *ctx);
 
+/* Per-context knobs. */
+#define CRH_OPT_COUNTER_LEVEL 1   /* 2 (default): every crh_counters field; 1: paths + rays only (timed runs)      */
+#define CRH_OPT_BLOCKS_PER_CU 2   /* persistent 256-thread workgroups launched per compute unit (default 4)        */
+int crh_set_option(crh_ctx *ctx, int option, int64_t value);
+
 /* Replaces "the CPU reads struct world directly": copies the flattened scene to HBM, derives the
  * device-side acceleration layout (leaf-ordered prepared triangles) and validates the node graph. */
 int crh_scene_upload(crh_ctx *ctx, const crh_scene_desc *scene);

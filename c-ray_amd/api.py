@@ -42,6 +42,7 @@ def library():
         "crh_context_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(ctx)]),
         "crh_context_destroy": (C.c_int, [ctx]),
         "crh_set_option": (C.c_int, [ctx, C.c_int, C.c_int64]),
+        "crh_debug_wave_stats": (C.c_int, [ctx, C.c_void_p, C.c_uint32]),
         "crh_scene_upload": (C.c_int, [ctx, C.POINTER(abi.SceneDesc)]),
         "crh_framebuffer_alloc": (C.c_int, [ctx, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
         "crh_framebuffer_free": (C.c_int, [ctx, C.c_void_p]),
@@ -129,6 +130,13 @@ class Context:
 
     def set_option(self, option, value):
         _check(self.L.crh_set_option(self.h, int(option), int(value)), "crh_set_option")
+
+    def wave_stats(self):
+        buf = np.zeros((8192, 2), dtype=np.uint64)
+        n = self.L.crh_debug_wave_stats(self.h, buf.ctypes.data, 8192)
+        if n < 0:
+            _check(n, "crh_debug_wave_stats")
+        return buf[:n]
 
     def upload(self, scene):
         desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)

@@ -2,12 +2,14 @@
  * cray_hip.hip — libcray_hip.so: the C-ABI of include/cray_hip.h and the gfx950 kernels behind it.
  *
  * Kernels (all hand-written for CDNA4, wave = 64):
- *   k_pathtrace<LEVEL>   persistent-thread path tracer: one ray per lane, a lane owns a pixel for all of
- *                        its passes (running mean folded in pass order, renderer.c:288-291) and pulls the
- *                        next pixel from a global work counter with ONE atomic per wave (__ballot +
- *                        readfirstlane), so lanes whose path ended are refilled in the same loop iteration
- *                        instead of idling. Traversal stack in LDS (entry-major, conflict-free), deep
- *                        stacks spill to a per-lane global slab.
+ *   k_pathtrace<LEVEL>   persistent-thread path tracer: one ray per lane. A wave pulls one pixel block
+ *                        (8x8 / 4x4) at a time from a global queue (one atomic per wave, readfirstlane
+ *                        broadcast) and strides its 64 lanes over the block's (pixel, pass) items: a lane
+ *                        whose path ended starts its next item in the same loop iteration, so lanes are
+ *                        refilled instead of idling, and all lanes of a wave stay on the same few pixels
+ *                        (coherent BVH walks). Samples are staged per wave and folded into the running mean
+ *                        in pass order (renderer.c:288-291). Traversal stack in LDS (entry-major,
+ *                        conflict-free); deep stacks spill to a per-lane global slab.
  *   k_trace_rays         getClosestIsect for caller rays (diagnostic / parity entry).
  *   k_to_srgb8           colorToSRGB + setPixel truncation.
  * No CPU fallback: every entry point fails with CRH_ERR_NO_DEVICE when there is no GPU.
@@ -42,51 +44,51 @@ static int fail(int code, const std::string &msg) { t_err = msg; return code; }
 	} while (0)
 
 /* ---- device-side helpers ------------------------------------------------------------------------ */
+/* Deep-stack overflow (entries beyond CRH_STACK_LDS) lives in a per-lane global slab. Kept out of line so that
+ * the LDS and the global pointer are never merged into one generic pointer (that would turn every stack
+ * access into a flat_load / flat_store). */
+__device__ __noinline__ void spillStore(uint32_t *p, uint32_t v) { *p = v; }
+__device__ __noinline__ uint32_t spillLoad(const uint32_t *p) { return *p; }
 struct LdsStack {
 	uint32_t *lds;       /* &s_stack[threadIdx.x]; entry i at lds[i * CRH_BLOCK]: bank = lane % 32, conflict-free */
 	uint32_t *spill;     /* &spill[global thread]; entry j at spill[j * stride] (coalesced across lanes) */
 	uint32_t stride;
 	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
-		if (i < CRH_STACK_LDS) lds[i * CRH_BLOCK] = v;
-		else spill[(size_t)(i - CRH_STACK_LDS) * stride] = v;
+		if (__builtin_expect(i < CRH_STACK_LDS, 1)) lds[i * CRH_BLOCK] = v;
+		else spillStore(spill + (size_t)(i - CRH_STACK_LDS) * stride, v);
 	}
 	__device__ __forceinline__ uint32_t pop(uint32_t i) {
-		if (i < CRH_STACK_LDS) return lds[i * CRH_BLOCK];
-		return spill[(size_t)(i - CRH_STACK_LDS) * stride];
+		if (__builtin_expect(i < CRH_STACK_LDS, 1)) return lds[i * CRH_BLOCK];
+		return spillLoad(spill + (size_t)(i - CRH_STACK_LDS) * stride);
 	}
 };
 
-/* Work queue over the pixels of a tile list. Item numbering: tiles in list order, inside a tile 8x8 pixel
- * blocks in row-major order, 64 consecutive items = one block (so one wave-wide fetch = one 8x8 patch of
- * coherent primary rays); items that fall outside a ragged tile edge are skipped. */
-struct TileWork {
+/* Work queue over the pixel blocks of a tile list: tiles in list order, inside a tile bw x bh pixel blocks in
+ * row-major order. One unit = one block for ALL passes of the dispatch (chunks of a block are folded in
+ * order by the wave that owns it). */
+struct BlockQueue {
 	const crh_tile *tiles;
-	const uint32_t *start;     /* start[t] = first item of tile t; start[ntiles] = total */
+	const uint32_t *start;     /* start[t] = first block of tile t; start[ntiles] = total */
 	uint32_t ntiles, total;
 	uint32_t *counter;
-	__device__ __forceinline__ bool next(int &x, int &y) {
-		for (;;) {
-			/* wave-aggregated fetch: the lanes that need work are exactly the active ones here */
-			const unsigned long long mask = __ballot(1);
-			const uint32_t lane = __lane_id();
-			const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-			uint32_t base = 0;
-			if (rank == 0) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-			base = __builtin_amdgcn_readfirstlane(base);
-			const uint32_t item = base + rank;
-			if (item >= total) return false;
-			uint32_t lo = 0, hi = ntiles;           /* largest t with start[t] <= item */
-			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (start[mid] <= item) lo = mid; else hi = mid; }
-			const crh_tile t = tiles[lo];
-			const uint32_t local = item - start[lo];
-			const uint32_t w = (uint32_t)(t.x1 - t.x0), h = (uint32_t)(t.y1 - t.y0);
-			const uint32_t bw = (w + 7u) >> 3;
-			const uint32_t blk = local >> 6, in = local & 63u;
-			const uint32_t px = (blk % bw) * 8u + (in & 7u), py = (blk / bw) * 8u + (in >> 3);
-			if (px < w && py < h) { x = t.x0 + (int)px; y = t.y0 + (int)py; return true; }
-		}
-	}
+	int bw, bh;
 };
+
+/* Pointers that arrive inside a by-value kernel-argument struct are generic ("flat") to the compiler; a round
+ * trip through the global address space lets it emit global_load instead of flat_load for the scene arrays. */
+template <class T>
+__device__ __forceinline__ const T *asGlobal(const T *p) {
+	return (const T *)(const __attribute__((address_space(1))) T *)p;
+}
+__device__ __forceinline__ DScene globalize(const DScene &S) {
+	DScene G = S;
+	G.nodes = asGlobal(S.nodes); G.tris = asGlobal(S.tris); G.prims = asGlobal(S.prims); G.polys = asGlobal(S.polys);
+	G.vertices = asGlobal(S.vertices); G.normals = asGlobal(S.normals); G.texcoords = asGlobal(S.texcoords);
+	G.instances = asGlobal(S.instances); G.meshes = asGlobal(S.meshes); G.materials = asGlobal(S.materials);
+	G.bsdfs = asGlobal(S.bsdfs); G.consts = asGlobal(S.consts); G.images = asGlobal(S.images); G.prog = asGlobal(S.prog);
+	G.textures = asGlobal(S.textures); G.texdata = asGlobal(S.texdata);
+	return G;
+}
 
 __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -97,19 +99,57 @@ template <int LEVEL> struct CountersFor;
 template <> struct CountersFor<2> { typedef Counters type; };
 template <> struct CountersFor<1> { typedef LiteCounters type; };
 
-template <int LEVEL>
-__global__ __launch_bounds__(CRH_BLOCK) void k_pathtrace(const DScene S, const crh_render_params P, TileWork W, float *fb,
-														   unsigned long long *counters, uint32_t *spill, uint32_t spillStride) {
+/* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
+template <int LEVEL, int WPS>
+__global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
+														   unsigned long long *counters, uint32_t *spill, uint32_t spillStride,
+														   float *stage, int chunk, unsigned long long *waveStats) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	const DScene S = globalize(Sarg);
+	const unsigned long long tStart = wall_clock64();
+	uint32_t unitsDone = 0;
 	LdsStack stk;
 	stk.lds = &s_stack[threadIdx.x];
 	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
 	stk.stride = spillStride;
 	typename CountersFor<LEVEL>::type cnt;
 	memset(&cnt, 0, sizeof(cnt));
-	renderLane(S, P, stk, W, fb, cnt);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
+	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
+	const int passEnd = P.first_pass + P.pass_count;
+	for (;;) {
+		uint32_t unit = 0;
+		if (lane == 0) unit = atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
+		unit = __builtin_amdgcn_readfirstlane(unit);
+		if (unit >= Q.total) break;
+		++unitsDone;
+		uint32_t lo = 0, hi = Q.ntiles;           /* largest t with start[t] <= unit */
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
+		const crh_tile t = asGlobal(Q.tiles)[lo];
+		const uint32_t local = unit - asGlobal(Q.start)[lo];
+		const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + Q.bw - 1) / (uint32_t)Q.bw;
+		BlockJob J;
+		J.bw = Q.bw; J.bh = Q.bh;
+		J.x0 = t.x0 + (int)(local % nbx) * Q.bw;
+		J.y0 = t.y0 + (int)(local / nbx) * Q.bh;
+		J.w = min(Q.bw, t.x1 - J.x0);
+		J.h = min(Q.bh, t.y1 - J.y0);
+		for (int c0 = P.first_pass; c0 < passEnd; c0 += chunk) {
+			J.passBegin = c0;
+			J.passCount = min(chunk, passEnd - c0);
+			renderItems(S, P, stk, J, lane, 64u, myStage, cnt);
+			__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
+			for (uint32_t pix = lane; pix < (uint32_t)(Q.bw * Q.bh); pix += 64u) foldBlockPixel(P, J, pix, myStage, fb);
+			__threadfence_block();                 /* ... and read before the next chunk overwrites them */
+		}
+	}
+	if (waveStats && lane == 0) {     /* debug: per-wave busy time (100 MHz ticks) and units processed */
+		waveStats[2 * wave] = wall_clock64() - tStart;
+		waveStats[2 * wave + 1] = unitsDone;
+	}
 	/* one atomic per wave and counter */
-	const bool lead = (__lane_id() == 0);
+	const bool lead = (lane == 0);
 	uint32_t v;
 	v = waveSum(cnt.paths); if (lead && v) atomicAdd(&counters[0], (unsigned long long)v);
 	v = waveSum(cnt.rays); if (lead && v) atomicAdd(&counters[1], (unsigned long long)v);
@@ -123,8 +163,9 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_pathtrace(const DScene S, const c
 	}
 }
 
-__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene S, const float *rays, uint64_t n, crh_hit *hits, uint32_t *spill, uint32_t spillStride) {
+__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits, uint32_t *spill, uint32_t spillStride) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	const DScene S = globalize(Sarg);
 	LdsStack stk;
 	stk.lds = &s_stack[threadIdx.x];
 	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
@@ -167,6 +208,13 @@ struct crh_ctx {
 	int cuCount = 0;
 	int blocksPerCU = 4;
 	int counterLevel = 2;
+	int passChunk = 64;
+	int unitItems = 1024;
+	int wavesPerSimd = 4;
+	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
+	uint32_t lastGrid = 0;
+	float *dStage = nullptr;
+	size_t stageFloats = 0;
 	bool haveScene = false;
 	DScene d;                              /* device pointers */
 	std::vector<void *> sceneAllocs;
@@ -278,6 +326,7 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dCounters) (void)hipFree(c->dCounters);
 	if (c->dWork) (void)hipFree(c->dWork);
 	if (c->dSpill) (void)hipFree(c->dSpill);
+	if (c->dStage) (void)hipFree(c->dStage);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return CRH_OK;
@@ -292,6 +341,19 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_BLOCKS_PER_CU:
 			if (value < 1 || value > 8) return fail(CRH_ERR_INVALID, "blocks per CU must be 1..8");
 			c->blocksPerCU = (int)value; return CRH_OK;
+		case CRH_OPT_WAVE_STATS:
+			if (value && !c->dWaveStats) { if (hipMalloc((void **)&c->dWaveStats, 2 * 8192 * sizeof(unsigned long long)) != hipSuccess) return fail(CRH_ERR_HIP, "wave stats alloc"); }
+			if (!value && c->dWaveStats) { (void)hipFree(c->dWaveStats); c->dWaveStats = nullptr; }
+			return CRH_OK;
+		case CRH_OPT_WAVES_PER_SIMD:
+			if (value != 1 && value != 4) return fail(CRH_ERR_INVALID, "waves per SIMD must be 1 (unconstrained) or 4");
+			c->wavesPerSimd = (int)value; return CRH_OK;
+		case CRH_OPT_UNIT_ITEMS:
+			if (value < 64 || value > (1 << 20)) return fail(CRH_ERR_INVALID, "unit items must be 64..2^20");
+			c->unitItems = (int)value; return CRH_OK;
+		case CRH_OPT_PASS_CHUNK:
+			if (value < 1 || value > 4096) return fail(CRH_ERR_INVALID, "pass chunk must be 1..4096");
+			c->passChunk = (int)value; return CRH_OK;
 		default: return fail(CRH_ERR_INVALID, "unknown option");
 	}
 }
@@ -410,6 +472,17 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (rc) return rc;
 	(void)resolveTimes(c, false);
 	if (c->pendingTimes.empty()) { for (void *p : c->deferredFrees) (void)hipFree(p); c->deferredFrees.clear(); }
+	/* Block shape: one work unit (a block for all passes of the dispatch) should hold about unitItems paths, so
+	 * that every wave gets many units (load balance) whatever the sample count: 16x16 pixels at 4 spp ... 2x2 at
+	 * 256 spp, 1x1 beyond. Smaller blocks also keep the 64 lanes of a wave on fewer pixels (coherent walks). */
+	uint64_t pixels = 0;
+	for (uint32_t t = 0; t < tile_count; ++t) pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * std::max(0, tiles[t].y1 - tiles[t].y0);
+	const uint64_t wavesMax = (uint64_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
+	int area = 1;
+	while (area < 256 && (int64_t)area * P->pass_count < c->unitItems) area *= 2;
+	while (area > 1 && pixels / area < 16 * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
+	int bw = 1, bh = 1;
+	while (bw * bh < area) { if (bw <= bh) bw *= 2; else bh *= 2; }
 	std::vector<uint32_t> start(tile_count + 1, 0);
 	uint64_t total = 0;
 	for (uint32_t t = 0; t < tile_count; ++t) {
@@ -417,15 +490,30 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		if (r.x0 < 0 || r.y0 < 0 || r.x1 > P->image_width || r.y1 > P->image_height || r.x0 > r.x1 || r.y0 > r.y1)
 			return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
 		start[t] = (uint32_t)total;
-		total += (uint64_t)((r.x1 - r.x0 + 7) / 8) * ((r.y1 - r.y0 + 7) / 8) * 64u;
-		if (total > 0xFFFFFFF0ull) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: more than 2^32 work items in one dispatch");
+		total += (uint64_t)((r.x1 - r.x0 + bw - 1) / bw) * ((r.y1 - r.y0 + bh - 1) / bh);
+		if (total > 0xFFFFFFF0ull) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: more than 2^32 pixel blocks in one dispatch");
 	}
 	start[tile_count] = (uint32_t)total;
 	if (total == 0 || P->pass_count == 0) return CRH_OK;
 
-	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (total + CRH_BLOCK - 1) / CRH_BLOCK);
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (total + 3) / 4);
 	rc = ensureSpill(c, grid * CRH_BLOCK);
 	if (rc) return rc;
+	/* passes per chunk: a chunk (block x passes) should also hold about unitItems paths, so that each lane runs >= 16
+	 * paths between two wave-wide folds */
+	const int chunk = std::min(P->pass_count, std::max(c->passChunk, (c->unitItems + area - 1) / area));
+	c->lastGrid = grid;
+	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > 8192) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
+	{
+		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
+		if (need > c->stageFloats) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (c->dStage) HIP_TRY(hipFree(c->dStage));
+			c->dStage = nullptr; c->stageFloats = 0;
+			HIP_TRY(hipMalloc((void **)&c->dStage, need * sizeof(float)));
+			c->stageFloats = need;
+		}
+	}
 
 	/* per-launch tile list in HBM (freed once the stream has drained) */
 	void *dTiles = nullptr;
@@ -435,22 +523,24 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	HIP_TRY(hipMemcpy(dTiles, tiles, tileBytes, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy((char *)dTiles + tileBytes, start.data(), startBytes, hipMemcpyHostToDevice));
 
-	TileWork W;
-	W.tiles = (const crh_tile *)dTiles;
-	W.start = (const uint32_t *)((char *)dTiles + tileBytes);
-	W.ntiles = tile_count;
-	W.total = (uint32_t)total;
-	W.counter = c->dWork + (c->workSlot++ % CRH_WORK_SLOTS);
-	HIP_TRY(hipMemsetAsync(W.counter, 0, sizeof(uint32_t), c->stream));
+	BlockQueue Q;
+	Q.tiles = (const crh_tile *)dTiles;
+	Q.start = (const uint32_t *)((char *)dTiles + tileBytes);
+	Q.ntiles = tile_count;
+	Q.total = (uint32_t)total;
+	Q.counter = c->dWork + (c->workSlot++ % CRH_WORK_SLOTS);
+	Q.bw = bw; Q.bh = bh;
+	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
 
 	crh_ctx::Timed ev;
 	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
-	if (c->counterLevel >= 2)
-		hipLaunchKernelGGL(k_pathtrace<2>, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, W, dev_fb, c->dCounters, c->dSpill, grid * CRH_BLOCK);
-	else
-		hipLaunchKernelGGL(k_pathtrace<1>, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, W, dev_fb, c->dCounters, c->dSpill, grid * CRH_BLOCK);
+#define CRH_LAUNCH(LEVEL, WPS) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+												  c->dCounters, c->dSpill, grid * CRH_BLOCK, c->dStage, chunk, c->dWaveStats)
+	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH(2, 4); else CRH_LAUNCH(2, 1); }
+	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH(1, 4); else CRH_LAUNCH(1, 1); }
+#undef CRH_LAUNCH
 	hipError_t e = hipGetLastError();
 	HIP_TRY(hipEventRecord(ev.b, c->stream));
 	c->pendingTimes.push_back(ev);
@@ -506,6 +596,16 @@ int crh_kernel_time_ms(crh_ctx *c, float *last_ms, double *total_ms, uint64_t *l
 	if (total_ms) *total_ms = c->totalMs;
 	if (launches) *launches = c->launches;
 	return CRH_OK;
+}
+
+/* debug: copy the per-wave {busy ticks @100 MHz, units} pairs of the last dispatch; returns the wave count */
+int crh_debug_wave_stats(crh_ctx *c, uint64_t *out, uint32_t max_waves) {
+	if (!c || !c->dWaveStats || !out) return fail(CRH_ERR_INVALID, "wave stats not enabled");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	const uint32_t n = std::min<uint32_t>(max_waves, c->lastGrid * (CRH_BLOCK / 64));
+	HIP_TRY(hipMemcpy(out, c->dWaveStats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	return (int)n;
 }
 
 int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits_host) {

@@ -51,13 +51,17 @@ struct alignas(16) DInstance {
 	uint32_t poly_base;   /* mesh: first polygon in polys[]                                  */
 };
 
-/* pure-node operand reference (compiled at upload, see cray_hip.hip: compile_operand) */
-#define CRH_OPR_CONST   0u   /* index into consts[] (f4)                       */
-#define CRH_OPR_IMAGE   1u   /* index into images[]                            */
-#define CRH_OPR_PROGRAM 2u   /* offset into prog[]                             */
-#define CRH_OPR(kind, idx) (((uint32_t)(kind) << 30) | (uint32_t)(idx))
-#define CRH_OPR_KIND(r) ((r) >> 30)
-#define CRH_OPR_IDX(r)  ((r) & 0x3FFFFFFFu)
+/* pure-node operand reference (compiled at upload, see scene_compile.cpp: operand()).
+ * Sub-graphs that do not depend on the hit are folded to constants on the host; the common hit-dependent
+ * leaves get their own kinds so that only rare graphs (checker, grayscale(image), ...) run a program. */
+#define CRH_OPR_CONST       0u   /* index into consts[] (f4)                                   */
+#define CRH_OPR_IMAGE       1u   /* index into images[]: colour = image fetch                  */
+#define CRH_OPR_IMAGE_ALPHA 2u   /* index into images[]: value = alpha of the fetch (alpha.c)  */
+#define CRH_OPR_GRADIENT    3u   /* index into consts[]: down, up (gradient.c:40-45)           */
+#define CRH_OPR_PROGRAM     4u   /* offset into prog[]                                         */
+#define CRH_OPR(kind, idx) (((uint32_t)(kind) << 29) | (uint32_t)(idx))
+#define CRH_OPR_KIND(r) ((r) >> 29)
+#define CRH_OPR_IDX(r)  ((r) & 0x1FFFFFFFu)
 
 struct DImage { uint32_t tex; uint32_t options; };
 
@@ -296,8 +300,9 @@ CRH_DEV uint32_t wrapIndex(int i, uint32_t W) {
 	if (i >= 0) return (uint32_t)i % W;
 	return (uint32_t)((uint64_t)(int64_t)i % (uint64_t)W);
 }
+struct TexCtx { const crh_texture *textures; const uint8_t *texdata; };
 template <class Cnt>
-CRH_DEV rgba texel(const DScene &S, const crh_texture &t, uint32_t x, uint32_t y, Cnt &cnt) {
+CRH_DEV rgba texel(const TexCtx S, const crh_texture &t, uint32_t x, uint32_t y, Cnt &cnt) {
 	CRH_COUNT(cnt, tex_fetches, 1);
 	const uint8_t *bytes = S.texdata + t.offset;
 	const float *floats = (const float *)bytes;
@@ -317,7 +322,7 @@ CRH_DEV rgba texel(const DScene &S, const crh_texture &t, uint32_t x, uint32_t y
 	return o;
 }
 template <class Cnt>
-CRH_DEV rgba textureGetPixelFiltered(const DScene &S, const crh_texture &t, float x, float y, Cnt &cnt) {
+CRH_DEV rgba textureGetPixelFiltered(const TexCtx S, const crh_texture &t, float x, float y, Cnt &cnt) {
 	x = x * (float)t.width;
 	y = y * (float)t.height;
 	float xcopy = x - 0.5f;
@@ -335,7 +340,7 @@ CRH_DEV rgba textureGetPixelFiltered(const DScene &S, const crh_texture &t, floa
 }
 /* image.c:31-48 */
 template <class Cnt>
-CRH_DEV rgba evalImage(const DScene &S, const DImage &im, v2 uv, Cnt &cnt) {
+CRH_DEV rgba evalImage(const TexCtx S, const DImage im, v2 uv, Cnt &cnt) {
 	if (im.tex == CRH_NONE) return rgba{1.0f, 0.0f, 0.5f, 1.0f};   /* warningMaterial().diffuse, material.c:38 */
 	const crh_texture t = S.textures[im.tex];
 	rgba out;
@@ -360,20 +365,33 @@ struct ShadeRec {
 	float ior;     /* material.IOR       */
 };
 
+/* gradient.c:40-45 */
+CRH_DEV rgba evalGradient(const f4 *consts, uint32_t cidx, const ShadeRec &rec) {
+	v3 unitDir = vnorm(rec.dir);
+	float t = 0.5f * (unitDir.y + 1.0f);
+	const f4 dn = consts[cidx], up = consts[cidx + 1];
+	return cadd(ccoef(1.0f - t, rgba{dn.x, dn.y, dn.z, dn.w}), ccoef(t, rgba{up.x, up.y, up.z, up.w}));
+}
 /* ---- pure nodes (colour / value / vector): postfix programs compiled at upload ---------------- */
-template <class Cnt>
-CRH_DEV_NOINLINE f4 runProgram(const DScene &S, uint32_t pc, const ShadeRec &rec, Cnt &cnt) {
+/* Out-of-line on the device (rare graphs only: checker, grayscale(image), ...). Everything is passed and
+ * returned BY VALUE: a reference parameter would pin the caller's scene / hit record / counters in scratch. */
+struct ProgCtx { const f4 *consts; const DImage *images; const DOp *prog; TexCtx tex; };
+struct ProgResult { f4 v; uint32_t fetches; };
+struct FetchCounter { static constexpr int level = 2; uint32_t tex_fetches; };
+CRH_DEV_NOINLINE ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) {
 	f4 slot[CRH_PROG_SLOTS];
+	FetchCounter cnt;
+	cnt.tex_fetches = 0;
 	for (;;) {
 		const DOp op = S.prog[pc++];
-		if (op.kind == CRH_OP_END) return slot[op.s0];
+		if (op.kind == CRH_OP_END) return ProgResult{slot[op.s0], cnt.tex_fetches};
 		const f4 a = slot[op.s0], b = slot[op.s1], c = slot[op.s2];
 		f4 r = f4{0.0f, 0.0f, 0.0f, 0.0f};
 		switch (op.kind) {
 			case CRH_COLOR_CONSTANT: case CRH_VALUE_CONSTANT: case CRH_VEC_CONSTANT:
 				r = S.consts[op.cidx]; break;
 			case CRH_COLOR_IMAGE: {
-				rgba o = evalImage(S, S.images[op.u], rec.uv, cnt);
+				rgba o = evalImage(S.tex, S.images[op.u], rec.uv, cnt);
 				r = f4{o.r, o.g, o.b, o.a}; break;
 			}
 			case CRH_COLOR_CHECKER: {          /* checker.c:31-54; a=A b=B c=scale (all already evaluated: pure) */
@@ -383,13 +401,7 @@ CRH_DEV_NOINLINE f4 runProgram(const DScene &S, uint32_t pc, const ShadeRec &rec
 				else sines = sinf(coef * rec.point.x) * sinf(coef * rec.point.y) * sinf(coef * rec.point.z);
 				r = sines < 0.0f ? a : b; break;
 			}
-			case CRH_COLOR_GRADIENT: {         /* gradient.c:40-45; consts[cidx]=down, consts[cidx+1]=up */
-				v3 unitDir = vnorm(rec.dir);
-				float t = 0.5f * (unitDir.y + 1.0f);
-				const f4 dn = S.consts[op.cidx], up = S.consts[op.cidx + 1];
-				rgba o = cadd(ccoef(1.0f - t, rgba{dn.x, dn.y, dn.z, dn.w}), ccoef(t, rgba{up.x, up.y, up.z, up.w}));
-				r = f4{o.r, o.g, o.b, o.a}; break;
-			}
+			case CRH_COLOR_GRADIENT: { rgba o = evalGradient(S.consts, op.cidx, rec); r = f4{o.r, o.g, o.b, o.a}; break; }
 			case CRH_COLOR_BLACKBODY: { rgba o = colorForKelvin(a.x); r = f4{o.r, o.g, o.b, o.a}; break; }
 			case CRH_COLOR_COMBINE: r = f4{a.x, a.x, a.x, 1.0f}; break;
 			case CRH_COLOR_COMBINERGB: r = f4{a.x, b.x, c.x, 1.0f}; break;
@@ -449,19 +461,25 @@ CRH_DEV_NOINLINE f4 runProgram(const DScene &S, uint32_t pc, const ShadeRec &rec
 	}
 }
 
+CRH_DEV ProgCtx progCtx(const DScene &S) { return ProgCtx{S.consts, S.images, S.prog, TexCtx{S.textures, S.texdata}}; }
 template <class Cnt>
 CRH_DEV rgba evalColor(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
 	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
 	if (k == CRH_OPR_CONST) { const f4 c = S.consts[i]; return rgba{c.x, c.y, c.z, c.w}; }
-	if (k == CRH_OPR_IMAGE) return evalImage(S, S.images[i], rec.uv, cnt);
-	const f4 c = runProgram(S, i, rec, cnt);
-	return rgba{c.x, c.y, c.z, c.w};
+	if (k == CRH_OPR_IMAGE) return evalImage(TexCtx{S.textures, S.texdata}, S.images[i], rec.uv, cnt);
+	if (k == CRH_OPR_GRADIENT) return evalGradient(S.consts, i, rec);
+	const ProgResult r = runProgram(progCtx(S), i, rec);
+	CRH_COUNT(cnt, tex_fetches, r.fetches);
+	return rgba{r.v.x, r.v.y, r.v.z, r.v.w};
 }
 template <class Cnt>
 CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
 	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
 	if (k == CRH_OPR_CONST) return S.consts[i].x;
-	return runProgram(S, i, rec, cnt).x;
+	if (k == CRH_OPR_IMAGE_ALPHA) return evalImage(TexCtx{S.textures, S.texdata}, S.images[i], rec.uv, cnt).a;
+	const ProgResult r = runProgram(progCtx(S), i, rec);
+	CRH_COUNT(cnt, tex_fetches, r.fetches);
+	return r.v.x;
 }
 
 /* ---- bsdf nodes: src/nodes/shaders ----------------------------------------------------------- */
@@ -606,16 +624,28 @@ CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
 }
 
 /* ---- intersection ------------------------------------------------------------------------------ */
-struct RayK { v3 o, d, inv, ss; uint32_t oct; };
+struct RayK { v3 o, d, inv, ss; uint32_t oct; };   /* oct bits 0..2: signbit of d (bvh.c:368-372); bits 4..6: d component == 0 */
 CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
 	RayK k;
 	k.o = o; k.d = d;
-	k.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u);
+	k.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u)
+		  | (d.x == 0.0f ? 16u : 0u) | (d.y == 0.0f ? 32u : 0u) | (d.z == 0.0f ? 64u : 0u);
 	k.inv = v3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 	k.ss = vscale(vmul(o, k.inv), -1.0f);
 	return k;
 }
-/* bvh.c:326-352; n0 = {minx,maxx,miny,maxy}, n1 = {minz,maxz,first,countLeaf} */
+/* bvh.c:326-352; n0 = {minx,maxx,miny,maxy}, n1 = {minz,maxz,first,countLeaf}.
+ *
+ * One deliberate difference, for rays with an exactly zero direction component (about one camera ray per
+ * 10^5 on a row that crosses the horizon): there invDir = inf and the reference's fma(bound, inf, -start*inf)
+ * is inf - inf = NaN whenever bound and start have the same sign; its NaN-ordered min/max then drops that
+ * slab AND the x slab, so the walk degenerates to a z-only test and visits every node and triangle of the
+ * scene (measured: 451 585 node + 524 290 triangle tests for one ray of input/hdr.json; ~10 ms on a CPU
+ * core, but a third of a second for one GPU lane with the other 63 waiting). Box tests only cull: the
+ * closest hit is decided by the triangle / sphere tests, which never use invDir. So for a zero component we
+ * test the slab exactly (inside iff min <= start <= max): the same hit comes out (up to exact-tie order),
+ * after a normal number of node visits. Documented in DESIGN.md ("degenerate rays"); tests/test_degenerate.py.
+ */
 CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDist, float &tEntry) {
 	const bool ox = k.oct & 1u, oy = k.oct & 2u, oz = k.oct & 4u;
 	float tMinX = __builtin_fmaf(ox ? n0.y : n0.x, k.inv.x, k.ss.x);
@@ -624,6 +654,12 @@ CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDis
 	float tMaxY = __builtin_fmaf(oy ? n0.z : n0.w, k.inv.y, k.ss.y);
 	float tMinZ = __builtin_fmaf(oz ? n1.y : n1.x, k.inv.z, k.ss.z);
 	float tMaxZ = __builtin_fmaf(oz ? n1.x : n1.y, k.inv.z, k.ss.z);
+	if (k.oct & 0x70u) {
+		const float inf = __builtin_inff();
+		if (k.oct & 16u) { const bool in = (n0.x <= k.o.x) && (k.o.x <= n0.y); tMinX = in ? -inf : inf; tMaxX = in ? inf : -inf; }
+		if (k.oct & 32u) { const bool in = (n0.z <= k.o.y) && (k.o.y <= n0.w); tMinY = in ? -inf : inf; tMaxY = in ? inf : -inf; }
+		if (k.oct & 64u) { const bool in = (n1.x <= k.o.z) && (k.o.z <= n1.y); tMinZ = in ? -inf : inf; tMaxZ = in ? inf : -inf; }
+	}
 	float tMin = tMinX > tMinY ? tMinX : tMinY;
 	float tMax = tMaxX < tMaxY ? tMaxX : tMaxY;
 	tMin = tMin > tMinZ ? tMin : tMinZ;
@@ -765,6 +801,9 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 wo, const v3 wd, Tra
 				continue;
 			}
 			if (inst->node_count < 1u) { hit.inst = -1; continue; }             /* bvh.c:362-365 via instance.c:175 */
+			/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
+			 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
+			if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) continue;
 			const RayK ko = makeRayK(o, d);
 			if (inst->node_count == 1u) {                                         /* bvh.c:382-387 */
 				const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
@@ -890,26 +929,40 @@ CRH_DEV bool bounceStep(const DScene &S, Stack &stk, PathState &p, int maxDepth,
 	return p.depth >= maxDepth;
 }
 
+/*
+ * The renderThread() pixel x pass loop (renderer.c:275-301), re-scheduled for a 64-wide wave.
+ *
+ * A wave owns one small pixel block (8x8 or 4x4 pixels of a tile) for a CHUNK of passes at a time. The
+ * block's (pixel, pass) pairs are numbered pixel-major and lane l takes items l, l+64, l+128, ... so at any
+ * moment the 64 lanes trace different passes of the SAME few pixels (coherent rays, one BLAS region in
+ * cache) and every lane sees the same mix of cheap and expensive pixels (no systematic imbalance). Each
+ * iteration of the lane loop is one bounce; a lane whose path ended starts its next item in the same
+ * iteration, so no lane idles until the block's items run out. Finished samples go to a per-wave staging
+ * slab; foldBlockPixel() then folds them into the running mean in pass order, exactly the reference's
+ * sequence (renderer.c:288-291), one pixel per lane.
+ */
+struct BlockJob {
+	int x0, y0;          /* block origin in reference coordinates (y from the bottom) */
+	int w, h;            /* valid extent inside the block (ragged tile edges) */
+	int bw, bh;          /* block shape in pixels */
+	int passBegin;       /* first pass of this chunk (completedSamples - 1) */
+	int passCount;       /* passes in this chunk */
+};
+
 /* running mean: renderer.c:288-291 */
-CRH_DEV void foldSample(float *px, float r, float g, float b, int completedSamples) {
+CRH_DEV void foldSample(float &r, float &g, float &b, float sr, float sg, float sb, int completedSamples) {
 	const float n1 = (float)(completedSamples - 1);
 	const float t = 1.0f / (float)completedSamples;
-	px[0] = ((px[0] * n1) + r) * t;
-	px[1] = ((px[1] * n1) + g) * t;
-	px[2] = ((px[2] * n1) + b) * t;
+	r = ((r * n1) + sr) * t;
+	g = ((g * n1) + sg) * t;
+	b = ((b * n1) + sb) * t;
 }
 
-/*
- * The renderThread() pixel x pass loop (renderer.c:275-301) for ONE lane, flattened so that every
- * iteration is one bounce: a lane whose path ended starts its pixel's next pass (or pulls the next
- * pixel from `work`) at the top of the same loop instead of idling until the rest of the wave is done.
- * A lane owns its pixel for all passes, so the running mean is folded in pass order exactly like the
- * reference. `work.next(x, y)` hands out pixels (reference coordinates: y from the bottom).
- */
-template <class Stack, class Work, class Cnt>
-CRH_DEV void renderLane(const DScene &S, const crh_render_params &P, Stack &stk, Work &work, float *fb, Cnt &cnt) {
-	const int passEnd = P.first_pass + P.pass_count;
-	int x = 0, y = 0, pass = passEnd;
+template <class Stack, class Cnt>
+CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk, const BlockJob &J, uint32_t lane, uint32_t laneStride,
+						 float *stage, Cnt &cnt) {
+	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
+	uint32_t item = lane, cur = 0;
 	bool havePath = false;
 	PathState p;
 	p.depth = 0; p.rng.state = 0;
@@ -917,11 +970,22 @@ CRH_DEV void renderLane(const DScene &S, const crh_render_params &P, Stack &stk,
 	p.wr = p.wg = p.wb = p.fr = p.fg = p.fb = 0.0f;
 	for (;;) {
 		if (!havePath) {
-			if (pass >= passEnd) {
-				if (!work.next(x, y)) break;
-				pass = P.first_pass;
-				if (pass >= passEnd) continue;
+			int x = 0, y = 0, pass = 0;
+			bool found = false;
+			while (item < nItems) {
+				const uint32_t pix = item / (uint32_t)J.passCount;
+				const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
+				if (px < J.w && py < J.h) {
+					x = J.x0 + px; y = J.y0 + py;
+					pass = J.passBegin + (int)(item % (uint32_t)J.passCount);
+					found = true;
+					break;
+				}
+				item += laneStride;
 			}
+			if (!found) break;
+			cur = item;
+			item += laneStride;
 			const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
 			initSampler(p.rng, pass, P.max_passes, pixIdx);                       /* :281 */
 			getCameraRay(S.camera, p.rng, x, y, p.ro, p.rd);                      /* :284 */
@@ -931,12 +995,23 @@ CRH_DEV void renderLane(const DScene &S, const crh_render_params &P, Stack &stk,
 		}
 		const bool done = (P.bounces <= 0) ? true : bounceStep(S, stk, p, P.bounces, cnt);
 		if (done) {
-			float *px = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;   /* texture.c:24-28 */
-			foldSample(px, p.fr, p.fg, p.fb, pass + 1);
-			++pass;
+			float *o = stage + (size_t)cur * 3;
+			o[0] = p.fr; o[1] = p.fg; o[2] = p.fb;
 			havePath = false;
 		}
 	}
+}
+
+/* Fold the staged samples of block pixel `pix` into the float framebuffer (texture.c:24-28 layout). */
+CRH_DEV void foldBlockPixel(const crh_render_params &P, const BlockJob &J, uint32_t pix, const float *stage, float *fb) {
+	const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
+	if (px >= J.w || py >= J.h) return;
+	const int x = J.x0 + px, y = J.y0 + py;
+	float *out = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;
+	float r = out[0], g = out[1], b = out[2];
+	const float *sp = stage + (size_t)pix * (size_t)J.passCount * 3;
+	for (int k = 0; k < J.passCount; ++k) foldSample(r, g, b, sp[3 * k], sp[3 * k + 1], sp[3 * k + 2], J.passBegin + k + 1);
+	out[0] = r; out[1] = g; out[2] = b;
 }
 
 }  // namespace crh

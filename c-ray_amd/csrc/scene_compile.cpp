@@ -145,16 +145,60 @@ struct Compiler {
 		return dst;
 	}
 
+	/* true if the sub-graph rooted at g reads nothing from the hit record (pure function of constants) */
+	bool hitIndependent(uint32_t g) {
+		if (g == CRH_NODE_NONE || g >= s->gnode_count) return false;
+		const crh_gnode &n = s->gnodes[g];
+		switch (n.kind) {
+			case CRH_COLOR_CONSTANT: case CRH_VALUE_CONSTANT: case CRH_VEC_CONSTANT: return true;
+			case CRH_COLOR_BLACKBODY: case CRH_COLOR_COMBINE: case CRH_COLOR_VECTOCOLOR: case CRH_VALUE_ALPHA: case CRH_VALUE_GRAYSCALE:
+				return n.a < g && hitIndependent(n.a);
+			case CRH_COLOR_COMBINERGB: return n.a < g && n.b < g && n.c < g && hitIndependent(n.a) && hitIndependent(n.b) && hitIndependent(n.c);
+			case CRH_VALUE_MATH: case CRH_VEC_VECMATH: return n.a < g && n.b < g && hitIndependent(n.a) && hitIndependent(n.b);
+			default: return false;   /* image, checker, gradient, fresnel, rayLength, normal read the hit */
+		}
+	}
+
+	/* Fold a hit-independent sub-graph by running its program once on the host: the same lane code
+	 * (pt_device.h, host build, -ffp-contract=off) with the host libm, i.e. exactly the value the reference
+	 * would recompute at every hit. */
+	f4 foldOnHost(uint32_t g, uint32_t parent, Cls cls) {
+		const size_t progMark = out.prog.size(), constMark = out.consts.size();
+		Slots sl;
+		const int res = emit(g, parent, cls, sl);
+		DOp end;
+		memset(&end, 0, sizeof(end));
+		end.kind = CRH_OP_END;
+		end.s0 = (uint8_t)res;
+		out.prog.push_back(end);
+		ProgCtx d;
+		memset(&d, 0, sizeof(d));
+		d.consts = out.consts.data(); d.prog = out.prog.data(); d.images = out.images.data();
+		ShadeRec rec;
+		memset(&rec, 0, sizeof(rec));
+		const f4 v = runProgram(d, (uint32_t)progMark, rec).v;
+		out.prog.resize(progMark);
+		out.consts.resize(constMark);
+		return v;
+	}
+
 	uint32_t operand(uint32_t g, uint32_t parent, Cls cls) {
 		const crh_gnode &n = gnode(g, parent, cls);
 		auto it = oprMemo.find(g);
 		if (it != oprMemo.end()) return it->second;
 		uint32_t r;
-		if (n.kind == CRH_COLOR_CONSTANT) r = CRH_OPR(CRH_OPR_CONST, addConst(n.f[0], n.f[1], n.f[2], n.f[3]));
-		else if (n.kind == CRH_VALUE_CONSTANT) r = CRH_OPR(CRH_OPR_CONST, addConst(n.f[0], 0, 0, 0));
-		else if (n.kind == CRH_VEC_CONSTANT) r = CRH_OPR(CRH_OPR_CONST, addConst(n.f[0], n.f[1], n.f[2], 0));
-		else if (n.kind == CRH_COLOR_IMAGE) r = CRH_OPR(CRH_OPR_IMAGE, addImage(n));
-		else {
+		if (hitIndependent(g)) {
+			const f4 v = foldOnHost(g, parent, cls);
+			r = CRH_OPR(CRH_OPR_CONST, addConst(v.x, v.y, v.z, v.w));
+		} else if (n.kind == CRH_COLOR_IMAGE) {
+			r = CRH_OPR(CRH_OPR_IMAGE, addImage(n));
+		} else if (n.kind == CRH_VALUE_ALPHA && n.a < g && s->gnodes[n.a].kind == CRH_COLOR_IMAGE) {
+			r = CRH_OPR(CRH_OPR_IMAGE_ALPHA, addImage(s->gnodes[n.a]));
+		} else if (n.kind == CRH_COLOR_GRADIENT) {
+			const uint32_t c = addConst(n.f[0], n.f[1], n.f[2], n.f[3]);
+			addConst(n.f[4], n.f[5], n.f[6], n.f[7]);
+			r = CRH_OPR(CRH_OPR_GRADIENT, c);
+		} else {
 			const uint32_t pc = (uint32_t)out.prog.size();
 			Slots sl;
 			const int res = emit(g, parent, cls, sl);

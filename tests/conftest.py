@@ -1,0 +1,97 @@
+"""Shared fixtures. CPU tier: `pytest -m "not gpu"`; GPU tier (parity through the C-ABI): `pytest -m gpu`."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_blob(tmp_path_factory):
+    """name -> path of the decompressed scene blob fixture."""
+    cache = {}
+    root = tmp_path_factory.mktemp("blobs")
+
+    def get(name):
+        if name not in cache:
+            out = os.path.join(root, name + ".blob")
+            with gzip.open(os.path.join(GOLDEN, name + ".blob.gz"), "rb") as f, open(out, "wb") as g:
+                g.write(f.read())
+            cache[name] = out
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def golden_ref(manifest):
+    """name -> float32 [H, W, 3] render buffer of the real reference (c-ray-ref-strict)."""
+    def get(name):
+        m = manifest[name]
+        with gzip.open(os.path.join(GOLDEN, name + ".ref.f32.gz"), "rb") as f:
+            return np.frombuffer(f.read(), dtype=np.float32).reshape(m["height"], m["width"], 3).copy()
+    return get
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"])
+    import oracle_py
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def emu(oracle):
+    """ctypes handle of the host emulation of the device lane code (tests/emu, test infrastructure)."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "tests", "emu")])
+    abi = oracle.abi
+    L = C.CDLL(os.path.join(REPO, "tests", "emu", "libcray_emu.so"))
+    L.emu_render_region.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RenderParams), C.c_void_p, C.POINTER(abi.Counters),
+                                    C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int]
+    L.emu_trace_rays.argtypes = [C.POINTER(abi.SceneDesc), C.c_void_p, C.c_uint64, C.c_void_p]
+    L.emu_compile_check.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.emu_last_error.restype = C.c_char_p
+    return L
+
+
+def image_stats(img, ref):
+    d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+    per_px = np.sqrt((d ** 2).sum(axis=2))
+    return {"rmse": float(np.sqrt((d ** 2).mean())), "max": float(d.max()), "mean_l2": float(per_px.mean()),
+            "frac_gt_1e-3": float((per_px > 1e-3).mean()), "frac_ne": float((d.max(axis=2) > 0).mean())}
+
+
+def camera_rays(desc, n, seed):
+    """n world-space rays from the camera position, spread around the viewing direction (6 floats each)."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 6), np.float32)
+    cam = desc.camera
+    A = np.array(list(cam.A), dtype=np.float64).reshape(3, 4)
+    local = np.stack([rng.normal(size=n) * 0.35, rng.normal(size=n) * 0.25, np.ones(n)], axis=1)
+    rays[:, 0:3] = A[:, 3]
+    rays[:, 3:6] = (local @ A[:, :3].T).astype(np.float32)
+    return rays

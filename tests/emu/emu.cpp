@@ -9,6 +9,7 @@
  * the GPU tier then only has to absorb the libm differences. Never linked into libcray_hip.so and never
  * used by bench.py or the product.
  */
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,15 +25,6 @@ struct ArrayStack {
 	uint32_t high = 0;
 	void push(uint32_t i, uint32_t v) { e[i] = v; if (i + 1 > high) high = i + 1; }
 	uint32_t pop(uint32_t i) { return e[i]; }
-};
-struct RegionWork {
-	int x0, y0, x1, y1, x, y;
-	bool next(int &ox, int &oy) {
-		if (x0 >= x1 || y < y0) return false;
-		ox = x; oy = y;
-		if (++x == x1) { x = x0; --y; }
-		return true;
-	}
 };
 DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
 	DScene d;
@@ -63,14 +55,20 @@ int emu_compile_check(const crh_scene_desc *scene, uint32_t *max_stack, uint32_t
 	return CRH_OK;
 }
 
-int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, float *fb, crh_counters *out, uint32_t *stack_high) {
+/* The kernel's schedule, one "wave" at a time: blocks of bw x bh pixels, chunks of `chunk` passes, 64 lanes
+ * striding over the block's items, then the per-pixel fold. */
+int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, float *fb, crh_counters *out, uint32_t *stack_high,
+					  int bw, int bh, int chunk) {
 	CompiledScene c;
 	int rc = compile_scene(scene, c, g_err);
 	if (rc != CRH_OK) return rc;
+	if (bw <= 0 || bh <= 0 || bw * bh > 256 || chunk <= 0) { g_err = "bad block shape"; return CRH_ERR_INVALID; }
 	const DScene d = make_dscene(scene, c);
 	crh_counters total;
 	memset(&total, 0, sizeof(total));
 	uint32_t high = 0;
+	const int W = p->x1 - p->x0, H = p->y1 - p->y0;
+	const int nbx = (W + bw - 1) / bw, nby = (H + bh - 1) / bh;
 	#pragma omp parallel
 	{
 		Counters cnt;
@@ -78,12 +76,22 @@ int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, f
 		crh_counters mine;
 		memset(&mine, 0, sizeof(mine));
 		uint32_t myHigh = 0;
+		std::vector<float> stage((size_t)bw * bh * chunk * 3);
 		#pragma omp for schedule(dynamic, 1)
-		for (int y = p->y1 - 1; y >= p->y0; --y) {
-			ArrayStack stk;
-			RegionWork w{p->x0, y, p->x1, y + 1, p->x0, y};
-			renderLane(d, *p, stk, w, fb, cnt);
-			if (stk.high > myHigh) myHigh = stk.high;
+		for (int blk = 0; blk < nbx * nby; ++blk) {
+			BlockJob J;
+			J.bw = bw; J.bh = bh;
+			J.x0 = p->x0 + (blk % nbx) * bw; J.y0 = p->y0 + (blk / nbx) * bh;
+			J.w = std::min(bw, p->x1 - J.x0); J.h = std::min(bh, p->y1 - J.y0);
+			for (int c0 = p->first_pass; c0 < p->first_pass + p->pass_count; c0 += chunk) {
+				J.passBegin = c0; J.passCount = std::min(chunk, p->first_pass + p->pass_count - c0);
+				for (uint32_t lane = 0; lane < 64; ++lane) {
+					ArrayStack stk;
+					renderItems(d, *p, stk, J, lane, 64u, stage.data(), cnt);
+					if (stk.high > myHigh) myHigh = stk.high;
+				}
+				for (uint32_t pix = 0; pix < (uint32_t)(bw * bh); ++pix) foldBlockPixel(*p, J, pix, stage.data(), fb);
+			}
 			mine.paths += cnt.paths; mine.rays += cnt.rays; mine.node_tests += cnt.node_tests; mine.tri_tests += cnt.tri_tests;
 			mine.inst_visits += cnt.inst_visits; mine.inst_hits += cnt.inst_hits; mine.sphere_tests += cnt.sphere_tests; mine.tex_fetches += cnt.tex_fetches;
 			memset(&cnt, 0, sizeof(cnt));
@@ -127,3 +135,30 @@ int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, c
 }
 
 }  // extern "C"
+
+/* debug: the most expensive single path (by node tests) in a region: out = {x, y, pass, node_tests, tri_tests, rays} */
+extern "C" int emu_find_heaviest_path(const crh_scene_desc *scene, const crh_render_params *p, uint64_t *out6) {
+	CompiledScene c;
+	int rc = compile_scene(scene, c, g_err);
+	if (rc != CRH_OK) return rc;
+	const DScene d = make_dscene(scene, c);
+	uint64_t best[6] = {0, 0, 0, 0, 0, 0};
+	#pragma omp parallel for schedule(dynamic, 1)
+	for (int y = p->y0; y < p->y1; ++y) {
+		uint64_t mine[6] = {0, 0, 0, 0, 0, 0};
+		std::vector<float> stage(3);
+		for (int x = p->x0; x < p->x1; ++x)
+			for (int pass = p->first_pass; pass < p->first_pass + p->pass_count; ++pass) {
+				BlockJob J{x, y, 1, 1, 1, 1, pass, 1};
+				ArrayStack stk;
+				Counters cnt;
+				memset(&cnt, 0, sizeof(cnt));
+				renderItems(d, *p, stk, J, 0u, 64u, stage.data(), cnt);
+				if (cnt.node_tests > mine[3]) { mine[0] = x; mine[1] = y; mine[2] = pass; mine[3] = cnt.node_tests; mine[4] = cnt.tri_tests; mine[5] = cnt.rays; }
+			}
+		#pragma omp critical
+		if (mine[3] > best[3]) memcpy(best, mine, sizeof(best));
+	}
+	memcpy(out6, best, sizeof(best));
+	return CRH_OK;
+}

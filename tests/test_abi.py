@@ -1,0 +1,65 @@
+"""The C-ABI: struct layouts of abi.py match include/cray_hip.h, the library loads and exports every symbol,
+and — without a GPU — refuses to compute instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STRUCTS = {"crh_bvh_node": "BvhNode", "crh_poly": "Poly", "crh_instance": "Instance", "crh_mesh": "Mesh", "crh_sphere": "Sphere",
+           "crh_material": "Material", "crh_gnode": "GNode", "crh_texture": "Texture", "crh_camera": "Camera",
+           "crh_scene_desc": "SceneDesc", "crh_render_params": "RenderParams", "crh_counters": "Counters", "crh_hit": "Hit",
+           "crh_blob_prefs": "BlobPrefs", "crh_tile": "Tile"}
+
+
+def test_struct_sizes_match_header(pkg, tmp_path):
+    src = tmp_path / "sizes.c"
+    body = "\n".join(f'printf("{c} %zu\\n", sizeof({c}));' for c in STRUCTS)
+    src.write_text('#include <stdio.h>\n#include "cray_hip.h"\nint main(void){' + body + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I" + os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode()
+    for line in out.splitlines():
+        cname, size = line.split()
+        assert C.sizeof(getattr(pkg.abi, STRUCTS[cname])) == int(size), cname
+    assert C.sizeof(pkg.abi.Instance) == 128 and C.sizeof(pkg.abi.BvhNode) == 32 and C.sizeof(pkg.abi.Poly) == 40
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(REPO, "include", "cray_hip.h")).read()
+    declared = set(re.findall(r"\b(crh_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pkg.abi.EXPORTED_SYMBOLS), declared ^ set(pkg.abi.EXPORTED_SYMBOLS)
+    lib = pkg.api.library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.crh_abi_version() == pkg.abi.ABI_VERSION
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    """On a box without a GPU the product must refuse (CRH_ERR_NO_DEVICE), never compute on the CPU."""
+    if pkg.api.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pkg.api.CrhError) as e:
+        pkg.api.Context(0)
+    assert e.value.code == pkg.abi.ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, bench.py (cpu_baseline) and __graft_entry__.smoke() may touch oracle/."""
+    for root, _, files in os.walk(os.path.join(REPO, "c-ray_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".cpp", ".hip")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "oracle_py" not in text and "libcray_oracle" not in text and "cray_oracle.h" not in text, os.path.join(root, f)
+
+
+def test_blob_roundtrip(pkg, golden_blob, tmp_path):
+    scene = pkg.api.Scene(golden_blob("fence"))
+    out = str(tmp_path / "copy.blob")
+    rc = pkg.api.library().crh_blob_save(out.encode(), scene.ptr, C.byref(scene.prefs))
+    assert rc == 0
+    assert open(out, "rb").read() == open(golden_blob("fence"), "rb").read()
+    with pytest.raises(pkg.api.CrhError):
+        pkg.api.Scene(str(tmp_path / "missing.blob"))

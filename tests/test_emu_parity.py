@@ -1,0 +1,93 @@
+"""CPU tier for the KERNEL LOGIC: the lane-level device code (c-ray_amd/csrc/pt_device.h) and the product's
+scene compiler, built for the host (tests/emu), must match the oracle bit for bit — same traversal order,
+RNG draw order, node programs, block/chunk schedule and fold order as the reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import camera_rays
+
+CASES = ["cfg1_scene", "alphanode", "fence", "glowmetal", "refraction", "uvsphere"]
+
+
+def emu_render(emu, oracle, scene, w, h, s, b, region=None, shape=(8, 8), chunk=64):
+    abi = oracle.abi
+    x0, y0, x1, y1 = region or (0, 0, w, h)
+    fb = np.zeros((h, w, 3), np.float32)
+    cnt, hi = abi.Counters(), C.c_uint32()
+    p = abi.RenderParams(x0, y0, x1, y1, w, h, 0, s, s, b)
+    rc = emu.emu_render_region(scene.ptr, C.byref(p), fb.ctypes.data, C.byref(cnt), C.byref(hi), shape[0], shape[1], chunk)
+    assert rc == 0, emu.emu_last_error()
+    return fb, cnt.as_dict(), hi.value
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_emulated_kernel_bit_exact_vs_reference(name, emu, oracle, manifest, golden_blob, golden_ref):
+    m = manifest[name]
+    scene = oracle.OracleScene(golden_blob(name))
+    fb, cnt, high = emu_render(emu, oracle, scene, m["width"], m["height"], m["samples"], m["bounces"])
+    ref = golden_ref(name)
+    assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32)), f"{name}: {(fb != ref).sum()} floats differ"
+    assert cnt["rays"] == m["rays"] and cnt["paths"] == m["width"] * m["height"] * m["samples"]
+    # exact node / triangle visit counts too, unless a zero-component ray took the exact-slab path (fewer visits)
+    assert cnt["node_tests"] <= m["node_tests"] and cnt["tri_tests"] <= m["tri_tests"]
+    assert cnt["node_tests"] >= 0.98 * m["node_tests"]
+    mx = C.c_uint32()
+    assert emu.emu_compile_check(scene.ptr, C.byref(mx), None, None) == 0
+    assert high <= mx.value, "traversal stack bound computed by the scene compiler was exceeded"
+
+
+@pytest.mark.parametrize("shape,chunk", [((8, 8), 3), ((4, 4), 1), ((2, 2), 64), ((16, 16), 2), ((1, 1), 4)])
+def test_block_schedule_is_order_independent(shape, chunk, emu, oracle, manifest, golden_blob, golden_ref):
+    """Any block shape / pass chunking folds the samples in pass order -> identical frame (ragged edges included)."""
+    m = manifest["fence"]
+    scene = oracle.OracleScene(golden_blob("fence"))
+    fb, _, _ = emu_render(emu, oracle, scene, m["width"], m["height"], m["samples"], m["bounces"], shape=shape, chunk=chunk)
+    assert np.array_equal(fb, golden_ref("fence"))
+
+
+@pytest.mark.parametrize("name", ["cfg1_scene", "refraction", "uvsphere"])
+def test_trace_rays_records_identical(name, emu, oracle, golden_blob):
+    scene = oracle.OracleScene(golden_blob(name))
+    rays = camera_rays(scene.desc, 20000, 3)
+    ho = oracle.trace_rays(scene, rays)
+    he = np.zeros(len(rays), dtype=oracle.abi.HIT_DTYPE)
+    assert emu.emu_trace_rays(scene.ptr, rays.ctypes.data, len(rays), he.ctypes.data) == 0
+    assert ho.tobytes() == he.tobytes()
+    assert (ho["inst"] >= 0).sum() > 500
+
+
+def test_zero_component_rays_same_hit_fewer_visits(emu, oracle, golden_blob):
+    """Rays with an exactly zero direction component: the reference's NaN slab arithmetic visits (nearly) every
+    node; the device code tests that slab exactly. Same hit record, never more node visits."""
+    scene = oracle.OracleScene(golden_blob("cfg1_scene"))
+    rays = camera_rays(scene.desc, 3000, 11)
+    rays[0::3, 3] = 0.0
+    rays[1::3, 4] = 0.0
+    rays[2::3, 5] = 0.0
+    ho = oracle.trace_rays(scene, rays)
+    he = np.zeros(len(rays), dtype=oracle.abi.HIT_DTYPE)
+    assert emu.emu_trace_rays(scene.ptr, rays.ctypes.data, len(rays), he.ctypes.data) == 0
+    for f in ("inst", "poly", "distance", "uv", "point", "normal", "material"):
+        assert np.array_equal(ho[f], he[f]), f
+    assert (he["node_tests"] <= ho["node_tests"]).all() and he["node_tests"].sum() < ho["node_tests"].sum()
+
+
+def test_scene_compiler_rejects_malformed_scenes(emu, oracle, golden_blob):
+    abi = oracle.abi
+    scene = oracle.OracleScene(golden_blob("fence"))
+    d = scene.desc
+
+    def check(expect):
+        rc = emu.emu_compile_check(scene.ptr, None, None, None)
+        assert rc == expect, (rc, emu.emu_last_error())
+
+    check(0)
+    old = d.abi_version; d.abi_version = 99; check(abi.ERR_INVALID); d.abi_version = old
+    old = d.background; d.background = 0; check(abi.ERR_INVALID); d.background = old
+    old = d.nodes[0].first; d.nodes[0].first = 10 ** 6; check(abi.ERR_INVALID); d.nodes[0].first = old
+    old = d.polys[0].v[0]; d.polys[0].v[0] = -5; check(abi.ERR_INVALID); d.polys[0].v[0] = old
+    old = d.instances[0].kind; d.instances[0].kind = 3; check(abi.ERR_UNSUPPORTED); d.instances[0].kind = old
+    old = d.materials[0].bsdf; d.materials[0].bsdf = abi.NODE_NONE; check(abi.ERR_INVALID); d.materials[0].bsdf = old
+    check(0)

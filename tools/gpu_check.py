@@ -76,19 +76,24 @@ def main():
             out[f"cfg2_{spp}spp"] = {"stats": stats(img, ref), "gpu_counters": cnt, "oracle_counters": ocnt, "kernel_ms": ms,
                                      "gpu_mrays": cnt["rays"] / ms / 1e3, "cpu_s": tc, "cpu_mrays": ocnt["rays"] / tc / 1e6}
             print(f"cfg2 {spp}spp", out[f"cfg2_{spp}spp"], flush=True)
-        for level in (2, 1):
-            ctx.set_option(pkg.abi.OPT_COUNTER_LEVEL, level)
-            for bpc in (1, 2, 4):
-                ctx.set_option(pkg.abi.OPT_BLOCKS_PER_CU, bpc)
-                ctx.clear(fb2, w, h)
-                ctx.reset_counters()
-                spp = 64
-                ctx.render_region(fb2, w, h, spp, b)
-                ctx.synchronize()
-                cnt = ctx.counters()
-                ms = ctx.kernel_time_ms()[0]
-                out[f"cfg2_{spp}spp_l{level}_b{bpc}"] = {"kernel_ms": ms, "rays": cnt["rays"], "mrays": cnt["rays"] / ms / 1e3}
-                print(f"cfg2 {spp}spp level{level} blocks/CU {bpc}", out[f"cfg2_{spp}spp_l{level}_b{bpc}"], flush=True)
+        for wps in (1, 4):
+            ctx.set_option(pkg.abi.OPT_WAVES_PER_SIMD, wps)
+            for level in (2, 1):
+                ctx.set_option(pkg.abi.OPT_COUNTER_LEVEL, level)
+                for bpc in ((1, 2) if wps == 1 else (2, 4)):
+                    for chunk in (16, 64):
+                        ctx.set_option(pkg.abi.OPT_BLOCKS_PER_CU, bpc)
+                        ctx.set_option(pkg.abi.OPT_PASS_CHUNK, chunk)
+                        ctx.clear(fb2, w, h)
+                        ctx.reset_counters()
+                        spp = 64
+                        ctx.render_region(fb2, w, h, spp, b)
+                        ctx.synchronize()
+                        cnt = ctx.counters()
+                        ms = ctx.kernel_time_ms()[0]
+                        key = f"cfg2_{spp}spp_w{wps}_l{level}_b{bpc}_c{chunk}"
+                        out[key] = {"kernel_ms": ms, "rays": cnt["rays"], "mrays": cnt["rays"] / ms / 1e3}
+                        print(key, out[key], flush=True)
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "gpu_check.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -32,7 +32,7 @@ using namespace crh;
 
 /* ---- tunables ---------------------------------------------------------------------------------- */
 #define CRH_BLOCK 256            /* 4 waves of 64 */
-#define CRH_STACK_LDS 24         /* traversal stack entries kept in LDS per lane (24 KB per block) */
+#define CRH_STACK_LDS 30         /* traversal stack entries kept in LDS per lane; with the 22 park slots: 52 KB per block, 3 blocks per CU */
 
 /* ---- error plumbing ---------------------------------------------------------------------------- */
 static thread_local std::string t_err;
@@ -53,6 +53,9 @@ struct LdsStack {
 	uint32_t *lds;       /* &s_stack[threadIdx.x]; entry i at lds[i * CRH_BLOCK]: bank = lane % 32, conflict-free */
 	uint32_t *spill;     /* &spill[global thread]; entry j at spill[j * stride] (coalesced across lanes) */
 	uint32_t stride;
+	uint32_t *parkp;     /* &s_park[threadIdx.x]; slot i at parkp[i * CRH_BLOCK] */
+	__device__ __forceinline__ void park(int i, uint32_t v) { parkp[i * CRH_BLOCK] = v; }
+	__device__ __forceinline__ uint32_t unpark(int i) { return parkp[i * CRH_BLOCK]; }
 	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
 		if (__builtin_expect(i < CRH_STACK_LDS, 1)) lds[i * CRH_BLOCK] = v;
 		else spillStore(spill + (size_t)(i - CRH_STACK_LDS) * stride, v);
@@ -86,7 +89,7 @@ __device__ __forceinline__ DScene globalize(const DScene &S) {
 	G.vertices = asGlobal(S.vertices); G.normals = asGlobal(S.normals); G.texcoords = asGlobal(S.texcoords);
 	G.instances = asGlobal(S.instances); G.meshes = asGlobal(S.meshes); G.materials = asGlobal(S.materials);
 	G.bsdfs = asGlobal(S.bsdfs); G.consts = asGlobal(S.consts); G.images = asGlobal(S.images); G.prog = asGlobal(S.prog);
-	G.textures = asGlobal(S.textures); G.texdata = asGlobal(S.texdata);
+	G.textures = asGlobal(S.textures); G.texels = asGlobal(S.texels);
 	return G;
 }
 
@@ -95,16 +98,13 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 	return v;
 }
 
-template <int LEVEL> struct CountersFor;
-template <> struct CountersFor<2> { typedef Counters type; };
-template <> struct CountersFor<1> { typedef LiteCounters type; };
-
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
-template <int LEVEL, int WPS>
+template <int LEVEL, int WPS, bool PROG>
 __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 														   unsigned long long *counters, uint32_t *spill, uint32_t spillStride,
 														   float *stage, int chunk, unsigned long long *waveStats) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
 	const unsigned long long tStart = wall_clock64();
 	uint32_t unitsDone = 0;
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 	stk.lds = &s_stack[threadIdx.x];
 	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
 	stk.stride = spillStride;
-	typename CountersFor<LEVEL>::type cnt;
+	stk.parkp = &s_park[threadIdx.x];
+	CountersT<LEVEL, PROG> cnt;
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
@@ -165,11 +166,13 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 
 __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits, uint32_t *spill, uint32_t spillStride) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
 	LdsStack stk;
 	stk.lds = &s_stack[threadIdx.x];
 	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
 	stk.stride = spillStride;
+	stk.parkp = &s_park[threadIdx.x];
 	for (uint64_t i = (uint64_t)blockIdx.x * CRH_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CRH_BLOCK) {
 		Counters cnt;
 		memset(&cnt, 0, sizeof(cnt));
@@ -216,6 +219,7 @@ struct crh_ctx {
 	float *dStage = nullptr;
 	size_t stageFloats = 0;
 	bool haveScene = false;
+	bool hasPrograms = true;     /* the compiled scene contains node programs -> kernel variant with runProgram() */
 	DScene d;                              /* device pointers */
 	std::vector<void *> sceneAllocs;
 	uint32_t maxStack = 0;
@@ -385,13 +389,14 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(consts, cs.consts.data(), cs.consts.size());
 	UP(images, cs.images.data(), cs.images.size());
 	UP(prog, cs.prog.data(), cs.prog.size());
-	UP(textures, scene->textures, (size_t)scene->texture_count);
-	UP(texdata, scene->texture_data, (size_t)scene->texture_bytes);
+	UP(textures, cs.textures.data(), cs.textures.size());
+	UP(texels, cs.texels.data(), cs.texels.size());
 #undef UP
 	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base;
 	d.background = cs.background; d.camera = cs.camera;
 	c->d = d;
 	c->maxStack = cs.max_stack;
+	c->hasPrograms = cs.prog.size() > 1 || getenv("CRH_FORCE_PROGRAMS") != nullptr;
 	c->haveScene = true;
 	return CRH_OK;
 }
@@ -536,10 +541,12 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
-#define CRH_LAUNCH(LEVEL, WPS) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+#define CRH_LAUNCH(LEVEL, WPS, PROG) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 												  c->dCounters, c->dSpill, grid * CRH_BLOCK, c->dStage, chunk, c->dWaveStats)
-	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH(2, 4); else CRH_LAUNCH(2, 1); }
-	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH(1, 4); else CRH_LAUNCH(1, 1); }
+#define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true); else CRH_LAUNCH(LEVEL, WPS, false); } while (0)
+	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
+	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
+#undef CRH_LAUNCH2
 #undef CRH_LAUNCH
 	hipError_t e = hipGetLastError();
 	HIP_TRY(hipEventRecord(ev.b, c->stream));

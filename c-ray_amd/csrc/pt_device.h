@@ -65,6 +65,16 @@ struct alignas(16) DInstance {
 
 struct DImage { uint32_t tex; uint32_t options; };
 
+/* Device texture: texels expanded at upload to one f4 {r,g,b,a} each (the /255.0f of 8-bit data, the channel
+ * replication of 1-channel data and the alpha default of texture.c:32-63 are applied once, with the same IEEE
+ * operations), rows stored so that texel (x, y) of textureGetPixelInternal is texels[first + x + y * width]. */
+struct DTexture {
+	uint32_t first;        /* index of the first texel in texels[] */
+	uint32_t width, height;
+	uint32_t m64w, m64h;   /* 2^64 mod width / height: (size_t)(negative int) % W of texture.c:37-38 in 32-bit math */
+	uint32_t pad[3];
+};
+
 /* postfix program op: dst = op(src...) over a small operand file of f4 slots */
 struct alignas(16) DOp {
 	uint16_t kind;        /* enum crh_node_kind of the pure node, or CRH_OP_END */
@@ -92,8 +102,8 @@ struct DScene {
 	const f4 *consts;
 	const DImage *images;
 	const DOp *prog;
-	const crh_texture *textures;
-	const uint8_t *texdata;
+	const DTexture *textures;
+	const f4 *texels;
 	uint32_t tlas_root;         /* device index of the TLAS root's child pair (or of the root leaf if tlas_node_count == 1) */
 	uint32_t tlas_node_count;
 	uint32_t tlas_prim_base;
@@ -101,18 +111,26 @@ struct DScene {
 	crh_camera camera;
 };
 
-/* Counter levels: 0 none, 1 rays + paths only (timed runs), 2 everything (parity / roofline runs). */
-struct Counters {
+/* Counter levels: 0 none, 1 rays + paths only (timed runs), 2 everything (parity / roofline runs).
+ * The counter type also carries the compile-time switch `programs`: kernels instantiated with programs = false
+ * contain no call to runProgram() (a device function call in the persistent loop costs ~200 SGPR spills and
+ * the callee's register budget); the host picks that variant when the compiled scene has no node programs. */
+template <int LEVEL, bool PROGRAMS> struct CountersT;
+template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	static constexpr int level = 2;
+	static constexpr bool programs = PROGRAMS;
 	uint32_t rays, node_tests, tri_tests, inst_visits, inst_hits, sphere_tests, tex_fetches, paths;
 };
-struct LiteCounters {
+template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
 	static constexpr int level = 1;
+	static constexpr bool programs = PROGRAMS;
 	uint32_t rays, paths;
 };
-struct NoCounters { static constexpr int level = 0; };
-template <class T> struct cnt_traits { static constexpr int level = T::level; };
-template <class T> struct cnt_traits<T &> { static constexpr int level = T::level; };
+typedef CountersT<2, true> Counters;
+typedef CountersT<1, true> LiteCounters;
+struct NoCounters { static constexpr int level = 0; static constexpr bool programs = true; };
+template <class T> struct cnt_traits { static constexpr int level = T::level; static constexpr bool programs = T::programs; };
+template <class T> struct cnt_traits<T &> { static constexpr int level = T::level; static constexpr bool programs = T::programs; };
 /* CRH_COUNT: detailed counters (level 2); CRH_COUNT1: rays / paths (level >= 1) */
 #define CRH_COUNT(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 2) (c).field += (n); } while (0)
 #define CRH_COUNT1(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 1) (c).field += (n); } while (0)
@@ -295,42 +313,30 @@ CRH_DEV void getCameraRay(const crh_camera &cam, Rng &rng, int x, int y, v3 &ro,
 }
 
 /* ---- textures: texture.c:32-79 ----------------------------------------------------------------- */
-/* (size_t)i % W for a possibly negative int i (sign-extended to 64 bits like the reference's cast) */
-CRH_DEV uint32_t wrapIndex(int i, uint32_t W) {
+/* (size_t)i % W for a possibly negative int i: the reference sign-extends to 64 bits, so a negative i wraps
+ * as (2^64 - |i|) % W = (m64 + W - |i| % W) % W with m64 = 2^64 mod W — all in 32-bit arithmetic here. */
+CRH_DEV uint32_t wrapIndex(int i, uint32_t W, uint32_t m64) {
 	if (i >= 0) return (uint32_t)i % W;
-	return (uint32_t)((uint64_t)(int64_t)i % (uint64_t)W);
+	const uint32_t a = (uint32_t)(-(int64_t)i) % W;
+	return (m64 + W - a) % W;
 }
-struct TexCtx { const crh_texture *textures; const uint8_t *texdata; };
+struct TexCtx { const DTexture *textures; const f4 *texels; };
 template <class Cnt>
-CRH_DEV rgba texel(const TexCtx S, const crh_texture &t, uint32_t x, uint32_t y, Cnt &cnt) {
+CRH_DEV rgba texel(const TexCtx S, const DTexture &t, uint32_t x, uint32_t y, Cnt &cnt) {
 	CRH_COUNT(cnt, tex_fetches, 1);
-	const uint8_t *bytes = S.texdata + t.offset;
-	const float *floats = (const float *)bytes;
-	const uint32_t W = t.width, H = t.height, C = t.channels;
-	const size_t base = ((size_t)x + (size_t)((H - 1u) - y) * (size_t)W) * (size_t)C;
-	rgba o;
-	if (C == 1u) {
-		o.r = t.is_float ? floats[base] : (float)bytes[base] / 255.0f;
-		o.g = o.r; o.b = o.r; o.a = 1.0f;
-	} else if (t.is_float) {
-		o.r = floats[base + 0]; o.g = floats[base + 1]; o.b = floats[base + 2];
-		o.a = t.has_alpha ? floats[base + 3] : 1.0f;
-	} else {
-		o.r = (float)bytes[base + 0] / 255.0f; o.g = (float)bytes[base + 1] / 255.0f; o.b = (float)bytes[base + 2] / 255.0f;
-		o.a = t.has_alpha ? (float)bytes[base + 3] / 255.0f : 1.0f;
-	}
-	return o;
+	const f4 o = S.texels[t.first + x + y * t.width];
+	return rgba{o.x, o.y, o.z, o.w};
 }
 template <class Cnt>
-CRH_DEV rgba textureGetPixelFiltered(const TexCtx S, const crh_texture &t, float x, float y, Cnt &cnt) {
+CRH_DEV rgba textureGetPixelFiltered(const TexCtx S, const DTexture &t, float x, float y, Cnt &cnt) {
 	x = x * (float)t.width;
 	y = y * (float)t.height;
 	float xcopy = x - 0.5f;
 	float ycopy = y - 0.5f;
 	int xint = (int)xcopy;
 	int yint = (int)ycopy;
-	const uint32_t x0 = wrapIndex(xint, t.width), x1 = wrapIndex(xint + 1, t.width);
-	const uint32_t y0 = wrapIndex(yint, t.height), y1 = wrapIndex(yint + 1, t.height);
+	const uint32_t x0 = wrapIndex(xint, t.width, t.m64w), x1 = wrapIndex(xint + 1, t.width, t.m64w);
+	const uint32_t y0 = wrapIndex(yint, t.height, t.m64h), y1 = wrapIndex(yint + 1, t.height, t.m64h);
 	rgba topleft = texel(S, t, x0, y0, cnt);
 	rgba topright = texel(S, t, x1, y0, cnt);
 	rgba botleft = texel(S, t, x0, y1, cnt);
@@ -342,12 +348,15 @@ CRH_DEV rgba textureGetPixelFiltered(const TexCtx S, const crh_texture &t, float
 template <class Cnt>
 CRH_DEV rgba evalImage(const TexCtx S, const DImage im, v2 uv, Cnt &cnt) {
 	if (im.tex == CRH_NONE) return rgba{1.0f, 0.0f, 0.5f, 1.0f};   /* warningMaterial().diffuse, material.c:38 */
-	const crh_texture t = S.textures[im.tex];
+	const DTexture t = S.textures[im.tex];
 	rgba out;
 	if (im.options & CRH_IMAGE_NO_BILINEAR) {
 		float x = uv.x * (float)t.width;
 		float y = uv.y * (float)t.height;
-		out = texel(S, t, (uint32_t)((unsigned long long)x % t.width), (uint32_t)((unsigned long long)y % t.height), cnt);
+		/* (size_t)x % W: exact for any finite non-negative float via fmodf (a negative x is undefined in C) */
+		const uint32_t xi = (uint32_t)fmodf(truncf(x), (float)t.width) % t.width;
+		const uint32_t yi = (uint32_t)fmodf(truncf(y), (float)t.height) % t.height;
+		out = texel(S, t, xi, yi, cnt);
 	} else {
 		out = textureGetPixelFiltered(S, t, uv.x, uv.y, cnt);
 	}
@@ -377,7 +386,7 @@ CRH_DEV rgba evalGradient(const f4 *consts, uint32_t cidx, const ShadeRec &rec) 
  * returned BY VALUE: a reference parameter would pin the caller's scene / hit record / counters in scratch. */
 struct ProgCtx { const f4 *consts; const DImage *images; const DOp *prog; TexCtx tex; };
 struct ProgResult { f4 v; uint32_t fetches; };
-struct FetchCounter { static constexpr int level = 2; uint32_t tex_fetches; };
+struct FetchCounter { static constexpr int level = 2; static constexpr bool programs = true; uint32_t tex_fetches; };
 CRH_DEV_NOINLINE ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) {
 	f4 slot[CRH_PROG_SLOTS];
 	FetchCounter cnt;
@@ -461,25 +470,31 @@ CRH_DEV_NOINLINE ProgResult runProgram(const ProgCtx S, uint32_t pc, const Shade
 	}
 }
 
-CRH_DEV ProgCtx progCtx(const DScene &S) { return ProgCtx{S.consts, S.images, S.prog, TexCtx{S.textures, S.texdata}}; }
+CRH_DEV ProgCtx progCtx(const DScene &S) { return ProgCtx{S.consts, S.images, S.prog, TexCtx{S.textures, S.texels}}; }
 template <class Cnt>
 CRH_DEV rgba evalColor(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
 	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
 	if (k == CRH_OPR_CONST) { const f4 c = S.consts[i]; return rgba{c.x, c.y, c.z, c.w}; }
-	if (k == CRH_OPR_IMAGE) return evalImage(TexCtx{S.textures, S.texdata}, S.images[i], rec.uv, cnt);
+	if (k == CRH_OPR_IMAGE) return evalImage(TexCtx{S.textures, S.texels}, S.images[i], rec.uv, cnt);
 	if (k == CRH_OPR_GRADIENT) return evalGradient(S.consts, i, rec);
-	const ProgResult r = runProgram(progCtx(S), i, rec);
-	CRH_COUNT(cnt, tex_fetches, r.fetches);
-	return rgba{r.v.x, r.v.y, r.v.z, r.v.w};
+	if constexpr (cnt_traits<Cnt>::programs) {
+		const ProgResult r = runProgram(progCtx(S), i, rec);
+		CRH_COUNT(cnt, tex_fetches, r.fetches);
+		return rgba{r.v.x, r.v.y, r.v.z, r.v.w};
+	}
+	return rgba{0.0f, 0.0f, 0.0f, 0.0f};
 }
 template <class Cnt>
 CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
 	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
 	if (k == CRH_OPR_CONST) return S.consts[i].x;
-	if (k == CRH_OPR_IMAGE_ALPHA) return evalImage(TexCtx{S.textures, S.texdata}, S.images[i], rec.uv, cnt).a;
-	const ProgResult r = runProgram(progCtx(S), i, rec);
-	CRH_COUNT(cnt, tex_fetches, r.fetches);
-	return r.v.x;
+	if (k == CRH_OPR_IMAGE_ALPHA) return evalImage(TexCtx{S.textures, S.texels}, S.images[i], rec.uv, cnt).a;
+	if constexpr (cnt_traits<Cnt>::programs) {
+		const ProgResult r = runProgram(progCtx(S), i, rec);
+		CRH_COUNT(cnt, tex_fetches, r.fetches);
+		return r.v.x;
+	}
+	return 0.0f;
 }
 
 /* ---- bsdf nodes: src/nodes/shaders ----------------------------------------------------------- */
@@ -690,15 +705,27 @@ struct TravHit {
  * tested with the old maxDist, leaf children intersected left then right before descending, nearer
  * inner child first (bvh.c:397-436). Hit attributes are derived after the walk (finishHit).
  *
+ * Shape ("while-while"): each round runs (1) node steps while the lane has an inner pair to test — popping
+ * the stack in the same loop when a subtree is exhausted —, (2) the pending leaf triangles, (3) at most one
+ * control step (enter the next instance of a TLAS leaf / leave a finished BLAS / finish). Every phase is a
+ * short uniform body, so a wave executes one kind of work at a time instead of all kinds every iteration.
+ *
  * Stack: LDS-resident (device) / local array (host emulation); entries are device node indices, plus
- * the saved TLAS state (resume node + pending instance ranges) while a lane is inside a BLAS.
+ * the saved TLAS state (resume pair, pending instance ranges, world-space ray constants) while a lane is
+ * inside a BLAS.
  */
+#define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
+/* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside
+ * a BLAS, and the path state that is dead during the walk (bounceStep) */
+enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT,
+       PK_WR, PK_WG, PK_WB, PK_FR, PK_FG, PK_FB, PK_RNG0, PK_RNG1, PK_DEPTH, CRH_PARK_SLOTS };
+
 template <class Stack, class Cnt>
-CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 wo, const v3 wd, TravHit &hit, Cnt &cnt) {
+CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD, TravHit &hit, Cnt &cnt) {
 	hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.slot = -1; hit.inst = -1;
 	CRH_COUNT1(cnt, rays, 1);
 	if (S.tlas_node_count < 1u) return;                                   /* bvh.c:362-365 */
-	RayK k = makeRayK(wo, wd);
+	RayK k = makeRayK(rayO, rayD);     /* current-level ray: the world ray in the TLAS, the object-space ray inside a BLAS */
 	uint32_t node = CRH_NONE;         /* device index of the child PAIR tested next (children are adjacent: bvh.c:393-394) */
 	uint32_t pA = 0, pAe = 0, pB = 0, pBe = 0;   /* pending leaf prim ranges [p, pe) at the current level: left leaf, right leaf */
 	uint32_t sp = 0, spBase = 0;
@@ -715,71 +742,83 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 wo, const v3 wd, Tra
 	}
 
 	for (;;) {
-		if (pA != pAe && inBlas) {
-			/* ---- triangle test: poly.c:17-53 on the prepared record ---- */
-			const uint32_t slot = pA++;
-			if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
-			const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
-			const v3 v0 = v3{q0.x, q0.y, q0.z}, e1 = v3{q0.w, q1.x, q1.y}, e2 = v3{q1.z, q1.w, q2.x}, n = v3{q2.y, q2.z, q2.w};
-			CRH_COUNT(cnt, tri_tests, 1);
-			const v3 c = vsub(v0, k.o);
-			const v3 r = vcross(k.d, c);
-			const float invDet = 1.0f / vdot(n, k.d);
-			const float u = vdot(r, e2) * invDet;
-			const float v = vdot(r, e1) * invDet;
-			if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
-				const float t = vdot(n, c) * invDet;
-				if (t >= 0.0f && t < hit.t) { hit.t = t; hit.u = u; hit.v = v; hit.slot = (int32_t)slot; instFound = true; }
-			}
-			continue;
-		}
-		if (pA == pAe && node != CRH_NONE) {
-			/* ---- node step: bvh.c:391-436 (only once the pending leaf prims of the previous step are done) ---- */
-			const uint32_t c0 = node;
-			const f4 l0 = S.nodes[2u * c0], l1 = S.nodes[2u * c0 + 1u], r0 = S.nodes[2u * c0 + 2u], r1 = S.nodes[2u * c0 + 3u];
+		/* ---- (1) node steps: bvh.c:391-436 ---- */
+		while (pA == pAe && node != CRH_NONE) {
+			const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
 			float tL, tR;
 			CRH_COUNT(cnt, node_tests, 2);
 			const bool hitL = intersectNode(l0, l1, k, hit.t, tL);
 			const bool hitR = intersectNode(r0, r1, k, hit.t, tR);
 			const bool leafL = CRH_DNODE_ISLEAF(l1), leafR = CRH_DNODE_ISLEAF(r1);
-			pA = pAe = pB = pBe = 0;
-			if (hitL && leafL) { pA = CRH_DNODE_FIRST(l1); pAe = pA + CRH_DNODE_COUNT(l1); }
+			const uint32_t fl = CRH_DNODE_FIRST(l1), fr = CRH_DNODE_FIRST(r1);
+			if (hitL && leafL) { pA = fl; pAe = fl + CRH_DNODE_COUNT(l1); }
 			if (hitR && leafR) {
-				const uint32_t f = CRH_DNODE_FIRST(r1), e = f + CRH_DNODE_COUNT(r1);
-				if (pA != pAe) { pB = f; pBe = e; } else { pA = f; pAe = e; }
+				const uint32_t e = fr + CRH_DNODE_COUNT(r1);
+				if (pA != pAe) { pB = fr; pBe = e; } else { pA = fr; pAe = e; }
 			}
 			const bool inL = hitL && !leafL, inR = hitR && !leafR;
-			const uint32_t cl = CRH_DNODE_FIRST(l1), cr = CRH_DNODE_FIRST(r1);
 			if (inL && inR) {
 				const bool swap = tL > tR;
-				node = swap ? cr : cl;
-				stk.push(sp++, swap ? cl : cr);
+				node = swap ? fr : fl;
+				stk.push(sp++, swap ? fl : fr);
 			} else if (inL || inR) {
-				node = inL ? cl : cr;
+				node = inL ? fl : fr;
+			} else if (pA == pAe && sp > spBase) {
+				node = stk.pop(--sp);             /* dead end with nothing pending: next subtree */
 			} else {
 				node = CRH_NONE;
 			}
-			continue;
 		}
+		/* ---- (2) leaf triangles: poly.c:17-53 on the prepared record ---- */
 		if (inBlas) {
-			if (sp > spBase) { node = stk.pop(--sp); continue; }
-			/* ---- BLAS exhausted: back to the TLAS (bvh.c:468-486 loop body tail) ---- */
+			while (pA != pAe) {
+				const uint32_t slot = pA++;
+				if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
+				const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
+				const v3 v0 = v3{q0.x, q0.y, q0.z}, e1 = v3{q0.w, q1.x, q1.y}, e2 = v3{q1.z, q1.w, q2.x}, n = v3{q2.y, q2.z, q2.w};
+				CRH_COUNT(cnt, tri_tests, 1);
+				const v3 c = vsub(v0, k.o);
+				const v3 r = vcross(k.d, c);
+				const float invDet = 1.0f / vdot(n, k.d);
+				const float u = vdot(r, e2) * invDet;
+				const float v = vdot(r, e1) * invDet;
+				if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
+					const float t = vdot(n, c) * invDet;
+					if (t >= 0.0f && t < hit.t) { hit.t = t; hit.u = u; hit.v = v; hit.slot = (int32_t)slot; instFound = true; }
+				}
+			}
+			if (node == CRH_NONE && sp > spBase) node = stk.pop(--sp);
+			if (node != CRH_NONE) continue;
+			/* ---- (3a) BLAS exhausted: back to the TLAS (bvh.c:468-486 loop body tail) ---- */
 			if (instFound) { hit.inst = curInst; CRH_COUNT(cnt, inst_hits, 1); }
 			inBlas = false;
+			k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
+			k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
+			k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
+			k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
+			k.oct = stk.unpark(PK_OCT);
 			pBe = stk.pop(--sp); pB = stk.pop(--sp); pAe = stk.pop(--sp); pA = stk.pop(--sp); node = stk.pop(--sp);
-			k = makeRayK(wo, wd);
+			spBase = 0;
+			if (pA == pAe) {
+				if (node == CRH_NONE && sp > 0u) node = stk.pop(--sp);
+				if (node == CRH_NONE) break;
+				continue;
+			}
+		} else if (pA == pAe) {
+			if (node == CRH_NONE && sp > 0u) node = stk.pop(--sp);
+			if (node == CRH_NONE) break;
 			continue;
 		}
-		if (pA != pAe) {
-			/* ---- TLAS leaf: next instance (bvh.c:472-484) ---- */
+		/* ---- (3b) TLAS leaf: next instance (bvh.c:472-484) ---- */
+		{
 			const uint32_t slot = pA++;
 			if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
 			const int32_t idx = S.prims[slot];       /* leaf.first is already an absolute prim slot */
 			const DInstance *inst = &S.instances[idx];
 			CRH_COUNT(cnt, inst_visits, 1);
 			/* transformRay(Ainv) + offset: instance.c:46-50 / 170-174 */
-			v3 o = xfPoint(wo, inst->Ainv);
-			const v3 d = xfVector(wd, inst->Ainv);
+			v3 o = xfPoint(k.o, inst->Ainv);
+			const v3 d = xfVector(k.d, inst->Ainv);
 			o = vadd(o, vscale(d, inst->ray_offset));
 			if (inst->kind == CRH_INSTANCE_SPHERE) {
 				/* sphere.c:20-50 */
@@ -798,31 +837,36 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 wo, const v3 wd, Tra
 						CRH_COUNT(cnt, inst_hits, 1);
 					}
 				}
-				continue;
-			}
-			if (inst->node_count < 1u) { hit.inst = -1; continue; }             /* bvh.c:362-365 via instance.c:175 */
-			/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
-			 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
-			if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) continue;
-			const RayK ko = makeRayK(o, d);
-			if (inst->node_count == 1u) {                                         /* bvh.c:382-387 */
-				const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
-				float tE;
-				CRH_COUNT(cnt, node_tests, 1);
-				if (!intersectNode(n0, n1, ko, hit.t, tE)) continue;
-				stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
-				node = CRH_NONE;
-				pA = CRH_DNODE_FIRST(n1); pAe = pA + CRH_DNODE_COUNT(n1); pB = pBe = 0;
+			} else if (inst->node_count < 1u) {
+				hit.inst = -1;                                                     /* bvh.c:362-365 via instance.c:175 */
+			} else if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) {
+				/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
+				 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
 			} else {
-				stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
-				node = inst->root;
-				pA = pAe = pB = pBe = 0;
+				const RayK ko = makeRayK(o, d);
+				bool enter = true;
+				uint32_t rootA = 0, rootAe = 0;
+				if (inst->node_count == 1u) {                                      /* bvh.c:382-387 */
+					const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
+					float tE;
+					CRH_COUNT(cnt, node_tests, 1);
+					enter = intersectNode(n0, n1, ko, hit.t, tE);
+					rootA = CRH_DNODE_FIRST(n1); rootAe = rootA + CRH_DNODE_COUNT(n1);
+				}
+				if (enter) {
+					stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
+					stk.park(PK_OX, asU32(k.o.x)); stk.park(PK_OY, asU32(k.o.y)); stk.park(PK_OZ, asU32(k.o.z));
+					stk.park(PK_DX, asU32(k.d.x)); stk.park(PK_DY, asU32(k.d.y)); stk.park(PK_DZ, asU32(k.d.z));
+					stk.park(PK_IX, asU32(k.inv.x)); stk.park(PK_IY, asU32(k.inv.y)); stk.park(PK_IZ, asU32(k.inv.z));
+					stk.park(PK_SX, asU32(k.ss.x)); stk.park(PK_SY, asU32(k.ss.y)); stk.park(PK_SZ, asU32(k.ss.z));
+					stk.park(PK_OCT, k.oct);
+					if (inst->node_count == 1u) { node = CRH_NONE; pA = rootA; pAe = rootAe; }
+					else { node = inst->root; pA = pAe = 0; }
+					pB = pBe = 0;
+					spBase = sp; inBlas = true; instFound = false; curInst = idx; k = ko;
+				}
 			}
-			spBase = sp; inBlas = true; instFound = false; curInst = idx; k = ko;
-			continue;
 		}
-		if (sp > 0u) { node = stk.pop(--sp); continue; }
-		break;
 	}
 }
 
@@ -902,7 +946,14 @@ struct PathState {
 template <class Stack, class Cnt>
 CRH_DEV bool bounceStep(const DScene &S, Stack &stk, PathState &p, int maxDepth, Cnt &cnt) {
 	TravHit hit;
+	/* weight, radiance, RNG and depth are dead during the walk: keep them in the lane's park slots, not in VGPRs */
+	stk.park(PK_WR, asU32(p.wr)); stk.park(PK_WG, asU32(p.wg)); stk.park(PK_WB, asU32(p.wb));
+	stk.park(PK_FR, asU32(p.fr)); stk.park(PK_FG, asU32(p.fg)); stk.park(PK_FB, asU32(p.fb));
+	stk.park(PK_RNG0, (uint32_t)p.rng.state); stk.park(PK_RNG1, (uint32_t)(p.rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)p.depth);
 	traverse(S, stk, p.ro, p.rd, hit, cnt);
+	p.wr = asF32(stk.unpark(PK_WR)); p.wg = asF32(stk.unpark(PK_WG)); p.wb = asF32(stk.unpark(PK_WB));
+	p.fr = asF32(stk.unpark(PK_FR)); p.fg = asF32(stk.unpark(PK_FG)); p.fb = asF32(stk.unpark(PK_FB));
+	p.rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32); p.depth = (int)stk.unpark(PK_DEPTH);
 	ShadeRec rec;
 	rec.dir = p.rd;
 	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */

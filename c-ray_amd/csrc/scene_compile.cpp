@@ -263,11 +263,43 @@ struct Compiler {
 
 		for (uint64_t t = 0; t < s->texture_count; ++t) {
 			const crh_texture &tx = s->textures[t];
-			CHECK(tx.width > 0 && tx.height > 0 && tx.channels >= 1 && tx.channels <= 4, CRH_ERR_INVALID, "texture %llu has a bad shape", (unsigned long long)t);
+			CHECK(tx.width > 0 && tx.height > 0 && (tx.channels == 1 || tx.channels == 3 || tx.channels == 4), CRH_ERR_INVALID, "texture %llu has a bad shape", (unsigned long long)t);
 			const uint64_t bytes = (uint64_t)tx.width * tx.height * tx.channels * (tx.is_float ? 4u : 1u);
 			CHECK(tx.offset % 4 == 0 && tx.offset + bytes <= s->texture_bytes, CRH_ERR_INVALID, "texture %llu data out of bounds", (unsigned long long)t);
 			CHECK(!tx.has_alpha || tx.channels == 4, CRH_ERR_INVALID, "texture %llu: has_alpha needs 4 channels", (unsigned long long)t);
+			CHECK(out.texels.size() + (uint64_t)tx.width * tx.height < 0xFFFFFFFFull, CRH_ERR_UNSUPPORTED, "more than 2^32 texels");
+			DTexture d;
+			memset(&d, 0, sizeof(d));
+			d.first = (uint32_t)out.texels.size();
+			d.width = tx.width; d.height = tx.height;
+			d.m64w = (uint32_t)((0xFFFFFFFFFFFFFFFFull % tx.width + 1) % tx.width);
+			d.m64h = (uint32_t)((0xFFFFFFFFFFFFFFFFull % tx.height + 1) % tx.height);
+			out.textures.push_back(d);
+			/* texture.c:32-63, once per texel instead of once per fetch */
+			const uint8_t *bytesp = s->texture_data + tx.offset;
+			const float *floats = (const float *)bytesp;
+			const size_t W = tx.width, H = tx.height, Cn = tx.channels;
+			out.texels.resize(out.texels.size() + W * H);
+			f4 *dst = out.texels.data() + d.first;
+			for (size_t y = 0; y < H; ++y)
+				for (size_t x = 0; x < W; ++x) {
+					const size_t base = (x + ((H - 1) - y) * W) * Cn;
+					f4 o;
+					if (Cn == 1) {
+						o.x = tx.is_float ? floats[base] : (float)bytesp[base] / 255.0f;
+						o.y = o.x; o.z = o.x; o.w = 1.0f;
+					} else if (tx.is_float) {
+						o.x = floats[base]; o.y = floats[base + 1]; o.z = floats[base + 2];
+						o.w = tx.has_alpha ? floats[base + 3] : 1.0f;
+					} else {
+						o.x = (float)bytesp[base] / 255.0f; o.y = (float)bytesp[base + 1] / 255.0f; o.z = (float)bytesp[base + 2] / 255.0f;
+						o.w = tx.has_alpha ? (float)bytesp[base + 3] / 255.0f : 1.0f;
+					}
+					dst[x + y * W] = o;
+				}
 		}
+		if (out.textures.empty()) { DTexture d; memset(&d, 0, sizeof(d)); d.width = d.height = 1; out.textures.push_back(d); }
+		if (out.texels.empty()) out.texels.push_back(f4{0, 0, 0, 0});
 
 		compileGraph();
 		CHECK(s->background < s->gnode_count && s->gnodes[s->background].kind == CRH_BSDF_BACKGROUND, CRH_ERR_INVALID, "scene.background is not a background node");
@@ -322,7 +354,7 @@ struct Compiler {
 			const int32_t ii = s->prim_indices[s->tlas_prim_base + k];
 			CHECK(ii >= 0 && (uint64_t)ii < s->instance_count, CRH_ERR_INVALID, "TLAS prim %u: instance index out of range", k);
 		}
-		out.max_stack = tlas.depth + 5 + maxBlasDepth + 1;
+		out.max_stack = tlas.depth + CRH_TLAS_SAVE + maxBlasDepth + 1;
 
 		out.instances.resize(std::max<uint64_t>(s->instance_count, 1));
 		for (uint64_t i = 0; i < s->instance_count; ++i) {

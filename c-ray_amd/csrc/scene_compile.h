@@ -13,6 +13,7 @@
  *   tris    per BLAS prim slot (leaf order) the prepared triangle v0, e1 = v0-v1, e2 = v2-v0, n = e1 x e2
  *           (poly.c:20-22, same fp32 operations, this TU is built with -ffp-contract=off): 48 B instead of
  *           4 B index + 40 B poly + 3 x 12 B scattered vertices.
+ *   textures / texels   every texture expanded to f4 texels (see DTexture).
  *   bsdfs / consts / images / prog   the node graph: bsdf nodes 1:1, colour/value/vector sub-graphs
  *           compiled to constants, image fetches or short postfix programs (pure functions of the hit).
  */
@@ -31,6 +32,8 @@ struct CompiledScene {
 	std::vector<f4> consts;
 	std::vector<DImage> images;
 	std::vector<DOp> prog;
+	std::vector<DTexture> textures;
+	std::vector<f4> texels;
 	uint32_t tlas_root = 0, tlas_node_count = 0, tlas_prim_base = 0, background = 0;
 	uint32_t max_stack = 0;     /* worst-case traversal stack entries (TLAS depth + saved TLAS state + deepest BLAS) */
 	uint32_t max_add_depth = 0;

@@ -25,6 +25,9 @@ struct ArrayStack {
 	uint32_t high = 0;
 	void push(uint32_t i, uint32_t v) { e[i] = v; if (i + 1 > high) high = i + 1; }
 	uint32_t pop(uint32_t i) { return e[i]; }
+	uint32_t pk[CRH_PARK_SLOTS];
+	void park(int i, uint32_t v) { pk[i] = v; }
+	uint32_t unpark(int i) { return pk[i]; }
 };
 DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
 	DScene d;
@@ -33,7 +36,7 @@ DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
 	d.vertices = s->vertices; d.normals = s->normals; d.texcoords = s->texcoords;
 	d.instances = c.instances.data(); d.meshes = s->meshes; d.materials = s->materials;
 	d.bsdfs = c.bsdfs.data(); d.consts = c.consts.data(); d.images = c.images.data(); d.prog = c.prog.data();
-	d.textures = s->textures; d.texdata = s->texture_data;
+	d.textures = c.textures.data(); d.texels = c.texels.data();
 	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base;
 	d.background = c.background; d.camera = c.camera;
 	return d;

@@ -120,6 +120,6 @@ EXPORTED_SYMBOLS = [
     "crh_set_option", "crh_debug_wave_stats",
     "crh_scene_upload", "crh_framebuffer_alloc", "crh_framebuffer_free", "crh_framebuffer_clear",
     "crh_framebuffer_download", "crh_framebuffer_to_srgb8", "crh_render_region", "crh_render_tiles",
-    "crh_synchronize", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
+    "crh_synchronize", "crh_frames_reduce", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
     "crh_blob_save", "crh_blob_load", "crh_blob_free",
 ]

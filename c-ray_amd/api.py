@@ -52,6 +52,7 @@ def library():
         "crh_render_region": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.c_void_p]),
         "crh_render_tiles": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.POINTER(abi.Tile), C.c_uint32, C.c_void_p]),
         "crh_synchronize": (C.c_int, [ctx]),
+        "crh_frames_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
         "crh_counters_get": (C.c_int, [ctx, C.POINTER(abi.Counters)]),
         "crh_counters_reset": (C.c_int, [ctx]),
         "crh_kernel_time_ms": (C.c_int, [ctx, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -50,7 +50,7 @@ def build(force=False, verbose=True, extra=()):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-I" + os.path.join(REPO, "include"),
                                "-I" + CSRC, "-c", src, "-o", obj])
         objs.append(obj)
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip"] + SOURCES + ["-x", "none"] + objs + ["-shared", "-o", LIB + ".tmp"]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip"] + SOURCES + ["-x", "none"] + objs + ["-shared", "-ldl", "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

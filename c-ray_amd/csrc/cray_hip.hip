@@ -16,6 +16,7 @@
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see c-ray_amd/build.py).
  */
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -560,6 +561,66 @@ int crh_render_region(crh_ctx *c, const crh_render_params *P, float *dev_fb) {
 	if (!P) return fail(CRH_ERR_INVALID, "crh_render_region: params is NULL");
 	const crh_tile t{P->x0, P->y0, P->x1, P->y1};
 	return crh_render_tiles(c, P, &t, 1, dev_fb);
+}
+
+/* ---- RCCL (loaded lazily: single-GPU users never need it) ---------------------------------------- */
+namespace {
+typedef void *ncclComm_t;
+struct Rccl {
+	void *lib = nullptr;
+	int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(int) = nullptr;
+	std::vector<int> devices;
+	std::vector<ncclComm_t> comms;
+	std::mutex mu;
+} g_rccl;
+const int kNcclFloat32 = 7, kNcclSum = 0;      /* ncclDataType_t / ncclRedOp_t values of rccl.h */
+}
+
+int crh_frames_reduce(crh_ctx **ctxs, float **fbs, int n, int width, int height) {
+	if (!ctxs || !fbs || n < 1 || width <= 0 || height <= 0) return fail(CRH_ERR_INVALID, "crh_frames_reduce: bad argument");
+	for (int i = 0; i < n; ++i) if (!ctxs[i] || !fbs[i]) return fail(CRH_ERR_INVALID, "crh_frames_reduce: NULL context or framebuffer");
+	if (n == 1) return CRH_OK;
+	std::lock_guard<std::mutex> lock(g_rccl.mu);
+	if (!g_rccl.lib) {
+		g_rccl.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!g_rccl.lib) g_rccl.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!g_rccl.lib) return fail(CRH_ERR_HIP, std::string("crh_frames_reduce: cannot load librccl: ") + dlerror());
+		g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(g_rccl.lib, "ncclCommInitAll");
+		g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
+		g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
+		g_rccl.Reduce = (decltype(g_rccl.Reduce))dlsym(g_rccl.lib, "ncclReduce");
+		g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+		if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce) {
+			g_rccl.lib = nullptr;
+			return fail(CRH_ERR_HIP, "crh_frames_reduce: librccl lacks the expected symbols");
+		}
+	}
+	std::vector<int> devs(n);
+	for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+	if (devs != g_rccl.devices) {
+		g_rccl.comms.assign(n, nullptr);
+		const int rc = g_rccl.CommInitAll(g_rccl.comms.data(), n, devs.data());
+		if (rc != 0) { g_rccl.devices.clear(); return fail(CRH_ERR_HIP, std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
+		g_rccl.devices = devs;
+	}
+	const size_t count = (size_t)width * height * 3;
+	int rc = g_rccl.GroupStart();
+	for (int i = 0; i < n && rc == 0; ++i) {
+		if (hipSetDevice(devs[i]) != hipSuccess) { rc = -1; break; }
+		rc = g_rccl.Reduce(fbs[i], fbs[i], count, kNcclFloat32, kNcclSum, 0, g_rccl.comms[i], ctxs[i]->stream);
+	}
+	const int rcEnd = g_rccl.GroupEnd();
+	if (rc == 0) rc = rcEnd;
+	if (rc != 0) return fail(CRH_ERR_HIP, std::string("ncclReduce: ") + (g_rccl.GetErrorString && rc > 0 ? g_rccl.GetErrorString(rc) : "error"));
+	for (int i = 0; i < n; ++i) {
+		HIP_TRY(hipSetDevice(devs[i]));
+		HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+	}
+	return CRH_OK;
 }
 
 int crh_synchronize(crh_ctx *c) {

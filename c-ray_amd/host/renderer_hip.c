@@ -1,0 +1,228 @@
+/*
+ * renderer_hip.c — drop-in replacement for the reference's src/renderer/renderer.c.
+ *
+ * It exports exactly the three symbols the rest of c-ray links against (src/renderer/renderer.h:101-107):
+ *     struct renderer *newRenderer(void);
+ *     struct texture  *renderFrame(struct renderer *r);     <- THE boundary (called from src/c-ray.c:280)
+ *     void             destroyRenderer(struct renderer *r);
+ * and leaves struct renderer / state / prefs / renderThreadState untouched, so src/c-ray.c, the JSON loader,
+ * tile.c, ui.c (SDL2 preview) and the PNG/BMP encoders keep working unmodified.
+ *
+ * What changes is who consumes the tile queue: instead of N pthread workers running the pixel x pass loop
+ * (renderer.c:258-327) there is ONE host thread per GPU. Each flattens nothing itself — the scene is
+ * flattened once (flatten.c) — owns a crh_ctx (libcray_hip.so), pulls batches of tiles from the reference's
+ * own nextTile() queue (tile.c:22-45) and renders a batch with one crh_render_tiles() dispatch. When the
+ * queue is empty the per-GPU float framebuffers (disjoint tiles, zero elsewhere) are summed onto GPU 0 with
+ * RCCL over xGMI (crh_frames_reduce), downloaded into state.renderBuffer, and converted to the 8-bit sRGB
+ * output with the reference's own colorToSRGB()/setPixel() on the host.
+ *
+ * Environment: CRAY_HIP_DEVICES=<n> caps the number of GPUs used; CRH_DUMP_F32=<path> dumps the float buffer.
+ * No GPU => logr(error, ...) (which exits, src/utils/logging.c:69-73): there is no CPU fallback in this file.
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdbool.h>
+
+#include "includes.h"
+#include "datatypes/image/imagefile.h"
+#include "renderer/renderer.h"
+#include "datatypes/image/texture.h"
+#include "datatypes/color.h"
+#include "datatypes/scene.h"
+#include "datatypes/tile.h"
+#include "datatypes/vertexbuffer.h"
+#include "utils/ui.h"
+#include "utils/logging.h"
+#include "utils/timer.h"
+#include "utils/platform/thread.h"
+#include "utils/platform/mutex.h"
+
+#include "cray_hip.h"
+#include "flatten.h"
+
+#define MAX_GPUS 16
+
+struct gpuWorker {
+	struct renderer *r;
+	struct renderThreadState *state;
+	const crh_scene_desc *scene;
+	crh_ctx *ctx;
+	float *fb;
+	int device;
+	int failed;
+	uint64_t rays;
+};
+
+static int tilesPerBatch(const struct renderer *r, int gpus) {
+	/* enough tiles per dispatch to fill a GPU, few enough that the queue still balances the GPUs */
+	int per = r->state.tileCount / (gpus * 4);
+	if (per < 1) per = 1;
+	if (per > 64) per = 64;
+	return per;
+}
+
+static void *gpuThread(void *arg) {
+	struct gpuWorker *w = threadUserData(arg);
+	struct renderer *r = w->r;
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	crh_render_params p;
+	memset(&p, 0, sizeof(p));
+	p.image_width = W; p.image_height = H;
+	p.first_pass = 0; p.pass_count = r->prefs.sampleCount; p.max_passes = r->prefs.sampleCount;
+	p.bounces = r->prefs.bounces;
+
+	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_scene_upload(w->ctx, w->scene) != CRH_OK ||
+		crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK) {
+		logr(warning, "GPU %d: %s\n", w->device, crh_last_error());
+		w->failed = 1;
+		w->state->threadComplete = true;
+		return NULL;
+	}
+	const int batchMax = tilesPerBatch(r, r->prefs.threadCount);
+	crh_tile *batch = calloc((size_t)batchMax, sizeof(*batch));
+	int *tileNums = calloc((size_t)batchMax, sizeof(*tileNums));
+	while (r->state.isRendering && !r->state.renderAborted) {
+		int n = 0;
+		while (n < batchMax) {
+			struct renderTile t = nextTile(r);
+			if (t.tileNum == -1) break;
+			batch[n] = (crh_tile){t.begin.x, t.begin.y, t.end.x, t.end.y};
+			tileNums[n++] = t.tileNum;
+		}
+		if (n == 0) break;
+		w->state->currentTileNum = tileNums[0];
+		w->state->completedSamples = 1;
+		if (crh_render_tiles(w->ctx, &p, batch, (uint32_t)n, w->fb) != CRH_OK || crh_synchronize(w->ctx) != CRH_OK) {
+			logr(warning, "GPU %d: %s\n", w->device, crh_last_error());
+			w->failed = 1;
+			break;
+		}
+		w->state->completedSamples = r->prefs.sampleCount;
+		for (int i = 0; i < n; ++i) {
+			struct renderTile *t = &r->state.renderTiles[tileNums[i]];
+			w->state->totalSamples += (uint64_t)t->width * t->height * (uint64_t)r->prefs.sampleCount;
+			t->isRendering = false;
+			t->renderComplete = true;
+		}
+		while (w->state->paused && !r->state.renderAborted) sleepMSec(100);
+	}
+	crh_counters c;
+	if (!w->failed && crh_counters_get(w->ctx, &c) == CRH_OK) w->rays = c.rays;
+	free(batch);
+	free(tileNums);
+	w->state->currentTileNum = -1;
+	w->state->threadComplete = true;
+	return NULL;
+}
+
+struct texture *renderFrame(struct renderer *r) {
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	struct texture *output = newTexture(char_p, r->prefs.imageWidth, r->prefs.imageHeight, 3);
+
+	int gpus = crh_device_count();
+	const char *cap = getenv("CRAY_HIP_DEVICES");
+	if (cap && atoi(cap) > 0 && atoi(cap) < gpus) gpus = atoi(cap);
+	if (gpus > MAX_GPUS) gpus = MAX_GPUS;
+	if (gpus < 1) logr(error, "c-ray-hip: no HIP device visible (this renderer has no CPU path)\n");
+
+	logr(info, "Starting C-ray MI355X renderer for frame %i\n", r->prefs.imgCount);
+	logr(info, "Rendering at %i x %i, %i samples, %i bounces on %i GPU%s.\n", W, H, r->prefs.sampleCount, r->prefs.bounces, gpus, PLURAL(gpus));
+
+	crh_scene_desc scene;
+	const int frc = crh_flatten_world(r, &scene);
+	if (frc != CRH_OK) logr(error, "c-ray-hip: the scene cannot be flattened for the GPU (%i)\n", frc);
+
+	r->state.isRendering = true;
+	r->state.renderAborted = false;
+	r->state.saveImage = true;
+	r->prefs.threadCount = gpus;              /* ui.c indexes threadStates[0..threadCount) */
+	r->state.threads = calloc((size_t)gpus, sizeof(*r->state.threads));
+	r->state.threadStates = calloc((size_t)gpus, sizeof(*r->state.threadStates));
+	struct gpuWorker workers[MAX_GPUS];
+	memset(workers, 0, sizeof(workers));
+	for (int g = 0; g < gpus; ++g) {
+		r->state.threadStates[g] = (struct renderThreadState){.thread_num = g, .renderer = r, .output = output, .currentTileNum = -1};
+		workers[g] = (struct gpuWorker){.r = r, .state = &r->state.threadStates[g], .scene = &scene, .device = g};
+		r->state.threads[g] = (struct crThread){.threadFunc = gpuThread, .userData = &workers[g]};
+		if (threadStart(&r->state.threads[g])) logr(error, "Failed to create the dispatch thread of GPU %i.\n", g);
+		r->state.activeThreads++;
+	}
+
+	/* main thread: keep the preview window / key handling alive while the GPUs work (ui.c contract) */
+	for (;;) {
+		int done = 0;
+		for (int g = 0; g < gpus; ++g) done += r->state.threadStates[g].threadComplete ? 1 : 0;
+		if (done == gpus) break;
+		getKeyboardInput(r);
+		drawWindow(r, output);
+		sleepMSec(r->state.renderAborted ? 1 : 4);
+	}
+	for (int g = 0; g < gpus; ++g) threadWait(&r->state.threads[g]);
+	r->state.activeThreads = 0;
+	r->state.isRendering = false;
+
+	int failed = 0;
+	uint64_t rays = 0;
+	for (int g = 0; g < gpus; ++g) { failed += workers[g].failed; rays += workers[g].rays; }
+	if (failed) logr(error, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), crh_last_error());
+
+	/* assemble the frame on GPU 0 (RCCL reduce over xGMI; tiles are disjoint so the sum is a gather) */
+	if (gpus > 1) {
+		crh_ctx *ctxs[MAX_GPUS];
+		float *fbs[MAX_GPUS];
+		for (int g = 0; g < gpus; ++g) { ctxs[g] = workers[g].ctx; fbs[g] = workers[g].fb; }
+		if (crh_frames_reduce(ctxs, fbs, gpus, W, H) != CRH_OK) logr(error, "c-ray-hip: framebuffer reduce failed: %s\n", crh_last_error());
+	}
+	struct texture *buf = r->state.renderBuffer;
+	if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
+		logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
+
+	/* 8-bit output exactly like renderer.c:294-300: colorToSRGB + setPixel truncation, on the host */
+	for (int y = 0; y < H; ++y)
+		for (int x = 0; x < W; ++x)
+			setPixel(output, colorToSRGB(textureGetPixel(buf, x, y, false)), x, y);
+
+	const char *dump = getenv("CRH_DUMP_F32");
+	if (dump) {
+		FILE *f = fopen(dump, "wb");
+		if (f) { fwrite(buf->data.float_p, sizeof(float), (size_t)W * H * 3, f); fclose(f); }
+	}
+	logr(info, "%llu rays traced on %i GPU%s.\n", (unsigned long long)rays, gpus, PLURAL(gpus));
+
+	for (int g = 0; g < gpus; ++g) {
+		crh_framebuffer_free(workers[g].ctx, workers[g].fb);
+		crh_context_destroy(workers[g].ctx);
+	}
+	crh_flatten_free(&scene);
+	return output;
+}
+
+struct renderer *newRenderer(void) {
+	struct renderer *r = calloc(1, sizeof(*r));
+	/* the estimators in ui.c / renderer statistics divide by these, so they start at 1 (renderer.c:331-333) */
+	r->state.timeSampleCount = 1;
+	r->state.finishedPasses = 1;
+	r->state.avgTileTime = 1;
+	r->state.tileMutex = createMutex();
+	r->state.timer = calloc(1, sizeof(*r->state.timer));
+	if (!g_vertices) allocVertexBuffers();
+	return r;
+}
+
+void destroyRenderer(struct renderer *r) {
+	if (!r) return;
+	destroyScene(r->scene);
+	destroyTexture(r->state.uiBuffer);
+	destroyTexture(r->state.renderBuffer);
+	destroyVertexBuffers();
+	free(r->state.threadStates);
+	free(r->state.threads);
+	free(r->state.renderTiles);
+	free(r->state.tileMutex);
+	free(r->state.timer);
+	free(r->prefs.assetPath);
+	free(r->prefs.imgFilePath);
+	free(r->prefs.imgFileName);
+	free(r);
+}

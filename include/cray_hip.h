@@ -285,6 +285,12 @@ int crh_render_region(crh_ctx *ctx, const crh_render_params *params, float *dev_
  * one launch per tile. Tiles must not overlap. */
 typedef struct crh_tile { int32_t x0, y0, x1, y1; } crh_tile;
 int crh_render_tiles(crh_ctx *ctx, const crh_render_params *params, const crh_tile *tiles, uint32_t tile_count, float *dev_fb);
+/* Multi-GPU inside one process (the C host, c-ray_amd/host/renderer_hip.c: one crh_ctx + one dispatch thread per
+ * GPU): sum the n per-GPU float framebuffers onto ctxs[0]'s with ONE RCCL reduce over xGMI (ncclReduce, float,
+ * sum, root 0; communicators from ncclCommInitAll). Tiles are disjoint and non-owned pixels are 0, so the sum is
+ * a gather. Replaces the TCP submitWork of 8-bit tiles (src/utils/protocol/worker.c:128-136, server.c:159-174).
+ * librccl is loaded on first use; n == 1 is a no-op. (Python hosts use torch.distributed instead: render.py.) */
+int crh_frames_reduce(crh_ctx **ctxs, float **dev_fbs, int n, int width, int height);
 /* Block until everything queued on the context's stream has finished. */
 int crh_synchronize(crh_ctx *ctx);
 

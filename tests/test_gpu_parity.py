@@ -170,3 +170,37 @@ def test_full_size_properties_cfg2(pkg, ctx, oracle):
     assert st["rmse"] <= 2e-3 and st["frac_gt_1e-3"] <= 5e-3, st
     assert abs(cnt["rays"] - ocnt["rays"]) <= 0.002 * ocnt["rays"]
     assert np.isfinite(img).all()
+
+
+def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest, golden_blob, golden_ref, tmp_path):
+    """c-ray-hip = the reference's own main.c / loader / encoders with renderer.c replaced by renderer_hip.c.
+    Its float buffer must equal the library path bit for bit (same kernels) and the reference within tolerance;
+    the BMP it writes goes through the reference's untouched encoder."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "c-ray_amd", "_lib", "c-ray-hip")
+    overlay = os.path.join(repo, "oracle", "_ref", "input")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(overlay, "scene.json"))):
+        pytest.skip("c-ray-hip or the asset overlay is not built (needs /root/reference at build time)")
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import refrun
+    m = manifest["cfg1_scene"]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    scene = refrun.rewrite_scene("scene.json", w, h, s, b, out_dir=str(tmp_path))
+    dump = str(tmp_path / "hip.f32")
+    env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES="1")
+    proc = subprocess.run([exe], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-2000:]
+    img = np.fromfile(dump, dtype=np.float32).reshape(h, w, 3)
+    lib_img, _, _ = gpu_render(pkg, ctx, golden_blob("cfg1_scene"), w, h, s, b)
+    assert np.array_equal(img, lib_img)
+    st = image_stats(img, golden_ref("cfg1_scene"))
+    assert st["rmse"] <= 5e-3 and st["frac_gt_1e-3"] <= 5e-3, st
+    bmp = [f for f in os.listdir(tmp_path) if f.endswith(".bmp")]
+    assert bmp, "the reference's encoder wrote no image"
+    data = open(tmp_path / bmp[0], "rb").read()
+    assert data[:2] == b"BM" and len(data) >= w * h * 3

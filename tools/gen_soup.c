@@ -41,7 +41,9 @@ int main(int argc, char **argv) {
 				c[0] + e1[0], c[1] + e1[1], c[2] + e1[2], c[0] + e2[0], c[1] + e2[1], c[2] + e2[2]);
 	}
 	fprintf(f, "usemtl grey\n");
-	for (long i = 0; i < n; ++i) fprintf(f, "f %ld %ld %ld\n", 3 * i + 1, 3 * i + 2, 3 * i + 3);
+	/* "v//": the reference tokenises every face vertex on / and reads three fields (wavefront.c:97-103), so a
+	 * bare "f 1 2 3" would dereference NULL there; empty fields parse as 0 = "unused" */
+	for (long i = 0; i < n; ++i) fprintf(f, "f %ld// %ld// %ld//\n", 3 * i + 1, 3 * i + 2, 3 * i + 3);
 	fclose(f);
 	return 0;
 }

@@ -117,7 +117,7 @@ HIT_DTYPE = [("inst", "<i4"), ("poly", "<i4"), ("distance", "<f4"), ("uv", "<f4"
 # every symbol include/cray_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "crh_device_count", "crh_last_error", "crh_abi_version", "crh_context_create", "crh_context_destroy",
-    "crh_set_option", "crh_debug_wave_stats",
+    "crh_set_option", "crh_debug_wave_stats", "crh_debug_phase_ticks",
     "crh_scene_upload", "crh_framebuffer_alloc", "crh_framebuffer_free", "crh_framebuffer_clear",
     "crh_framebuffer_download", "crh_framebuffer_to_srgb8", "crh_render_region", "crh_render_tiles",
     "crh_synchronize", "crh_frames_reduce", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",

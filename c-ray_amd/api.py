@@ -43,6 +43,7 @@ def library():
         "crh_context_destroy": (C.c_int, [ctx]),
         "crh_set_option": (C.c_int, [ctx, C.c_int, C.c_int64]),
         "crh_debug_wave_stats": (C.c_int, [ctx, C.c_void_p, C.c_uint32]),
+        "crh_debug_phase_ticks": (C.c_int, [ctx, C.c_void_p]),
         "crh_scene_upload": (C.c_int, [ctx, C.POINTER(abi.SceneDesc)]),
         "crh_framebuffer_alloc": (C.c_int, [ctx, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
         "crh_framebuffer_free": (C.c_int, [ctx, C.c_void_p]),
@@ -138,6 +139,12 @@ class Context:
         if n < 0:
             _check(n, "crh_debug_wave_stats")
         return buf[:n]
+
+    def phase_ticks(self):
+        buf = np.zeros(7, dtype=np.uint64)
+        _check(self.L.crh_debug_phase_ticks(self.h, buf.ctypes.data), "crh_debug_phase_ticks")
+        return {"setup": int(buf[0]), "traverse": int(buf[1]), "shade": int(buf[2]), "w_node": int(buf[3]), "w_tri": int(buf[4]),
+                "w_ctrl": int(buf[5]), "w_round": int(buf[6])}
 
     def upload(self, scene):
         desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)

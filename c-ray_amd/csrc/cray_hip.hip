@@ -9,7 +9,7 @@
  *                        refilled instead of idling, and all lanes of a wave stay on the same few pixels
  *                        (coherent BVH walks). Samples are staged per wave and folded into the running mean
  *                        in pass order (renderer.c:288-291). Traversal stack in LDS (entry-major,
- *                        conflict-free); deep stacks spill to a per-lane global slab.
+ *                        conflict-free); deeper entries in a private array.
  *   k_trace_rays         getClosestIsect for caller rays (diagnostic / parity entry).
  *   k_to_srgb8           colorToSRGB + setPixel truncation.
  * No CPU fallback: every entry point fails with CRH_ERR_NO_DEVICE when there is no GPU.
@@ -33,7 +33,7 @@ using namespace crh;
 
 /* ---- tunables ---------------------------------------------------------------------------------- */
 #define CRH_BLOCK 256            /* 4 waves of 64 */
-#define CRH_STACK_LDS 30         /* traversal stack entries kept in LDS per lane; with the 22 park slots: 52 KB per block, 3 blocks per CU */
+#define CRH_STACK_LDS 24         /* traversal stack entries kept in LDS per lane; with the 16 park slots: 40 KB per block, 4 blocks per CU */
 
 /* ---- error plumbing ---------------------------------------------------------------------------- */
 static thread_local std::string t_err;
@@ -45,25 +45,28 @@ static int fail(int code, const std::string &msg) { t_err = msg; return code; }
 	} while (0)
 
 /* ---- device-side helpers ------------------------------------------------------------------------ */
-/* Deep-stack overflow (entries beyond CRH_STACK_LDS) lives in a per-lane global slab. Kept out of line so that
- * the LDS and the global pointer are never merged into one generic pointer (that would turn every stack
- * access into a flat_load / flat_store). */
-__device__ __noinline__ void spillStore(uint32_t *p, uint32_t v) { *p = v; }
-__device__ __noinline__ uint32_t spillLoad(const uint32_t *p) { return *p; }
+/* Per-lane traversal stack: the first CRH_STACK_LDS entries live in LDS (entry-major: entry i of lane l at
+ * word i * 256 + l, bank = l mod 32, conflict-free), deeper entries in a private (scratch) array. The two are
+ * addressed through their own address spaces — never through one generic pointer, which would turn every stack
+ * access into a flat_load / flat_store. LDS + overflow cover the worst case the scene compiler can report
+ * (64 + 5 + 64 + 1, bvh.c:32). The park slots (pt_device.h: PK_*) are LDS too. */
+#define CRH_STACK_OVF 110
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsStack {
-	uint32_t *lds;       /* &s_stack[threadIdx.x]; entry i at lds[i * CRH_BLOCK]: bank = lane % 32, conflict-free */
-	uint32_t *spill;     /* &spill[global thread]; entry j at spill[j * stride] (coalesced across lanes) */
-	uint32_t stride;
-	uint32_t *parkp;     /* &s_park[threadIdx.x]; slot i at parkp[i * CRH_BLOCK] */
+	lds_u32 *lds;        /* &s_stack[threadIdx.x] */
+	lds_u32 *parkp;      /* &s_park[threadIdx.x]  */
+	uint32_t ovf[CRH_STACK_OVF];
 	__device__ __forceinline__ void park(int i, uint32_t v) { parkp[i * CRH_BLOCK] = v; }
 	__device__ __forceinline__ uint32_t unpark(int i) { return parkp[i * CRH_BLOCK]; }
 	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
 		if (__builtin_expect(i < CRH_STACK_LDS, 1)) lds[i * CRH_BLOCK] = v;
-		else spillStore(spill + (size_t)(i - CRH_STACK_LDS) * stride, v);
+		else ovf[i - CRH_STACK_LDS] = v;
 	}
 	__device__ __forceinline__ uint32_t pop(uint32_t i) {
-		if (__builtin_expect(i < CRH_STACK_LDS, 1)) return lds[i * CRH_BLOCK];
-		return spillLoad(spill + (size_t)(i - CRH_STACK_LDS) * stride);
+		uint32_t v;
+		if (__builtin_expect(i < CRH_STACK_LDS, 1)) v = lds[i * CRH_BLOCK];
+		else v = ovf[i - CRH_STACK_LDS];
+		return v;
 	}
 };
 
@@ -110,10 +113,8 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 	const unsigned long long tStart = wall_clock64();
 	uint32_t unitsDone = 0;
 	LdsStack stk;
-	stk.lds = &s_stack[threadIdx.x];
-	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
-	stk.stride = spillStride;
-	stk.parkp = &s_park[threadIdx.x];
+	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
+	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
 	CountersT<LEVEL, PROG> cnt;
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;
@@ -162,6 +163,15 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 		v = waveSum(cnt.inst_hits); if (lead && v) atomicAdd(&counters[5], (unsigned long long)v);
 		v = waveSum(cnt.sphere_tests); if (lead && v) atomicAdd(&counters[6], (unsigned long long)v);
 		v = waveSum(cnt.tex_fetches); if (lead && v) atomicAdd(&counters[7], (unsigned long long)v);
+		if (lead) {   /* debug phase clocks: one sample per wave (lane 0) */
+			atomicAdd(&counters[8], (unsigned long long)cnt.t_setup);
+			atomicAdd(&counters[9], (unsigned long long)cnt.t_trav);
+			atomicAdd(&counters[10], (unsigned long long)cnt.t_shade);
+		}
+		v = waveSum(cnt.w_node); if (lead && v) atomicAdd(&counters[11], (unsigned long long)v);
+		v = waveSum(cnt.w_tri); if (lead && v) atomicAdd(&counters[12], (unsigned long long)v);
+		v = waveSum(cnt.w_ctrl); if (lead && v) atomicAdd(&counters[13], (unsigned long long)v);
+		v = waveSum(cnt.w_round); if (lead && v) atomicAdd(&counters[14], (unsigned long long)v);
 	}
 }
 
@@ -170,10 +180,8 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
 	LdsStack stk;
-	stk.lds = &s_stack[threadIdx.x];
-	stk.spill = spill + (size_t)blockIdx.x * CRH_BLOCK + threadIdx.x;
-	stk.stride = spillStride;
-	stk.parkp = &s_park[threadIdx.x];
+	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
+	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
 	for (uint64_t i = (uint64_t)blockIdx.x * CRH_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CRH_BLOCK) {
 		Counters cnt;
 		memset(&cnt, 0, sizeof(cnt));
@@ -306,8 +314,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 		if (stream) c->stream = (hipStream_t)stream;
 		else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->ownStream = (e == hipSuccess); }
 	}
-	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, 8 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, 16 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
 	if (e != hipSuccess) {
 		const std::string msg = std::string("crh_context_create: ") + hipGetErrorString(e);
@@ -649,7 +657,7 @@ int crh_counters_reset(crh_ctx *c) {
 	if (!c) return fail(CRH_ERR_INVALID, "crh_counters_reset: ctx is NULL");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
-	HIP_TRY(hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long)));
 	c->lastMs = 0.0f; c->totalMs = 0.0; c->launches = 0;
 	return CRH_OK;
 }
@@ -663,6 +671,17 @@ int crh_kernel_time_ms(crh_ctx *c, float *last_ms, double *total_ms, uint64_t *l
 	if (last_ms) *last_ms = c->lastMs;
 	if (total_ms) *total_ms = c->totalMs;
 	if (launches) *launches = c->launches;
+	return CRH_OK;
+}
+
+/* debug: wall-clock ticks (100 MHz), summed over waves, spent in {item setup, BVH walk, shading} by the counting kernel */
+int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* 7 values: ticks {setup, walk, shade}, wave iterations {node, tri, ctrl, round} */) {
+	if (!c || !out3) return fail(CRH_ERR_INVALID, "crh_debug_phase_ticks: NULL argument");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	unsigned long long h[7];
+	HIP_TRY(hipMemcpy(h, c->dCounters + 8, sizeof(h), hipMemcpyDeviceToHost));
+	for (int i = 0; i < 7; ++i) out3[i] = h[i];
 	return CRH_OK;
 }
 

@@ -120,6 +120,8 @@ template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	static constexpr int level = 2;
 	static constexpr bool programs = PROGRAMS;
 	uint32_t rays, node_tests, tri_tests, inst_visits, inst_hits, sphere_tests, tex_fetches, paths;
+	uint32_t t_setup, t_trav, t_shade;   /* debug: wall-clock ticks (100 MHz) this wave spent per phase */
+	uint32_t w_node, w_tri, w_ctrl, w_round;   /* debug: WAVE-level iteration counts of the walk's phases (first active lane counts) */
 };
 template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
 	static constexpr int level = 1;
@@ -133,6 +135,16 @@ template <class T> struct cnt_traits { static constexpr int level = T::level; st
 template <class T> struct cnt_traits<T &> { static constexpr int level = T::level; static constexpr bool programs = T::programs; };
 /* CRH_COUNT: detailed counters (level 2); CRH_COUNT1: rays / paths (level >= 1) */
 #define CRH_COUNT(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 2) (c).field += (n); } while (0)
+#if defined(__HIPCC__)
+#define CRH_TICK() ((uint32_t)wall_clock64())
+#else
+#define CRH_TICK() 0u
+#endif
+#if defined(__HIPCC__)
+#define CRH_WAVE_ITER(c, field) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 2) { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) (c).field += 1; } } while (0)
+#else
+#define CRH_WAVE_ITER(c, field) do { } while (0)
+#endif
 #define CRH_COUNT1(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 1) (c).field += (n); } while (0)
 
 /* ---- vector.h / color.h ---------------------------------------------------------------------- */
@@ -639,37 +651,55 @@ CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
 }
 
 /* ---- intersection ------------------------------------------------------------------------------ */
-struct RayK { v3 o, d, inv, ss; uint32_t oct; };   /* oct bits 0..2: signbit of d (bvh.c:368-372); bits 4..6: d component == 0 */
+/* oct bits 0..2: signbit of d (bvh.c:368-372); bits 4..6: that slab is tested exactly (|1/d| > 1e30, incl. d == 0);
+ * bit 7: some component of the ray is not finite (reference NaN semantics are then followed literally). */
+struct RayK { v3 o, d, inv, ss; uint32_t oct; };
+#define CRH_RAY_SLOW 0xF0u
+CRH_DEV bool finitef(float x) { return fabsf(x) <= FLT_MAX; }
 CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
 	RayK k;
 	k.o = o; k.d = d;
-	k.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u)
-		  | (d.x == 0.0f ? 16u : 0u) | (d.y == 0.0f ? 32u : 0u) | (d.z == 0.0f ? 64u : 0u);
 	k.inv = v3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 	k.ss = vscale(vmul(o, k.inv), -1.0f);
+	const bool fin = finitef(o.x) && finitef(o.y) && finitef(o.z) && finitef(d.x) && finitef(d.y) && finitef(d.z);
+	k.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u)
+		  | (fabsf(k.inv.x) > 1e30f ? 16u : 0u) | (fabsf(k.inv.y) > 1e30f ? 32u : 0u) | (fabsf(k.inv.z) > 1e30f ? 64u : 0u)
+		  | (fin ? 0u : 128u);
 	return k;
 }
 /* bvh.c:326-352; n0 = {minx,maxx,miny,maxy}, n1 = {minz,maxz,first,countLeaf}.
  *
- * One deliberate difference, for rays with an exactly zero direction component (about one camera ray per
- * 10^5 on a row that crosses the horizon): there invDir = inf and the reference's fma(bound, inf, -start*inf)
- * is inf - inf = NaN whenever bound and start have the same sign; its NaN-ordered min/max then drops that
- * slab AND the x slab, so the walk degenerates to a z-only test and visits every node and triangle of the
- * scene (measured: 451 585 node + 524 290 triangle tests for one ray of input/hdr.json; ~10 ms on a CPU
- * core, but a third of a second for one GPU lane with the other 63 waiting). Box tests only cull: the
- * closest hit is decided by the triangle / sphere tests, which never use invDir. So for a zero component we
- * test the slab exactly (inside iff min <= start <= max): the same hit comes out (up to exact-tie order),
- * after a normal number of node visits. Documented in DESIGN.md ("degenerate rays"); tests/test_degenerate.py.
+ * Fast path (every ordinary ray): with finite inputs and |invDir| <= 1e30 no product overflows, no NaN can arise,
+ * and the reference's compare-select chain IS max / min (the octant-selected bound is the smaller / larger of the
+ * two slab parameters because invDir carries the sign the octant was taken from), so v_min / v_max / v_max3 /
+ * v_min3 give the same boolean and the same tEntry (up to the sign of zero, which no comparison sees).
+ *
+ * Slow path, two deliberate, result-preserving differences ("degenerate rays"):
+ *  - a direction component that is zero (or so small that 1/d > 1e30): the reference computes
+ *    fma(bound, inf, -start*inf) = inf - inf = NaN whenever bound and start have the same sign, and its
+ *    NaN-ordered selects then drop that slab AND the x slab, so the walk visits every node and triangle of the
+ *    scene (measured: 451 585 node + 524 290 triangle tests for one camera ray of input/hdr.json, about one ray
+ *    per frame on the image row that crosses the horizon; ~10 ms on a CPU core, a third of a second for one GPU
+ *    lane with the chip waiting). Box tests only cull — the closest hit is decided by the triangle / sphere tests,
+ *    which never use invDir — so such a slab is tested exactly (inside iff min <= start <= max): same hit (up to
+ *    exact-tie order), after a normal number of node visits. tests: test_zero_component_rays.
+ *  - non-finite rays follow the reference's select chain literally.
  */
 CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDist, float &tEntry) {
+	const float xa = __builtin_fmaf(n0.x, k.inv.x, k.ss.x), xb = __builtin_fmaf(n0.y, k.inv.x, k.ss.x);
+	const float ya = __builtin_fmaf(n0.z, k.inv.y, k.ss.y), yb = __builtin_fmaf(n0.w, k.inv.y, k.ss.y);
+	const float za = __builtin_fmaf(n1.x, k.inv.z, k.ss.z), zb = __builtin_fmaf(n1.y, k.inv.z, k.ss.z);
+	if (!(k.oct & CRH_RAY_SLOW)) {
+		const float tMin = fmaxf(fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fminf(za, zb)), 0.0f);
+		const float tMax = fminf(fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fmaxf(za, zb)), maxDist);
+		tEntry = tMin;
+		return tMin <= tMax;
+	}
 	const bool ox = k.oct & 1u, oy = k.oct & 2u, oz = k.oct & 4u;
-	float tMinX = __builtin_fmaf(ox ? n0.y : n0.x, k.inv.x, k.ss.x);
-	float tMaxX = __builtin_fmaf(ox ? n0.x : n0.y, k.inv.x, k.ss.x);
-	float tMinY = __builtin_fmaf(oy ? n0.w : n0.z, k.inv.y, k.ss.y);
-	float tMaxY = __builtin_fmaf(oy ? n0.z : n0.w, k.inv.y, k.ss.y);
-	float tMinZ = __builtin_fmaf(oz ? n1.y : n1.x, k.inv.z, k.ss.z);
-	float tMaxZ = __builtin_fmaf(oz ? n1.x : n1.y, k.inv.z, k.ss.z);
-	if (k.oct & 0x70u) {
+	float tMinX = ox ? xb : xa, tMaxX = ox ? xa : xb;
+	float tMinY = oy ? yb : ya, tMaxY = oy ? ya : yb;
+	float tMinZ = oz ? zb : za, tMaxZ = oz ? za : zb;
+	if (!(k.oct & 128u)) {
 		const float inf = __builtin_inff();
 		if (k.oct & 16u) { const bool in = (n0.x <= k.o.x) && (k.o.x <= n0.y); tMinX = in ? -inf : inf; tMaxX = in ? inf : -inf; }
 		if (k.oct & 32u) { const bool in = (n0.z <= k.o.y) && (k.o.y <= n0.w); tMinY = in ? -inf : inf; tMaxY = in ? inf : -inf; }
@@ -717,7 +747,7 @@ struct TravHit {
 #define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
 /* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside
  * a BLAS, and the path state that is dead during the walk (bounceStep) */
-enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT,
+enum { PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT,
        PK_WR, PK_WG, PK_WB, PK_FR, PK_FG, PK_FB, PK_RNG0, PK_RNG1, PK_DEPTH, CRH_PARK_SLOTS };
 
 template <class Stack, class Cnt>
@@ -742,8 +772,10 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 	}
 
 	for (;;) {
+		CRH_WAVE_ITER(cnt, w_round);
 		/* ---- (1) node steps: bvh.c:391-436 ---- */
 		while (pA == pAe && node != CRH_NONE) {
+			CRH_WAVE_ITER(cnt, w_node);
 			const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
 			float tL, tR;
 			CRH_COUNT(cnt, node_tests, 2);
@@ -772,6 +804,7 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 		/* ---- (2) leaf triangles: poly.c:17-53 on the prepared record ---- */
 		if (inBlas) {
 			while (pA != pAe) {
+				CRH_WAVE_ITER(cnt, w_tri);
 				const uint32_t slot = pA++;
 				if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
 				const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
@@ -792,8 +825,7 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 			/* ---- (3a) BLAS exhausted: back to the TLAS (bvh.c:468-486 loop body tail) ---- */
 			if (instFound) { hit.inst = curInst; CRH_COUNT(cnt, inst_hits, 1); }
 			inBlas = false;
-			k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
-			k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
+			k.o = rayO; k.d = rayD;      /* the world ray stays in registers (the caller needs it after the walk anyway) */
 			k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
 			k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
 			k.oct = stk.unpark(PK_OCT);
@@ -811,6 +843,7 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 		}
 		/* ---- (3b) TLAS leaf: next instance (bvh.c:472-484) ---- */
 		{
+			CRH_WAVE_ITER(cnt, w_ctrl);
 			const uint32_t slot = pA++;
 			if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
 			const int32_t idx = S.prims[slot];       /* leaf.first is already an absolute prim slot */
@@ -855,8 +888,6 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 				}
 				if (enter) {
 					stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
-					stk.park(PK_OX, asU32(k.o.x)); stk.park(PK_OY, asU32(k.o.y)); stk.park(PK_OZ, asU32(k.o.z));
-					stk.park(PK_DX, asU32(k.d.x)); stk.park(PK_DY, asU32(k.d.y)); stk.park(PK_DZ, asU32(k.d.z));
 					stk.park(PK_IX, asU32(k.inv.x)); stk.park(PK_IY, asU32(k.inv.y)); stk.park(PK_IZ, asU32(k.inv.z));
 					stk.park(PK_SX, asU32(k.ss.x)); stk.park(PK_SY, asU32(k.ss.y)); stk.park(PK_SZ, asU32(k.ss.z));
 					stk.park(PK_OCT, k.oct);
@@ -950,7 +981,10 @@ CRH_DEV bool bounceStep(const DScene &S, Stack &stk, PathState &p, int maxDepth,
 	stk.park(PK_WR, asU32(p.wr)); stk.park(PK_WG, asU32(p.wg)); stk.park(PK_WB, asU32(p.wb));
 	stk.park(PK_FR, asU32(p.fr)); stk.park(PK_FG, asU32(p.fg)); stk.park(PK_FB, asU32(p.fb));
 	stk.park(PK_RNG0, (uint32_t)p.rng.state); stk.park(PK_RNG1, (uint32_t)(p.rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)p.depth);
+	uint32_t tk0 = 0;
+	if constexpr (cnt_traits<Cnt>::level >= 2) tk0 = CRH_TICK();
 	traverse(S, stk, p.ro, p.rd, hit, cnt);
+	if constexpr (cnt_traits<Cnt>::level >= 2) { const uint32_t tk1 = CRH_TICK(); cnt.t_trav += tk1 - tk0; }
 	p.wr = asF32(stk.unpark(PK_WR)); p.wg = asF32(stk.unpark(PK_WG)); p.wb = asF32(stk.unpark(PK_WB));
 	p.fr = asF32(stk.unpark(PK_FR)); p.fg = asF32(stk.unpark(PK_FG)); p.fb = asF32(stk.unpark(PK_FB));
 	p.rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32); p.depth = (int)stk.unpark(PK_DEPTH);
@@ -1020,6 +1054,8 @@ CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk
 	p.ro = p.rd = v3{0.0f, 0.0f, 0.0f};
 	p.wr = p.wg = p.wb = p.fr = p.fg = p.fb = 0.0f;
 	for (;;) {
+		uint32_t tks = 0;
+		if constexpr (cnt_traits<Cnt>::level >= 2) tks = CRH_TICK();
 		if (!havePath) {
 			int x = 0, y = 0, pass = 0;
 			bool found = false;
@@ -1044,7 +1080,12 @@ CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk
 			CRH_COUNT1(cnt, paths, 1);
 			havePath = true;
 		}
+		if constexpr (cnt_traits<Cnt>::level >= 2) cnt.t_setup += CRH_TICK() - tks;
+		uint32_t tkb = 0;
+		if constexpr (cnt_traits<Cnt>::level >= 2) tkb = CRH_TICK();
+		const uint32_t travBefore = [&]() { if constexpr (cnt_traits<Cnt>::level >= 2) return cnt.t_trav; else return 0u; }();
 		const bool done = (P.bounces <= 0) ? true : bounceStep(S, stk, p, P.bounces, cnt);
+		if constexpr (cnt_traits<Cnt>::level >= 2) cnt.t_shade += (CRH_TICK() - tkb) - (cnt.t_trav - travBefore);
 		if (done) {
 			float *o = stage + (size_t)cur * 3;
 			o[0] = p.fr; o[1] = p.fg; o[2] = p.fb;

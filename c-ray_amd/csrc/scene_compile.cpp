@@ -72,6 +72,7 @@ struct Compiler {
 				depth[n.first] = std::max(depth[n.first], d);
 				depth[n.first + 1] = std::max(depth[n.first + 1], d);
 				info.depth = std::max(info.depth, d);
+				CHECK(d <= 64, CRH_ERR_UNSUPPORTED, "%s deeper than MAX_BVH_DEPTH 64 (bvh.c:32)", what);
 			}
 			f4 a{n.bounds[0], n.bounds[1], n.bounds[2], n.bounds[3]};
 			f4 b{n.bounds[4], n.bounds[5], asF32(first), asF32((count & 0x3FFFFFFFu) | (leaf ? 0x40000000u : 0u))};

@@ -263,6 +263,7 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);
+int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out3);
 
 /* Replaces "the CPU reads struct world directly": copies the flattened scene to HBM, derives the
  * device-side acceleration layout (leaf-ordered prepared triangles) and validates the node graph. */

@@ -13,7 +13,7 @@ w, h, b = 1280, 720, 8
 fb = ctx.framebuffer(w, h)
 ctx.set_option(abi.OPT_WAVE_STATS, 1)
 ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
-for wps, bpcs in ((1, (1, 2)), (4, (2, 3, 4))):
+for wps, bpcs in ((4, (3, 4)),):
     ctx.set_option(abi.OPT_WAVES_PER_SIMD, wps)
     for bpc in bpcs:
         ctx.set_option(abi.OPT_BLOCKS_PER_CU, bpc)

@@ -141,10 +141,13 @@ class Context:
         return buf[:n]
 
     def phase_ticks(self):
-        buf = np.zeros(7, dtype=np.uint64)
+        buf = np.zeros(11, dtype=np.uint64)
         _check(self.L.crh_debug_phase_ticks(self.h, buf.ctypes.data), "crh_debug_phase_ticks")
-        return {"setup": int(buf[0]), "traverse": int(buf[1]), "shade": int(buf[2]), "w_node": int(buf[3]), "w_tri": int(buf[4]),
-                "w_ctrl": int(buf[5]), "w_round": int(buf[6])}
+        keys = ("setup", "traverse", "shade", "w_node", "w_tri", "w_ctrl", "w_round", "w_shade", "w_setup", "u_node", "u_shade")
+        return {k: int(v) for k, v in zip(keys, buf)}
+
+    def set_sched(self, node, tri, ctrl, serve_min):
+        self.set_option(abi.OPT_SCHED_WEIGHTS, node | (tri << 12) | (ctrl << 24) | (serve_min << 36))
 
     def upload(self, scene):
         desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)

@@ -102,11 +102,14 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 	return v;
 }
 
+/* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
+struct Sched { int wNode, wTri, wCtrl, serveMin, unused; };
+
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
 template <int LEVEL, int WPS, bool PROG>
 __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 														   unsigned long long *counters, uint32_t *spill, uint32_t spillStride,
-														   float *stage, int chunk, unsigned long long *waveStats) {
+														   float *stage, int chunk, unsigned long long *waveStats, const Sched K) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
@@ -141,7 +144,70 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 		for (int c0 = P.first_pass; c0 < passEnd; c0 += chunk) {
 			J.passBegin = c0;
 			J.passCount = min(chunk, passEnd - c0);
-			renderItems(S, P, stk, J, lane, 64u, myStage, cnt);
+			/* ---- the wave-level scheduler: every iteration, ballot which step each lane needs next and run the ONE
+			 * kind with the best (lanes waiting) x (1 / cost of that step) score for all lanes that want it. Cheap
+			 * steps (node, triangle) therefore run at high lane occupancy while lanes that reached an expensive step
+			 * (shading, item setup, instance change) wait until enough of them have gathered. Each lane's own sequence
+			 * of steps — hence every result — is independent of the schedule. ---- */
+			Walk w;
+			Item it;
+			memset(&w, 0, sizeof(w));
+			w.phase = PH_SETUP;
+			it.next = lane; it.cur = 0;
+			for (;;) {
+				const uint32_t ph = w.phase;
+				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL));
+				const int nR = __popcll(__ballot(ph == PH_SHADE || ph == PH_SETUP));      /* lanes waiting to be served */
+				if ((nN | nT | nC | nR) == 0) break;                         /* every lane is PH_DONE */
+				/* expensive steps (shading, item setup) are served together, and only once enough lanes wait for them
+				 * (or nothing else can run); the cheap walk steps compete by lanes x weight */
+				int pick;
+				if (nR >= K.serveMin || (nN | nT | nC) == 0) {
+					pick = PH_SHADE;
+				} else {
+					int best = nN * K.wNode;
+					pick = PH_NODE;
+					if (nT * K.wTri > best) { best = nT * K.wTri; pick = PH_TRI; }
+					if (nC * K.wCtrl > best) { best = nC * K.wCtrl; pick = PH_CTRL; }
+				}
+				uint32_t tk = 0;
+				if constexpr (LEVEL >= 2) tk = CRH_TICK();
+				switch (pick) {
+					case PH_NODE: {          /* keep stepping while at least 3/4 of the lanes that started this run still want node steps */
+						int now = nN;
+						do {
+							if (w.phase == PH_NODE) stepNode(S, w, stk, cnt);
+							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
+							now = __popcll(__ballot(w.phase == PH_NODE));
+						} while (now * 4 >= nN * 3);
+						break;
+					}
+					case PH_TRI: {
+						int now = nT;
+						do {
+							if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+							if constexpr (LEVEL >= 2) { if (lane == 0) cnt.w_tri += 1; }
+							now = __popcll(__ballot(w.phase == PH_TRI));
+						} while (now * 4 >= nT * 3);
+						break;
+					}
+					case PH_CTRL: if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt); break;
+					default:
+						if (ph == PH_SHADE) stepShade(S, P, w, it, stk, myStage, cnt);
+						if (w.phase == PH_SETUP) stepSetup(S, P, J, 64u, w, it, stk, myStage, cnt);
+						break;
+				}
+				if constexpr (LEVEL >= 2) {
+					if (lane == 0) {
+						const uint32_t dt = CRH_TICK() - tk;
+						cnt.w_round += 1;
+						if (pick == PH_NODE) { cnt.t_trav += dt; }
+						else if (pick == PH_TRI) { cnt.t_trav += dt; }
+						else if (pick == PH_CTRL) { cnt.w_ctrl += 1; cnt.t_trav += dt; }
+						else { cnt.w_shade += 1; cnt.t_shade += dt; cnt.u_shade += (uint32_t)nR; }
+					}
+				}
+			}
 			__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
 			for (uint32_t pix = lane; pix < (uint32_t)(Q.bw * Q.bh); pix += 64u) foldBlockPixel(P, J, pix, myStage, fb);
 			__threadfence_block();                 /* ... and read before the next chunk overwrites them */
@@ -172,6 +238,10 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 		v = waveSum(cnt.w_tri); if (lead && v) atomicAdd(&counters[12], (unsigned long long)v);
 		v = waveSum(cnt.w_ctrl); if (lead && v) atomicAdd(&counters[13], (unsigned long long)v);
 		v = waveSum(cnt.w_round); if (lead && v) atomicAdd(&counters[14], (unsigned long long)v);
+		v = waveSum(cnt.w_shade); if (lead && v) atomicAdd(&counters[15], (unsigned long long)v);
+		v = waveSum(cnt.w_setup); if (lead && v) atomicAdd(&counters[16], (unsigned long long)v);
+		v = waveSum(cnt.u_node); if (lead && v) atomicAdd(&counters[17], (unsigned long long)v);
+		v = waveSum(cnt.u_shade); if (lead && v) atomicAdd(&counters[18], (unsigned long long)v);
 	}
 }
 
@@ -222,6 +292,7 @@ struct crh_ctx {
 	int counterLevel = 2;
 	int passChunk = 64;
 	int unitItems = 1024;
+	Sched sched = {70, 160, 40, 40, 0};
 	int wavesPerSimd = 4;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;
@@ -314,8 +385,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 		if (stream) c->stream = (hipStream_t)stream;
 		else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->ownStream = (e == hipSuccess); }
 	}
-	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, 16 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, 24 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, 24 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
 	if (e != hipSuccess) {
 		const std::string msg = std::string("crh_context_create: ") + hipGetErrorString(e);
@@ -361,6 +432,11 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_WAVES_PER_SIMD:
 			if (value != 1 && value != 4) return fail(CRH_ERR_INVALID, "waves per SIMD must be 1 (unconstrained) or 4");
 			c->wavesPerSimd = (int)value; return CRH_OK;
+		case CRH_OPT_SCHED_WEIGHTS:   /* four 12-bit fields, low to high: node, tri, ctrl weights; lanes that must wait before shading / setup is served */
+			c->sched.wNode = (int)(value & 0xFFF); c->sched.wTri = (int)((value >> 12) & 0xFFF); c->sched.wCtrl = (int)((value >> 24) & 0xFFF);
+			c->sched.serveMin = (int)((value >> 36) & 0xFFF);
+			if (c->sched.wNode < 1 || c->sched.wTri < 1 || c->sched.wCtrl < 1 || c->sched.serveMin < 1 || c->sched.serveMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
+			return CRH_OK;
 		case CRH_OPT_UNIT_ITEMS:
 			if (value < 64 || value > (1 << 20)) return fail(CRH_ERR_INVALID, "unit items must be 64..2^20");
 			c->unitItems = (int)value; return CRH_OK;
@@ -551,7 +627,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
 #define CRH_LAUNCH(LEVEL, WPS, PROG) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
-												  c->dCounters, c->dSpill, grid * CRH_BLOCK, c->dStage, chunk, c->dWaveStats)
+												  c->dCounters, c->dSpill, grid * CRH_BLOCK, c->dStage, chunk, c->dWaveStats, c->sched)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true); else CRH_LAUNCH(LEVEL, WPS, false); } while (0)
 	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
 	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
@@ -657,7 +733,7 @@ int crh_counters_reset(crh_ctx *c) {
 	if (!c) return fail(CRH_ERR_INVALID, "crh_counters_reset: ctx is NULL");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
-	HIP_TRY(hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemset(c->dCounters, 0, 24 * sizeof(unsigned long long)));
 	c->lastMs = 0.0f; c->totalMs = 0.0; c->launches = 0;
 	return CRH_OK;
 }
@@ -675,13 +751,13 @@ int crh_kernel_time_ms(crh_ctx *c, float *last_ms, double *total_ms, uint64_t *l
 }
 
 /* debug: wall-clock ticks (100 MHz), summed over waves, spent in {item setup, BVH walk, shading} by the counting kernel */
-int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* 7 values: ticks {setup, walk, shade}, wave iterations {node, tri, ctrl, round} */) {
+int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* 11 values: ticks {setup, walk, shade}, wave steps {node, tri, ctrl, all, shade, setup}, lanes served {node, shade} */) {
 	if (!c || !out3) return fail(CRH_ERR_INVALID, "crh_debug_phase_ticks: NULL argument");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
-	unsigned long long h[7];
+	unsigned long long h[11];
 	HIP_TRY(hipMemcpy(h, c->dCounters + 8, sizeof(h), hipMemcpyDeviceToHost));
-	for (int i = 0; i < 7; ++i) out3[i] = h[i];
+	for (int i = 0; i < 11; ++i) out3[i] = h[i];
 	return CRH_OK;
 }
 

@@ -121,7 +121,8 @@ template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	static constexpr bool programs = PROGRAMS;
 	uint32_t rays, node_tests, tri_tests, inst_visits, inst_hits, sphere_tests, tex_fetches, paths;
 	uint32_t t_setup, t_trav, t_shade;   /* debug: wall-clock ticks (100 MHz) this wave spent per phase */
-	uint32_t w_node, w_tri, w_ctrl, w_round;   /* debug: WAVE-level iteration counts of the walk's phases (first active lane counts) */
+	uint32_t w_node, w_tri, w_ctrl, w_round, w_shade, w_setup;   /* debug: WAVE-level step counts by kind (lane 0 counts) */
+	uint32_t u_node, u_shade;                                     /* debug: lanes served by the node / shade steps */
 };
 template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
 	static constexpr int level = 1;
@@ -160,6 +161,12 @@ CRH_DEV v3 vneg(v3 v) { return v3{-v.x, -v.y, -v.z}; }
 CRH_DEV v3 vreflect(v3 I, v3 N) { return vsub(I, vscale(N, vdot(N, I) * 2.0f)); }
 CRH_DEV float wrapMax(float x, float mx) { return fmodf(mx + fmodf(x, mx), mx); }
 CRH_DEV float wrapMinMax(float x, float mn, float mx) { return mn + wrapMax(x - mn, mx - mn); }
+/* wrapMinMax(x, 0, 1) (vector.h:215-221) without the two fmodf for the common 0 <= x < 1: fmodf(x, 1) = x exactly,
+ * 1 + x rounds once into [1, 2], and fmodf(that, 1) is exact (that - 1, or 0 when the sum rounded up to 2). Same bits. */
+CRH_DEV float wrap01(float x) {
+	if (x >= 0.0f && x < 1.0f) { const float y = 1.0f + x; return 0.0f + (y < 2.0f ? y - 1.0f : 0.0f); }
+	return wrapMinMax(x, 0.0f, 1.0f);
+}
 CRH_DEV float rmin(float a, float b) { return a < b ? a : b; }     /* includes.h:20 */
 CRH_DEV float rmax(float a, float b) { return a > b ? a : b; }     /* includes.h:21 */
 
@@ -328,6 +335,7 @@ CRH_DEV void getCameraRay(const crh_camera &cam, Rng &rng, int x, int y, v3 &ro,
 /* (size_t)i % W for a possibly negative int i: the reference sign-extends to 64 bits, so a negative i wraps
  * as (2^64 - |i|) % W = (m64 + W - |i| % W) % W with m64 = 2^64 mod W — all in 32-bit arithmetic here. */
 CRH_DEV uint32_t wrapIndex(int i, uint32_t W, uint32_t m64) {
+	if ((W & (W - 1u)) == 0u) return (uint32_t)i & (W - 1u);      /* power of two: the two's-complement low bits ARE the 64-bit modulo */
 	if (i >= 0) return (uint32_t)i % W;
 	const uint32_t a = (uint32_t)(-(int64_t)i) % W;
 	return (m64 + W - a) % W;
@@ -643,8 +651,8 @@ CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
 	float theta = acosf((-ud.y / 1.0f));
 	float u = theta / CRH_PI;
 	float v = (phi / (CRH_PI / 2.0f));
-	u = wrapMinMax(u, 0.0f, 1.0f);
-	v = wrapMinMax(v, 0.0f, 1.0f);
+	u = wrap01(u);
+	v = wrap01(v);
 	rec.uv = v2{v, u};
 	float strength = evalValue(S, n.b, rec, cnt);
 	return ccoef(strength, evalColor(S, n.a, rec, cnt));
@@ -728,177 +736,201 @@ struct TravHit {
 };
 
 /*
- * getClosestIsect (pathtrace.c:26-30) -> traverseTopLevelBvh (bvh.c:488-496) as ONE loop per lane:
- * the TLAS walk, the per-instance ray transform (instance.c:45-60,169-185) and the BLAS walk
- * (bvh.c:354-441) share the node-step code so that lanes at different levels stay in the same
- * instruction stream. Order of every box / triangle / instance test is the reference's: both children
- * tested with the old maxDist, leaf children intersected left then right before descending, nearer
- * inner child first (bvh.c:397-436). Hit attributes are derived after the walk (finishHit).
+ * getClosestIsect (pathtrace.c:26-30) -> traverseTopLevelBvh (bvh.c:488-496) as a per-lane STATE MACHINE.
  *
- * Shape ("while-while"): each round runs (1) node steps while the lane has an inner pair to test — popping
- * the stack in the same loop when a subtree is exhausted —, (2) the pending leaf triangles, (3) at most one
- * control step (enter the next instance of a TLAS leaf / leave a finished BLAS / finish). Every phase is a
- * short uniform body, so a wave executes one kind of work at a time instead of all kinds every iteration.
+ * A lane's walk is cut into steps of three kinds — NODE (test one child pair, bvh.c:391-436), TRI (one leaf
+ * triangle, poly.c:17-53) and CTRL (enter the next instance of a TLAS leaf / leave a finished BLAS / finish,
+ * instance.c:45-60,169-185, bvh.c:468-486) — and `phase` says which kind the lane needs next. The order of every
+ * box / triangle / instance test is the reference's: both children tested with the old maxDist, leaf children
+ * intersected left then right before descending, nearer inner child first. Because each step is a short
+ * straight-line body, the wave-level scheduler (cray_hip.hip: k_pathtrace) can run, at every iteration, the ONE
+ * kind of step that most lanes are waiting for — lanes never sit out a whole divergent loop of their neighbours.
+ * Hit attributes are derived after the walk (finishHit).
  *
- * Stack: LDS-resident (device) / local array (host emulation); entries are device node indices, plus
- * the saved TLAS state (resume pair, pending instance ranges, world-space ray constants) while a lane is
- * inside a BLAS.
+ * Stack: LDS-resident (device) / local array (host emulation); entries are device node indices, plus the saved
+ * TLAS state (resume pair, pending instance ranges) while a lane is inside a BLAS; the world-space slab constants
+ * are parked in fixed LDS slots meanwhile.
  */
 #define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
-/* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside
- * a BLAS, and the path state that is dead during the walk (bounceStep) */
+/* fixed per-lane park slots (LDS on the device): the world-space slab constants while a lane is inside a BLAS, and
+ * the path state (weight, radiance, RNG, depth), which only the shading / setup steps touch */
 enum { PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT,
        PK_WR, PK_WG, PK_WB, PK_FR, PK_FG, PK_FB, PK_RNG0, PK_RNG1, PK_DEPTH, CRH_PARK_SLOTS };
 
-template <class Stack, class Cnt>
-CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD, TravHit &hit, Cnt &cnt) {
-	hit.t = FLT_MAX; hit.u = 0.0f; hit.v = 0.0f; hit.slot = -1; hit.inst = -1;
-	CRH_COUNT1(cnt, rays, 1);
-	if (S.tlas_node_count < 1u) return;                                   /* bvh.c:362-365 */
-	RayK k = makeRayK(rayO, rayD);     /* current-level ray: the world ray in the TLAS, the object-space ray inside a BLAS */
-	uint32_t node = CRH_NONE;         /* device index of the child PAIR tested next (children are adjacent: bvh.c:393-394) */
-	uint32_t pA = 0, pAe = 0, pB = 0, pBe = 0;   /* pending leaf prim ranges [p, pe) at the current level: left leaf, right leaf */
-	uint32_t sp = 0, spBase = 0;
-	bool inBlas = false, instFound = false;
-	int32_t curInst = -1;
+enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5 };
 
+struct Walk {
+	uint32_t phase;
+	RayK k;                                  /* current-level ray: world ray in the TLAS, object-space ray inside a BLAS */
+	v3 ro, rd;                               /* the world ray of this bounce */
+	uint32_t node;                           /* device index of the child PAIR tested next (children are adjacent: bvh.c:393-394) */
+	uint32_t pA, pAe, pB, pBe;               /* pending leaf prim ranges [p, pe) at the current level: left leaf, right leaf */
+	uint32_t sp, spBase;
+	uint32_t inBlas, instFound;
+	int32_t curInst;
+	TravHit hit;
+};
+
+/* after a step that left no pending prims: continue with the next pair, pop one, or hand over to CTRL */
+template <class Stack>
+CRH_DEV void walkAdvance(Walk &w, Stack &stk) {
+	if (w.pA != w.pAe) { w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
+	if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
+	if (w.node != CRH_NONE) { w.phase = PH_NODE; return; }
+	w.phase = w.inBlas ? PH_CTRL : PH_SHADE;       /* BLAS exhausted -> leave it; TLAS exhausted -> the walk is over */
+}
+
+template <class Stack, class Cnt>
+CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v3 d, Cnt &cnt) {
+	w.ro = o; w.rd = d;
+	w.hit.t = FLT_MAX; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -1; w.hit.inst = -1;
+	w.node = CRH_NONE; w.pA = w.pAe = w.pB = w.pBe = 0; w.sp = 0; w.spBase = 0;
+	w.inBlas = 0; w.instFound = 0; w.curInst = -1;
+	CRH_COUNT1(cnt, rays, 1);
+	w.k = makeRayK(o, d);
+	if (S.tlas_node_count < 1u) { w.phase = PH_SHADE; return; }              /* bvh.c:362-365 */
 	if (S.tlas_node_count == 1u) {                                          /* bvh.c:382-387 */
 		const f4 n0 = S.nodes[2u * S.tlas_root], n1 = S.nodes[2u * S.tlas_root + 1u];
 		float tE;
 		CRH_COUNT(cnt, node_tests, 1);
-		if (intersectNode(n0, n1, k, hit.t, tE)) { pA = CRH_DNODE_FIRST(n1); pAe = pA + CRH_DNODE_COUNT(n1); }
+		if (intersectNode(n0, n1, w.k, w.hit.t, tE)) { w.pA = CRH_DNODE_FIRST(n1); w.pAe = w.pA + CRH_DNODE_COUNT(n1); }
 	} else {
-		node = S.tlas_root;
+		w.node = S.tlas_root;
 	}
+	walkAdvance(w, stk);
+}
 
-	for (;;) {
-		CRH_WAVE_ITER(cnt, w_round);
-		/* ---- (1) node steps: bvh.c:391-436 ---- */
-		while (pA == pAe && node != CRH_NONE) {
-			CRH_WAVE_ITER(cnt, w_node);
-			const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
-			float tL, tR;
-			CRH_COUNT(cnt, node_tests, 2);
-			const bool hitL = intersectNode(l0, l1, k, hit.t, tL);
-			const bool hitR = intersectNode(r0, r1, k, hit.t, tR);
-			const bool leafL = CRH_DNODE_ISLEAF(l1), leafR = CRH_DNODE_ISLEAF(r1);
-			const uint32_t fl = CRH_DNODE_FIRST(l1), fr = CRH_DNODE_FIRST(r1);
-			if (hitL && leafL) { pA = fl; pAe = fl + CRH_DNODE_COUNT(l1); }
-			if (hitR && leafR) {
-				const uint32_t e = fr + CRH_DNODE_COUNT(r1);
-				if (pA != pAe) { pB = fr; pBe = e; } else { pA = fr; pAe = e; }
-			}
-			const bool inL = hitL && !leafL, inR = hitR && !leafR;
-			if (inL && inR) {
-				const bool swap = tL > tR;
-				node = swap ? fr : fl;
-				stk.push(sp++, swap ? fl : fr);
-			} else if (inL || inR) {
-				node = inL ? fl : fr;
-			} else if (pA == pAe && sp > spBase) {
-				node = stk.pop(--sp);             /* dead end with nothing pending: next subtree */
-			} else {
-				node = CRH_NONE;
+/* NODE: bvh.c:391-436 */
+template <class Stack, class Cnt>
+CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+	const uint32_t node = w.node;
+	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
+	float tL, tR;
+	CRH_COUNT(cnt, node_tests, 2);
+	const bool hitL = intersectNode(l0, l1, w.k, w.hit.t, tL);
+	const bool hitR = intersectNode(r0, r1, w.k, w.hit.t, tR);
+	const bool leafL = CRH_DNODE_ISLEAF(l1), leafR = CRH_DNODE_ISLEAF(r1);
+	const uint32_t fl = CRH_DNODE_FIRST(l1), fr = CRH_DNODE_FIRST(r1);
+	if (hitL && leafL) { w.pA = fl; w.pAe = fl + CRH_DNODE_COUNT(l1); }
+	if (hitR && leafR) {
+		const uint32_t e = fr + CRH_DNODE_COUNT(r1);
+		if (w.pA != w.pAe) { w.pB = fr; w.pBe = e; } else { w.pA = fr; w.pAe = e; }
+	}
+	const bool inL = hitL && !leafL, inR = hitR && !leafR;
+	if (inL && inR) {
+		const bool swap = tL > tR;
+		w.node = swap ? fr : fl;
+		stk.push(w.sp++, swap ? fl : fr);
+	} else if (inL || inR) {
+		w.node = inL ? fl : fr;
+	} else {
+		w.node = CRH_NONE;
+	}
+	walkAdvance(w, stk);
+}
+
+/* TRI: poly.c:17-53 on the prepared record (one triangle per step) */
+template <class Stack, class Cnt>
+CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+	const uint32_t slot = w.pA++;
+	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
+	const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
+	const v3 v0 = v3{q0.x, q0.y, q0.z}, e1 = v3{q0.w, q1.x, q1.y}, e2 = v3{q1.z, q1.w, q2.x}, n = v3{q2.y, q2.z, q2.w};
+	CRH_COUNT(cnt, tri_tests, 1);
+	const v3 c = vsub(v0, w.k.o);
+	const v3 r = vcross(w.k.d, c);
+	const float invDet = 1.0f / vdot(n, w.k.d);
+	const float u = vdot(r, e2) * invDet;
+	const float v = vdot(r, e1) * invDet;
+	if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
+		const float t = vdot(n, c) * invDet;
+		if (t >= 0.0f && t < w.hit.t) { w.hit.t = t; w.hit.u = u; w.hit.v = v; w.hit.slot = (int32_t)slot; w.instFound = 1; }
+	}
+	walkAdvance(w, stk);
+}
+
+/* CTRL: leave a finished BLAS (bvh.c:468-486 loop body tail) and / or visit the next instance of a TLAS leaf (bvh.c:472-484) */
+template <class Stack, class Cnt>
+CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+	if (w.inBlas) {
+		if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
+		w.inBlas = 0; w.instFound = 0;
+		w.k.o = w.ro; w.k.d = w.rd;
+		w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
+		w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
+		w.k.oct = stk.unpark(PK_OCT);
+		w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
+		w.spBase = 0;
+		if (w.pA == w.pAe) { walkAdvance(w, stk); return; }
+	}
+	/* next instance */
+	const uint32_t slot = w.pA++;
+	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
+	const int32_t idx = S.prims[slot];       /* leaf.first is already an absolute prim slot */
+	const DInstance *inst = &S.instances[idx];
+	CRH_COUNT(cnt, inst_visits, 1);
+	/* transformRay(Ainv) + offset: instance.c:46-50 / 170-174 */
+	v3 o = xfPoint(w.k.o, inst->Ainv);
+	const v3 d = xfVector(w.k.d, inst->Ainv);
+	o = vadd(o, vscale(d, inst->ray_offset));
+	if (inst->kind == CRH_INSTANCE_SPHERE) {
+		/* sphere.c:20-50 */
+		CRH_COUNT(cnt, sphere_tests, 1);
+		const float A = vdot(d, d);
+		const float B = 2.0f * vdot(d, o);
+		const float C = vdot(o, o) - (inst->radius * inst->radius);
+		const float disc = B * B - 4.0f * A * C;
+		if (!(disc < 0.0f)) {
+			const float sq = sqrtf(disc);
+			float t0 = (-B + sq) / 2.0f;
+			const float t1 = (-B - sq) / 2.0f;
+			if (t0 > t1 && t1 > 0.0f) t0 = t1;
+			if (!(t0 < 0.00001f || t0 > w.hit.t)) {
+				w.hit.t = t0; w.hit.slot = -1; w.hit.inst = idx;
+				CRH_COUNT(cnt, inst_hits, 1);
 			}
 		}
-		/* ---- (2) leaf triangles: poly.c:17-53 on the prepared record ---- */
-		if (inBlas) {
-			while (pA != pAe) {
-				CRH_WAVE_ITER(cnt, w_tri);
-				const uint32_t slot = pA++;
-				if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
-				const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
-				const v3 v0 = v3{q0.x, q0.y, q0.z}, e1 = v3{q0.w, q1.x, q1.y}, e2 = v3{q1.z, q1.w, q2.x}, n = v3{q2.y, q2.z, q2.w};
-				CRH_COUNT(cnt, tri_tests, 1);
-				const v3 c = vsub(v0, k.o);
-				const v3 r = vcross(k.d, c);
-				const float invDet = 1.0f / vdot(n, k.d);
-				const float u = vdot(r, e2) * invDet;
-				const float v = vdot(r, e1) * invDet;
-				if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
-					const float t = vdot(n, c) * invDet;
-					if (t >= 0.0f && t < hit.t) { hit.t = t; hit.u = u; hit.v = v; hit.slot = (int32_t)slot; instFound = true; }
-				}
-			}
-			if (node == CRH_NONE && sp > spBase) node = stk.pop(--sp);
-			if (node != CRH_NONE) continue;
-			/* ---- (3a) BLAS exhausted: back to the TLAS (bvh.c:468-486 loop body tail) ---- */
-			if (instFound) { hit.inst = curInst; CRH_COUNT(cnt, inst_hits, 1); }
-			inBlas = false;
-			k.o = rayO; k.d = rayD;      /* the world ray stays in registers (the caller needs it after the walk anyway) */
-			k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
-			k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
-			k.oct = stk.unpark(PK_OCT);
-			pBe = stk.pop(--sp); pB = stk.pop(--sp); pAe = stk.pop(--sp); pA = stk.pop(--sp); node = stk.pop(--sp);
-			spBase = 0;
-			if (pA == pAe) {
-				if (node == CRH_NONE && sp > 0u) node = stk.pop(--sp);
-				if (node == CRH_NONE) break;
-				continue;
-			}
-		} else if (pA == pAe) {
-			if (node == CRH_NONE && sp > 0u) node = stk.pop(--sp);
-			if (node == CRH_NONE) break;
-			continue;
+	} else if (inst->node_count < 1u) {
+		w.hit.inst = -1;                                                     /* bvh.c:362-365 via instance.c:175 */
+	} else if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) {
+		/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
+		 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
+	} else {
+		const RayK ko = makeRayK(o, d);
+		bool enter = true;
+		uint32_t rootA = 0, rootAe = 0;
+		if (inst->node_count == 1u) {                                      /* bvh.c:382-387 */
+			const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
+			float tE;
+			CRH_COUNT(cnt, node_tests, 1);
+			enter = intersectNode(n0, n1, ko, w.hit.t, tE);
+			rootA = CRH_DNODE_FIRST(n1); rootAe = rootA + CRH_DNODE_COUNT(n1);
 		}
-		/* ---- (3b) TLAS leaf: next instance (bvh.c:472-484) ---- */
-		{
-			CRH_WAVE_ITER(cnt, w_ctrl);
-			const uint32_t slot = pA++;
-			if (pA == pAe) { pA = pB; pAe = pBe; pB = pBe = 0; }
-			const int32_t idx = S.prims[slot];       /* leaf.first is already an absolute prim slot */
-			const DInstance *inst = &S.instances[idx];
-			CRH_COUNT(cnt, inst_visits, 1);
-			/* transformRay(Ainv) + offset: instance.c:46-50 / 170-174 */
-			v3 o = xfPoint(k.o, inst->Ainv);
-			const v3 d = xfVector(k.d, inst->Ainv);
-			o = vadd(o, vscale(d, inst->ray_offset));
-			if (inst->kind == CRH_INSTANCE_SPHERE) {
-				/* sphere.c:20-50 */
-				CRH_COUNT(cnt, sphere_tests, 1);
-				const float A = vdot(d, d);
-				const float B = 2.0f * vdot(d, o);
-				const float C = vdot(o, o) - (inst->radius * inst->radius);
-				const float disc = B * B - 4.0f * A * C;
-				if (!(disc < 0.0f)) {
-					const float sq = sqrtf(disc);
-					float t0 = (-B + sq) / 2.0f;
-					const float t1 = (-B - sq) / 2.0f;
-					if (t0 > t1 && t1 > 0.0f) t0 = t1;
-					if (!(t0 < 0.00001f || t0 > hit.t)) {
-						hit.t = t0; hit.slot = -1; hit.inst = idx;
-						CRH_COUNT(cnt, inst_hits, 1);
-					}
-				}
-			} else if (inst->node_count < 1u) {
-				hit.inst = -1;                                                     /* bvh.c:362-365 via instance.c:175 */
-			} else if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) {
-				/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
-				 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
-			} else {
-				const RayK ko = makeRayK(o, d);
-				bool enter = true;
-				uint32_t rootA = 0, rootAe = 0;
-				if (inst->node_count == 1u) {                                      /* bvh.c:382-387 */
-					const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
-					float tE;
-					CRH_COUNT(cnt, node_tests, 1);
-					enter = intersectNode(n0, n1, ko, hit.t, tE);
-					rootA = CRH_DNODE_FIRST(n1); rootAe = rootA + CRH_DNODE_COUNT(n1);
-				}
-				if (enter) {
-					stk.push(sp++, node); stk.push(sp++, pA); stk.push(sp++, pAe); stk.push(sp++, pB); stk.push(sp++, pBe);
-					stk.park(PK_IX, asU32(k.inv.x)); stk.park(PK_IY, asU32(k.inv.y)); stk.park(PK_IZ, asU32(k.inv.z));
-					stk.park(PK_SX, asU32(k.ss.x)); stk.park(PK_SY, asU32(k.ss.y)); stk.park(PK_SZ, asU32(k.ss.z));
-					stk.park(PK_OCT, k.oct);
-					if (inst->node_count == 1u) { node = CRH_NONE; pA = rootA; pAe = rootAe; }
-					else { node = inst->root; pA = pAe = 0; }
-					pB = pBe = 0;
-					spBase = sp; inBlas = true; instFound = false; curInst = idx; k = ko;
-				}
-			}
+		if (enter) {
+			stk.push(w.sp++, w.node); stk.push(w.sp++, w.pA); stk.push(w.sp++, w.pAe); stk.push(w.sp++, w.pB); stk.push(w.sp++, w.pBe);
+			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
+			stk.park(PK_SX, asU32(w.k.ss.x)); stk.park(PK_SY, asU32(w.k.ss.y)); stk.park(PK_SZ, asU32(w.k.ss.z));
+			stk.park(PK_OCT, w.k.oct);
+			if (inst->node_count == 1u) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
+			else { w.node = inst->root; w.pA = w.pAe = 0; }
+			w.pB = w.pBe = 0;
+			w.spBase = w.sp; w.inBlas = 1; w.instFound = 0; w.curInst = idx; w.k = ko;
 		}
 	}
+	walkAdvance(w, stk);
+}
+
+/* The whole walk for one lane (k_trace_rays, host emulation): run steps until the walk hands over to shading. */
+template <class Stack, class Cnt>
+CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD, TravHit &hit, Cnt &cnt) {
+	Walk w;
+	walkBegin(S, w, stk, rayO, rayD, cnt);
+	while (w.phase != PH_SHADE) {
+		if (w.phase == PH_NODE) stepNode(S, w, stk, cnt);
+		else if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+		else stepCtrl(S, w, stk, cnt);
+	}
+	hit = w.hit;
 }
 
 /* Hit attributes after the walk: exactly what instance.c:45-60 / 169-185 + poly.c:37-48 leave in the record. */
@@ -923,8 +955,8 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 		float theta = asinf(n.y);
 		float v = (theta + CRH_PI / 2.0f) / CRH_PI;
 		float u = 1.0f - (phi + CRH_PI) / (CRH_PI * 2.0f);
-		u = wrapMinMax(u, 0.0f, 1.0f);
-		v = wrapMinMax(v, 0.0f, 1.0f);
+		u = wrap01(u);
+		v = wrap01(v);
 		h.uv = v2{u, v};
 		h.poly = -1;
 		h.material = inst->material;
@@ -964,68 +996,7 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 	return h;
 }
 
-/* ---- one path: pathtrace.c:32-60, flattened to one bounce per call ------------------------------ */
-struct PathState {
-	v3 ro, rd;
-	float wr, wg, wb;      /* weight (alpha never reaches RGB) */
-	float fr, fg, fb;      /* finalColor                        */
-	int depth;
-	Rng rng;
-};
-
-/* One iteration of the pathTrace() loop body. Returns true when the path is complete. */
-template <class Stack, class Cnt>
-CRH_DEV bool bounceStep(const DScene &S, Stack &stk, PathState &p, int maxDepth, Cnt &cnt) {
-	TravHit hit;
-	/* weight, radiance, RNG and depth are dead during the walk: keep them in the lane's park slots, not in VGPRs */
-	stk.park(PK_WR, asU32(p.wr)); stk.park(PK_WG, asU32(p.wg)); stk.park(PK_WB, asU32(p.wb));
-	stk.park(PK_FR, asU32(p.fr)); stk.park(PK_FG, asU32(p.fg)); stk.park(PK_FB, asU32(p.fb));
-	stk.park(PK_RNG0, (uint32_t)p.rng.state); stk.park(PK_RNG1, (uint32_t)(p.rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)p.depth);
-	uint32_t tk0 = 0;
-	if constexpr (cnt_traits<Cnt>::level >= 2) tk0 = CRH_TICK();
-	traverse(S, stk, p.ro, p.rd, hit, cnt);
-	if constexpr (cnt_traits<Cnt>::level >= 2) { const uint32_t tk1 = CRH_TICK(); cnt.t_trav += tk1 - tk0; }
-	p.wr = asF32(stk.unpark(PK_WR)); p.wg = asF32(stk.unpark(PK_WG)); p.wb = asF32(stk.unpark(PK_WB));
-	p.fr = asF32(stk.unpark(PK_FR)); p.fg = asF32(stk.unpark(PK_FG)); p.fb = asF32(stk.unpark(PK_FB));
-	p.rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32); p.depth = (int)stk.unpark(PK_DEPTH);
-	ShadeRec rec;
-	rec.dir = p.rd;
-	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */
-		rec.point = v3{0.0f, 0.0f, 0.0f}; rec.normal = v3{0.0f, 0.0f, 0.0f}; rec.uv = v2{0.0f, 0.0f};
-		rec.distance = hit.t; rec.ior = 0.0f;
-		const rgba bg = sampleBackground(S, rec, cnt);
-		p.fr = p.fr + (p.wr * bg.r); p.fg = p.fg + (p.wg * bg.g); p.fb = p.fb + (p.wb * bg.b);
-		return true;
-	}
-	const HitInfo h = finishHit(S, p.ro, p.rd, hit);
-	const crh_material mat = S.materials[h.material];
-	p.fr = p.fr + (p.wr * mat.emission[0]); p.fg = p.fg + (p.wg * mat.emission[1]); p.fb = p.fb + (p.wb * mat.emission[2]);   /* :44 */
-	rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = hit.t; rec.ior = mat.ior;
-	const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, p.rng, cnt);   /* :46 */
-	p.ro = h.point; p.rd = s.out;                                    /* :47 */
-	float probability = 1.0f;
-	if (p.depth >= 4) {                                              /* :51-55 */
-		probability = rmax(s.r, rmax(s.g, s.b));
-		if (getDimension(p.rng) > probability) return true;
-	}
-	const float ip = 1.0f / probability;                             /* :57 */
-	p.wr = (s.r * p.wr) * ip; p.wg = (s.g * p.wg) * ip; p.wb = (s.b * p.wb) * ip;
-	p.depth++;
-	return p.depth >= maxDepth;
-}
-
-/*
- * The renderThread() pixel x pass loop (renderer.c:275-301), re-scheduled for a 64-wide wave.
- *
- * A wave owns one small pixel block (8x8 or 4x4 pixels of a tile) for a CHUNK of passes at a time. The
- * block's (pixel, pass) pairs are numbered pixel-major and lane l takes items l, l+64, l+128, ... so at any
- * moment the 64 lanes trace different passes of the SAME few pixels (coherent rays, one BLAS region in
- * cache) and every lane sees the same mix of cheap and expensive pixels (no systematic imbalance). Each
- * iteration of the lane loop is one bounce; a lane whose path ended starts its next item in the same
- * iteration, so no lane idles until the block's items run out. Finished samples go to a per-wave staging
- * slab; foldBlockPixel() then folds them into the running mean in pass order, exactly the reference's
- * sequence (renderer.c:288-291), one pixel per lane.
- */
+/* ---- one path: pathtrace.c:32-60 as SHADE steps; renderer.c:275-301 as SETUP steps -------------------- */
 struct BlockJob {
 	int x0, y0;          /* block origin in reference coordinates (y from the bottom) */
 	int w, h;            /* valid extent inside the block (ragged tile edges) */
@@ -1043,53 +1014,120 @@ CRH_DEV void foldSample(float &r, float &g, float &b, float sr, float sg, float 
 	b = ((b * n1) + sb) * t;
 }
 
+struct Item { uint32_t next, cur; };    /* next item this lane will take / the item of the path in flight */
+
+/*
+ * SETUP: the lane's next (pixel, pass) item of the block chunk, or PH_DONE. Items are numbered pixel-major and
+ * lane l takes items l, l+stride, ...: the 64 lanes of a wave trace different passes of the same few pixels.
+ * initSampler + getCameraRay (renderer.c:280-284), path state parked, walk started.
+ */
+template <class Stack, class Cnt>
+CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, Item &it,
+					   Stack &stk, float *stage, Cnt &cnt) {
+	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
+	for (;;) {
+		int x = 0, y = 0, pass = 0;
+		bool found = false;
+		while (it.next < nItems) {
+			const uint32_t pix = it.next / (uint32_t)J.passCount;
+			const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
+			if (px < J.w && py < J.h) {
+				x = J.x0 + px; y = J.y0 + py;
+				pass = J.passBegin + (int)(it.next % (uint32_t)J.passCount);
+				found = true;
+				break;
+			}
+			it.next += laneStride;
+		}
+		if (!found) { w.phase = PH_DONE; return; }
+		it.cur = it.next;
+		it.next += laneStride;
+		CRH_COUNT1(cnt, paths, 1);
+		if (P.bounces <= 0) {                      /* pathTrace() with maxDepth 0 returns black */
+			float *o = stage + (size_t)it.cur * 3;
+			o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+			continue;
+		}
+		Rng rng;
+		const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
+		initSampler(rng, pass, P.max_passes, pixIdx);                         /* :281 */
+		v3 ro, rd;
+		getCameraRay(S.camera, rng, x, y, ro, rd);                            /* :284 */
+		stk.park(PK_WR, asU32(1.0f)); stk.park(PK_WG, asU32(1.0f)); stk.park(PK_WB, asU32(1.0f));
+		stk.park(PK_FR, 0u); stk.park(PK_FG, 0u); stk.park(PK_FB, 0u);
+		stk.park(PK_RNG0, (uint32_t)rng.state); stk.park(PK_RNG1, (uint32_t)(rng.state >> 32)); stk.park(PK_DEPTH, 0u);
+		walkBegin(S, w, stk, ro, rd, cnt);
+		return;
+	}
+}
+
+/*
+ * SHADE: one iteration of the pathTrace() loop body after getClosestIsect (pathtrace.c:39-57). Either the path goes
+ * on (next ray, walk restarted) or its radiance is staged and the lane goes back to SETUP.
+ */
+template <class Stack, class Cnt>
+CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, Item &it, Stack &stk, float *stage, Cnt &cnt) {
+	float wr = asF32(stk.unpark(PK_WR)), wg = asF32(stk.unpark(PK_WG)), wb = asF32(stk.unpark(PK_WB));
+	float fr = asF32(stk.unpark(PK_FR)), fg = asF32(stk.unpark(PK_FG)), fb = asF32(stk.unpark(PK_FB));
+	bool done;
+	ShadeRec rec;
+	rec.dir = w.rd;
+	if (w.hit.inst < 0) {                                            /* pathtrace.c:39-42 */
+		rec.point = v3{0.0f, 0.0f, 0.0f}; rec.normal = v3{0.0f, 0.0f, 0.0f}; rec.uv = v2{0.0f, 0.0f};
+		rec.distance = w.hit.t; rec.ior = 0.0f;
+		const rgba bg = sampleBackground(S, rec, cnt);
+		fr = fr + (wr * bg.r); fg = fg + (wg * bg.g); fb = fb + (wb * bg.b);
+		done = true;
+	} else {
+		Rng rng;
+		rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32);
+		int depth = (int)stk.unpark(PK_DEPTH);
+		const HitInfo h = finishHit(S, w.ro, w.rd, w.hit);
+		const crh_material mat = S.materials[h.material];
+		fr = fr + (wr * mat.emission[0]); fg = fg + (wg * mat.emission[1]); fb = fb + (wb * mat.emission[2]);   /* :44 */
+		rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = w.hit.t; rec.ior = mat.ior;
+		const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, rng, cnt);     /* :46 */
+		done = false;
+		float probability = 1.0f;
+		if (depth >= 4) {                                                /* :51-55 */
+			probability = rmax(s.r, rmax(s.g, s.b));
+			if (getDimension(rng) > probability) done = true;
+		}
+		if (!done) {
+			const float ip = 1.0f / probability;                         /* :57 */
+			wr = (s.r * wr) * ip; wg = (s.g * wg) * ip; wb = (s.b * wb) * ip;
+			++depth;
+			done = depth >= P.bounces;
+		}
+		if (!done) {
+			stk.park(PK_WR, asU32(wr)); stk.park(PK_WG, asU32(wg)); stk.park(PK_WB, asU32(wb));
+			stk.park(PK_FR, asU32(fr)); stk.park(PK_FG, asU32(fg)); stk.park(PK_FB, asU32(fb));
+			stk.park(PK_RNG0, (uint32_t)rng.state); stk.park(PK_RNG1, (uint32_t)(rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)depth);
+			walkBegin(S, w, stk, h.point, s.out, cnt);                   /* :47 */
+			return;
+		}
+	}
+	float *o = stage + (size_t)it.cur * 3;
+	o[0] = fr; o[1] = fg; o[2] = fb;
+	w.phase = PH_SETUP;
+}
+
+/* One lane, all steps in sequence (host emulation and any non-scheduled use): the block chunk's items of this lane. */
 template <class Stack, class Cnt>
 CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk, const BlockJob &J, uint32_t lane, uint32_t laneStride,
 						 float *stage, Cnt &cnt) {
-	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
-	uint32_t item = lane, cur = 0;
-	bool havePath = false;
-	PathState p;
-	p.depth = 0; p.rng.state = 0;
-	p.ro = p.rd = v3{0.0f, 0.0f, 0.0f};
-	p.wr = p.wg = p.wb = p.fr = p.fg = p.fb = 0.0f;
+	Walk w;
+	Item it;
+	it.next = lane; it.cur = 0;
+	w.phase = PH_SETUP;
 	for (;;) {
-		uint32_t tks = 0;
-		if constexpr (cnt_traits<Cnt>::level >= 2) tks = CRH_TICK();
-		if (!havePath) {
-			int x = 0, y = 0, pass = 0;
-			bool found = false;
-			while (item < nItems) {
-				const uint32_t pix = item / (uint32_t)J.passCount;
-				const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
-				if (px < J.w && py < J.h) {
-					x = J.x0 + px; y = J.y0 + py;
-					pass = J.passBegin + (int)(item % (uint32_t)J.passCount);
-					found = true;
-					break;
-				}
-				item += laneStride;
-			}
-			if (!found) break;
-			cur = item;
-			item += laneStride;
-			const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
-			initSampler(p.rng, pass, P.max_passes, pixIdx);                       /* :281 */
-			getCameraRay(S.camera, p.rng, x, y, p.ro, p.rd);                      /* :284 */
-			p.wr = p.wg = p.wb = 1.0f; p.fr = p.fg = p.fb = 0.0f; p.depth = 0;
-			CRH_COUNT1(cnt, paths, 1);
-			havePath = true;
-		}
-		if constexpr (cnt_traits<Cnt>::level >= 2) cnt.t_setup += CRH_TICK() - tks;
-		uint32_t tkb = 0;
-		if constexpr (cnt_traits<Cnt>::level >= 2) tkb = CRH_TICK();
-		const uint32_t travBefore = [&]() { if constexpr (cnt_traits<Cnt>::level >= 2) return cnt.t_trav; else return 0u; }();
-		const bool done = (P.bounces <= 0) ? true : bounceStep(S, stk, p, P.bounces, cnt);
-		if constexpr (cnt_traits<Cnt>::level >= 2) cnt.t_shade += (CRH_TICK() - tkb) - (cnt.t_trav - travBefore);
-		if (done) {
-			float *o = stage + (size_t)cur * 3;
-			o[0] = p.fr; o[1] = p.fg; o[2] = p.fb;
-			havePath = false;
+		switch (w.phase) {
+			case PH_SETUP: stepSetup(S, P, J, laneStride, w, it, stk, stage, cnt); break;
+			case PH_NODE: stepNode(S, w, stk, cnt); break;
+			case PH_TRI: stepTri(S, w, stk, cnt); break;
+			case PH_CTRL: stepCtrl(S, w, stk, cnt); break;
+			case PH_SHADE: stepShade(S, P, w, it, stk, stage, cnt); break;
+			default: return;
 		}
 	}
 }

@@ -34,22 +34,27 @@ class FrameRenderer:
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        # the kernels run on torch's current stream so that they are ordered with the collective
-        self.stream = torch.cuda.current_stream(self.device)
+        # A dedicated (non-default) torch stream: the kernels are launched on its raw hipStream_t through the C-ABI and the
+        # tensor ops / the collective are issued under `with torch.cuda.stream(...)`, so everything is ordered on ONE stream.
+        # (torch's default stream has the raw handle 0, which the C-ABI would read as "create your own stream".)
+        self.stream = torch.cuda.Stream(device=self.device)
         self.ctx = api.Context(device, self.stream.cuda_stream)
         self.ctx.upload(scene)
-        self.fb = torch.zeros((self.height, self.width, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(self.stream):
+            self.fb = torch.zeros((self.height, self.width, 3), dtype=torch.float32, device=self.device)
         self.tiles = owned_tiles(self.width, self.height, tile[0], tile[1], order, rank, world)
 
     def render(self, samples, bounces, clear=True):
         """Enqueue this rank's tiles (asynchronous on the stream)."""
-        if clear:
-            self.fb.zero_()
-        if self.tiles:
-            self.ctx.render_tiles(self.fb.data_ptr(), self.width, self.height, samples, bounces, self.tiles)
+        with self.torch.cuda.stream(self.stream):
+            if clear:
+                self.fb.zero_()
+            if self.tiles:
+                self.ctx.render_tiles(self.fb.data_ptr(), self.width, self.height, samples, bounces, self.tiles)
 
     def reduce(self, dist=None):
-        return reduce_frame(self.fb, self.world, dist)
+        with self.torch.cuda.stream(self.stream):
+            return reduce_frame(self.fb, self.world, dist)
 
     def close(self):
         self.ctx.close()

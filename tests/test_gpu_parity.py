@@ -204,3 +204,31 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     assert bmp, "the reference's encoder wrote no image"
     data = open(tmp_path / bmp[0], "rb").read()
     assert data[:2] == b"BM" and len(data) >= w * h * 3
+
+
+def test_frame_renderer_on_torch_stream(pkg, ctx, manifest, golden_blob):
+    """The torch.distributed host (render.py): kernels on a torch stream, framebuffer = torch tensor. Same frame as the
+    plain C-ABI path, for the full tile list and for an interleaved 1-of-2 share (the other half stays exactly zero)."""
+    import torch
+    m = manifest["refraction"]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    full, _, _ = gpu_render(pkg, ctx, golden_blob("refraction"), w, h, s, b)
+    scene = pkg.api.Scene(golden_blob("refraction"))
+    fr = pkg.render.FrameRenderer(pkg.api, scene, w, h, device=0, rank=0, world=1, tile=(32, 32))
+    fr.render(s, b)
+    fr.reduce(None)
+    torch.cuda.synchronize()
+    assert np.array_equal(fr.fb.cpu().numpy(), full)
+    fr.render(s, b)                       # re-rendering clears first: same frame again
+    torch.cuda.synchronize()
+    assert np.array_equal(fr.fb.cpu().numpy(), full)
+    fr.close()
+    parts = []
+    for r in range(2):
+        f2 = pkg.render.FrameRenderer(pkg.api, scene, w, h, device=0, rank=r, world=2, tile=(32, 32))
+        f2.render(s, b)
+        torch.cuda.synchronize()
+        parts.append(f2.fb.cpu().numpy())
+        f2.close()
+    assert np.array_equal(parts[0] + parts[1], full)
+    assert not (np.abs(parts[0]) * np.abs(parts[1])).any()      # disjoint ownership

@@ -33,6 +33,12 @@ def library():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} is missing: run `python c-ray_amd/build.py` "
                                 "(or __graft_entry__.build()); there is no CPU fallback")
+    # torch wheels bundle their own libamdhip64; whichever HIP runtime is loaded first owns the device, and a second copy
+    # then reports "No HIP GPUs". Let torch (when present) load its copy first: libcray_hip's NEEDED libamdhip64 resolves to it.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     ctx = C.c_void_p
     sig = {

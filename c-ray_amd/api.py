@@ -13,7 +13,7 @@ import numpy as np
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_lib", "libcray_hip.so")
+LIB_PATH = os.environ.get("CRH_LIB") or os.path.join(HERE, "_lib", "libcray_hip.so")    # CRH_LIB: A/B another build (dev)
 
 
 class CrhError(RuntimeError):
@@ -147,9 +147,10 @@ class Context:
         return buf[:n]
 
     def phase_ticks(self):
-        buf = np.zeros(11, dtype=np.uint64)
+        buf = np.zeros(16, dtype=np.uint64)
         _check(self.L.crh_debug_phase_ticks(self.h, buf.ctypes.data), "crh_debug_phase_ticks")
-        keys = ("setup", "traverse", "shade", "w_node", "w_tri", "w_ctrl", "w_round", "w_shade", "w_setup", "u_node", "u_shade")
+        keys = ("setup", "traverse", "shade", "w_node", "w_tri", "w_ctrl", "w_round", "w_shade", "w_setup", "u_node", "u_shade",
+                "a_n", "a_t", "a_c", "a_r", "a_d")
         return {k: int(v) for k, v in zip(keys, buf)}
 
     def set_sched(self, node, tri, ctrl, serve_min):

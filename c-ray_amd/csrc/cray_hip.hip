@@ -292,7 +292,7 @@ struct crh_ctx {
 	int counterLevel = 2;
 	int passChunk = 64;
 	int unitItems = 1024;
-	Sched sched = {70, 160, 40, 40, 0};
+	Sched sched = {70, 160, 80, 40, 0};
 	int wavesPerSimd = 4;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;

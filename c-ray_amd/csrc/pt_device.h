@@ -693,13 +693,26 @@ CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
  *    exact-tie order), after a normal number of node visits. tests: test_zero_component_rays.
  *  - non-finite rays follow the reference's select chain literally.
  */
+/* v_min / v_max / v_max3 / v_min3 on values that are already canonical (results of fma on finite inputs): written as
+ * instructions so that the compiler does not put a quieting v_max x,x in front of every operand */
+#if defined(__HIPCC__)
+CRH_DEV float hwmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+CRH_DEV float hwmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+CRH_DEV float hwmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+CRH_DEV float hwmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+CRH_DEV float hwmin(float a, float b) { return fminf(a, b); }
+CRH_DEV float hwmax(float a, float b) { return fmaxf(a, b); }
+CRH_DEV float hwmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+CRH_DEV float hwmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+#endif
 CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDist, float &tEntry) {
 	const float xa = __builtin_fmaf(n0.x, k.inv.x, k.ss.x), xb = __builtin_fmaf(n0.y, k.inv.x, k.ss.x);
 	const float ya = __builtin_fmaf(n0.z, k.inv.y, k.ss.y), yb = __builtin_fmaf(n0.w, k.inv.y, k.ss.y);
 	const float za = __builtin_fmaf(n1.x, k.inv.z, k.ss.z), zb = __builtin_fmaf(n1.y, k.inv.z, k.ss.z);
 	if (!(k.oct & CRH_RAY_SLOW)) {
-		const float tMin = fmaxf(fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fminf(za, zb)), 0.0f);
-		const float tMax = fminf(fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fmaxf(za, zb)), maxDist);
+		const float tMin = hwmax3(hwmax(hwmin(xa, xb), hwmin(ya, yb)), hwmin(za, zb), 0.0f);
+		const float tMax = hwmin3(hwmin(hwmax(xa, xb), hwmax(ya, yb)), hwmax(za, zb), maxDist);
 		tEntry = tMin;
 		return tMin <= tMax;
 	}
@@ -811,21 +824,18 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	const bool hitR = intersectNode(r0, r1, w.k, w.hit.t, tR);
 	const bool leafL = CRH_DNODE_ISLEAF(l1), leafR = CRH_DNODE_ISLEAF(r1);
 	const uint32_t fl = CRH_DNODE_FIRST(l1), fr = CRH_DNODE_FIRST(r1);
-	if (hitL && leafL) { w.pA = fl; w.pAe = fl + CRH_DNODE_COUNT(l1); }
-	if (hitR && leafR) {
-		const uint32_t e = fr + CRH_DNODE_COUNT(r1);
-		if (w.pA != w.pAe) { w.pB = fr; w.pBe = e; } else { w.pA = fr; w.pAe = e; }
-	}
+	/* pending leaf ranges (none are pending when a node step runs): left leaf first, then the right one */
+	const bool lL = hitL && leafL, lR = hitR && leafR;
+	const uint32_t nL = lL ? CRH_DNODE_COUNT(l1) : 0u, nR = lR ? CRH_DNODE_COUNT(r1) : 0u;
+	w.pA = lL ? fl : fr;
+	w.pAe = w.pA + (lL ? nL : nR);
+	w.pB = fr;
+	w.pBe = fr + (lL ? nR : 0u);
+	/* descent: both inner -> nearer first, the other one on the stack */
 	const bool inL = hitL && !leafL, inR = hitR && !leafR;
-	if (inL && inR) {
-		const bool swap = tL > tR;
-		w.node = swap ? fr : fl;
-		stk.push(w.sp++, swap ? fl : fr);
-	} else if (inL || inR) {
-		w.node = inL ? fl : fr;
-	} else {
-		w.node = CRH_NONE;
-	}
+	const bool swap = tL > tR;
+	if (inL && inR) stk.push(w.sp++, swap ? fl : fr);
+	w.node = (inL && inR) ? (swap ? fr : fl) : (inL ? fl : (inR ? fr : CRH_NONE));
 	walkAdvance(w, stk);
 }
 

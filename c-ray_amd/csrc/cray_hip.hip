@@ -291,7 +291,8 @@ struct crh_ctx {
 	int blocksPerCU = 4;
 	int counterLevel = 2;
 	int passChunk = 64;
-	int unitItems = 1024;
+	int unitItems = 2048;
+	int unitsPerWave = 8;
 	Sched sched = {70, 160, 80, 40, 0};
 	int wavesPerSimd = 4;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
@@ -437,6 +438,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			c->sched.serveMin = (int)((value >> 36) & 0xFFF);
 			if (c->sched.wNode < 1 || c->sched.wTri < 1 || c->sched.wCtrl < 1 || c->sched.serveMin < 1 || c->sched.serveMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
 			return CRH_OK;
+		case CRH_OPT_UNITS_PER_WAVE:
+			if (value < 1 || value > 1024) return fail(CRH_ERR_INVALID, "units per wave must be 1..1024");
+			c->unitsPerWave = (int)value; return CRH_OK;
 		case CRH_OPT_UNIT_ITEMS:
 			if (value < 64 || value > (1 << 20)) return fail(CRH_ERR_INVALID, "unit items must be 64..2^20");
 			c->unitItems = (int)value; return CRH_OK;
@@ -570,7 +574,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	const uint64_t wavesMax = (uint64_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
 	int area = 1;
 	while (area < 256 && (int64_t)area * P->pass_count < c->unitItems) area *= 2;
-	while (area > 1 && pixels / area < 16 * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
+	while (area > 1 && pixels / area < (uint64_t)c->unitsPerWave * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
 	int bw = 1, bh = 1;
 	while (bw * bh < area) { if (bw <= bh) bw *= 2; else bh *= 2; }
 	std::vector<uint32_t> start(tile_count + 1, 0);

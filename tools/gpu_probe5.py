@@ -11,10 +11,12 @@ for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 256, 8), ("cfg3_venus", 1920,
     scene = api.Scene(os.path.join(BUILT, name + ".blob"))
     ctx.upload(scene)
     fb = ctx.framebuffer(w, h)
-    best = None
-    for rep in range(2):
-        ctx.clear(fb, w, h); ctx.reset_counters()
-        ctx.render_region(fb, w, h, spp, b); ctx.synchronize()
-        ms = ctx.kernel_time_ms()[0]; rays = ctx.counters()["rays"]
-        best = ms if best is None else min(best, ms)
-    print(f"{name}: {best:.1f} ms {rays/best/1e3:.0f} Mray/s", flush=True)
+    for items, upw in ((1024, 16), (2048, 8), (4096, 8), (4096, 4), (8192, 4)):
+        ctx.set_option(abi.OPT_UNIT_ITEMS, items); ctx.set_option(abi.OPT_UNITS_PER_WAVE, upw)
+        best = None
+        for rep in range(2):
+            ctx.clear(fb, w, h); ctx.reset_counters()
+            ctx.render_region(fb, w, h, spp, b); ctx.synchronize()
+            ms = ctx.kernel_time_ms()[0]; rays = ctx.counters()["rays"]
+            best = ms if best is None else min(best, ms)
+        print(f"{name} items {items} units/wave>={upw}: {best:.1f} ms {rays/best/1e3:.0f} Mray/s", flush=True)

@@ -108,7 +108,7 @@ struct Sched { int wNode, wTri, wCtrl, serveMin, unused; };
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
 template <int LEVEL, int WPS, bool PROG>
 __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
-														   unsigned long long *counters, uint32_t *spill, uint32_t spillStride,
+														   unsigned long long *counters,
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 	}
 }
 
-__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits, uint32_t *spill, uint32_t spillStride) {
+__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
@@ -303,12 +303,9 @@ struct crh_ctx {
 	bool hasPrograms = true;     /* the compiled scene contains node programs -> kernel variant with runProgram() */
 	DScene d;                              /* device pointers */
 	std::vector<void *> sceneAllocs;
-	uint32_t maxStack = 0;
 	unsigned long long *dCounters = nullptr;
 	uint32_t *dWork = nullptr;             /* ring of work counters, one per in-flight launch */
 	uint32_t workSlot = 0;
-	uint32_t *dSpill = nullptr;
-	size_t spillEntries = 0;
 	std::vector<void *> deferredFrees;     /* per-launch tile lists: freed once the stream has drained */
 	struct Timed { hipEvent_t a, b; };
 	std::vector<Timed> pendingTimes;
@@ -410,7 +407,6 @@ int crh_context_destroy(crh_ctx *c) {
 	for (auto &t : c->eventPool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	if (c->dCounters) (void)hipFree(c->dCounters);
 	if (c->dWork) (void)hipFree(c->dWork);
-	if (c->dSpill) (void)hipFree(c->dSpill);
 	if (c->dStage) (void)hipFree(c->dStage);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -484,7 +480,6 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base;
 	d.background = cs.background; d.camera = cs.camera;
 	c->d = d;
-	c->maxStack = cs.max_stack;
 	c->hasPrograms = cs.prog.size() > 1 || getenv("CRH_FORCE_PROGRAMS") != nullptr;
 	c->haveScene = true;
 	return CRH_OK;
@@ -545,18 +540,6 @@ int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int hei
 	return CRH_OK;
 }
 
-static int ensureSpill(crh_ctx *c, uint32_t threads) {
-	const size_t extra = c->maxStack > CRH_STACK_LDS ? (size_t)(c->maxStack - CRH_STACK_LDS) : 0;
-	const size_t need = std::max<size_t>(extra * threads, 1);
-	if (need <= c->spillEntries) return CRH_OK;
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	if (c->dSpill) HIP_TRY(hipFree(c->dSpill));
-	c->dSpill = nullptr; c->spillEntries = 0;
-	HIP_TRY(hipMalloc((void **)&c->dSpill, need * sizeof(uint32_t)));
-	c->spillEntries = need;
-	return CRH_OK;
-}
-
 int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, float *dev_fb) {
 	if (!c || !P || !dev_fb || (!tiles && tile_count)) return fail(CRH_ERR_INVALID, "crh_render_tiles: NULL argument");
 	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_render_tiles: no scene uploaded");
@@ -591,8 +574,6 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (total == 0 || P->pass_count == 0) return CRH_OK;
 
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (total + 3) / 4);
-	rc = ensureSpill(c, grid * CRH_BLOCK);
-	if (rc) return rc;
 	/* passes per chunk: a chunk (block x passes) should also hold about unitItems paths, so that each lane runs >= 16
 	 * paths between two wave-wide folds */
 	const int chunk = std::min(P->pass_count, std::max(c->passChunk, (c->unitItems + area - 1) / area));
@@ -631,7 +612,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
 #define CRH_LAUNCH(LEVEL, WPS, PROG) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
-												  c->dCounters, c->dSpill, grid * CRH_BLOCK, c->dStage, chunk, c->dWaveStats, c->sched)
+												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true); else CRH_LAUNCH(LEVEL, WPS, false); } while (0)
 	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
 	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
@@ -782,15 +763,13 @@ int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits
 	int rc = setDevice(c);
 	if (rc) return rc;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (n + CRH_BLOCK - 1) / CRH_BLOCK);
-	rc = ensureSpill(c, grid * CRH_BLOCK);
-	if (rc) return rc;
 	float *dRays = nullptr;
 	crh_hit *dHits = nullptr;
 	hipError_t e = hipMalloc((void **)&dRays, n * 6 * sizeof(float));
 	if (e == hipSuccess) e = hipMalloc((void **)&dHits, n * sizeof(crh_hit));
 	if (e == hipSuccess) e = hipMemcpyAsync(dRays, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, dRays, n, dHits, c->dSpill, grid * CRH_BLOCK);
+		hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, dRays, n, dHits);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(hits_host, dHits, n * sizeof(crh_hit), hipMemcpyDeviceToHost, c->stream);

@@ -141,11 +141,6 @@ template <class T> struct cnt_traits<T &> { static constexpr int level = T::leve
 #else
 #define CRH_TICK() 0u
 #endif
-#if defined(__HIPCC__)
-#define CRH_WAVE_ITER(c, field) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 2) { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) (c).field += 1; } } while (0)
-#else
-#define CRH_WAVE_ITER(c, field) do { } while (0)
-#endif
 #define CRH_COUNT1(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 1) (c).field += (n); } while (0)
 
 /* ---- vector.h / color.h ---------------------------------------------------------------------- */

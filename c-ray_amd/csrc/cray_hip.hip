@@ -33,7 +33,9 @@ using namespace crh;
 
 /* ---- tunables ---------------------------------------------------------------------------------- */
 #define CRH_BLOCK 256            /* 4 waves of 64 */
+#ifndef CRH_STACK_LDS
 #define CRH_STACK_LDS 24         /* traversal stack entries kept in LDS per lane; with the 16 park slots: 40 KB per block, 4 blocks per CU */
+#endif
 
 /* ---- error plumbing ---------------------------------------------------------------------------- */
 static thread_local std::string t_err;
@@ -50,7 +52,7 @@ static int fail(int code, const std::string &msg) { t_err = msg; return code; }
  * addressed through their own address spaces — never through one generic pointer, which would turn every stack
  * access into a flat_load / flat_store. LDS + overflow cover the worst case the scene compiler can report
  * (64 + 5 + 64 + 1, bvh.c:32). The park slots (pt_device.h: PK_*) are LDS too. */
-#define CRH_STACK_OVF 110
+#define CRH_STACK_OVF (134 - CRH_STACK_LDS)
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsStack {
 	lds_u32 *lds;        /* &s_stack[threadIdx.x] */
@@ -106,8 +108,11 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 struct Sched { int wNode, wTri, wCtrl, serveMin, unused; };
 
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
+#ifndef CRH_WPS_OVERRIDE
+#define CRH_WPS_OVERRIDE WPS
+#endif
 template <int LEVEL, int WPS, bool PROG>
-__global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
+__global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 														   unsigned long long *counters,
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_pathtrace(const DScene Sarg,
 						const uint32_t dt = CRH_TICK() - tk;
 						cnt.w_round += 1;
 						if (pick == PH_NODE) { cnt.t_trav += dt; }
-						else if (pick == PH_TRI) { cnt.t_trav += dt; }
-						else if (pick == PH_CTRL) { cnt.w_ctrl += 1; cnt.t_trav += dt; }
+						else if (pick == PH_TRI) { cnt.t_setup += dt; }
+						else if (pick == PH_CTRL) { cnt.w_ctrl += 1; cnt.w_setup += dt; }
 						else { cnt.w_shade += 1; cnt.t_shade += dt; cnt.u_shade += (uint32_t)nR; }
 					}
 				}

@@ -1029,16 +1029,19 @@ struct Item { uint32_t next, cur; };    /* next item this lane will take / the i
 template <class Stack, class Cnt>
 CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, Item &it,
 					   Stack &stk, float *stage, Cnt &cnt) {
-	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
+	const uint32_t pc = (uint32_t)J.passCount, bw = (uint32_t)J.bw;       /* bw is a power of two; pc usually is */
+	const uint32_t nItems = (uint32_t)(J.bw * J.bh) * pc;
+	const bool pcPow2 = (pc & (pc - 1u)) == 0u;
+	const uint32_t pcShift = 31u - (uint32_t)__builtin_clz(pc | 1u), bwShift = 31u - (uint32_t)__builtin_clz(bw | 1u);
 	for (;;) {
 		int x = 0, y = 0, pass = 0;
 		bool found = false;
 		while (it.next < nItems) {
-			const uint32_t pix = it.next / (uint32_t)J.passCount;
-			const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
+			const uint32_t pix = pcPow2 ? (it.next >> pcShift) : (it.next / pc);
+			const int px = (int)(pix & (bw - 1u)), py = (int)(pix >> bwShift);
 			if (px < J.w && py < J.h) {
 				x = J.x0 + px; y = J.y0 + py;
-				pass = J.passBegin + (int)(it.next % (uint32_t)J.passCount);
+				pass = J.passBegin + (int)(pcPow2 ? (it.next & (pc - 1u)) : (it.next - pix * pc));
 				found = true;
 				break;
 			}

@@ -11,7 +11,7 @@ for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 256, 8), ("cfg3_venus", 1920,
     scene = api.Scene(os.path.join(BUILT, name + ".blob"))
     ctx.upload(scene)
     fb = ctx.framebuffer(w, h)
-    for items, upw in ((1024, 16), (2048, 8), (4096, 8), (4096, 4), (8192, 4)):
+    for items, upw in ((2048, 8),):
         ctx.set_option(abi.OPT_UNIT_ITEMS, items); ctx.set_option(abi.OPT_UNITS_PER_WAVE, upw)
         best = None
         for rep in range(2):

@@ -147,14 +147,14 @@ class Context:
         return buf[:n]
 
     def phase_ticks(self):
-        buf = np.zeros(16, dtype=np.uint64)
+        buf = np.zeros(24, dtype=np.uint64)
         _check(self.L.crh_debug_phase_ticks(self.h, buf.ctypes.data), "crh_debug_phase_ticks")
         keys = ("setup", "traverse", "shade", "w_node", "w_tri", "w_ctrl", "w_round", "w_shade", "w_setup", "u_node", "u_shade",
-                "a_n", "a_t", "a_c", "a_r", "a_d")
+                "t_swap", "t_gen", "n_swap", "n_gen", "u_swap", "u_tri", "u_ctrl")
         return {k: int(v) for k, v in zip(keys, buf)}
 
-    def set_sched(self, node, tri, ctrl, serve_min):
-        self.set_option(abi.OPT_SCHED_WEIGHTS, node | (tri << 12) | (ctrl << 24) | (serve_min << 36))
+    def set_sched(self, node, tri, ctrl, serve_min, swap_min=0):
+        self.set_option(abi.OPT_SCHED_WEIGHTS, node | (tri << 12) | (ctrl << 24) | (serve_min << 36) | (swap_min << 48))
 
     def upload(self, scene):
         desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)

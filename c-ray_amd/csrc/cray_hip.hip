@@ -34,7 +34,7 @@ using namespace crh;
 /* ---- tunables ---------------------------------------------------------------------------------- */
 #define CRH_BLOCK 256            /* 4 waves of 64 */
 #ifndef CRH_STACK_LDS
-#define CRH_STACK_LDS 24         /* traversal stack entries kept in LDS per lane; with the 16 park slots: 40 KB per block, 4 blocks per CU */
+#define CRH_STACK_LDS 23         /* traversal stack entries kept in LDS per lane; with the 16 park slots + queue cursors: < 40 KB per block, 4 blocks per CU */
 #endif
 
 /* ---- error plumbing ---------------------------------------------------------------------------- */
@@ -104,8 +104,41 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 	return v;
 }
 
+#define CRH_NCOUNTERS 32
+
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, serveMin, unused; };
+struct Sched { int wNode, wTri, wCtrl, serveMin, swapMin; };
+
+/* Per-wave work stacks in global memory (field-major: field f of slot s at [f * CAP + s]). They are LIFO so that the
+ * hot part is only as deep as the live backlog (tens of records): it stays in L2 instead of cycling through a ring. */
+#define CRH_RAY_CAP 256u     /* < 64 waiting + 64 from GEN + 64 from SHADE */
+#define CRH_HIT_CAP 128u     /* < 64 waiting + 64 retired by one SWAP */
+#define CRH_RAY_FIELDS 16    /* o, d, weight, radiance, rng (2), depth, item */
+#define CRH_HIT_FIELDS 21    /* ray record + t, u, v, slot, inst */
+#define CRH_MISS_FIELDS 11   /* d, weight, radiance, item, t */
+#define CRH_WAVE_QUEUE_FLOATS (CRH_RAY_FIELDS * CRH_RAY_CAP + (CRH_HIT_FIELDS + CRH_MISS_FIELDS) * CRH_HIT_CAP)
+
+__device__ __forceinline__ void putRay(float *q, uint32_t cap, const v3 &o, const v3 &d, const PathRec &r, uint32_t item) {
+	q[0 * cap] = o.x; q[1 * cap] = o.y; q[2 * cap] = o.z;
+	q[3 * cap] = d.x; q[4 * cap] = d.y; q[5 * cap] = d.z;
+	q[6 * cap] = r.wr; q[7 * cap] = r.wg; q[8 * cap] = r.wb;
+	q[9 * cap] = r.fr; q[10 * cap] = r.fg; q[11 * cap] = r.fb;
+	q[12 * cap] = asF32((uint32_t)r.rng.state); q[13 * cap] = asF32((uint32_t)(r.rng.state >> 32));
+	q[14 * cap] = asF32((uint32_t)r.depth); q[15 * cap] = asF32(item);
+}
+__device__ __forceinline__ void getRay(const float *q, uint32_t cap, v3 &o, v3 &d, PathRec &r, uint32_t &item) {
+	o = v3{q[0 * cap], q[1 * cap], q[2 * cap]}; d = v3{q[3 * cap], q[4 * cap], q[5 * cap]};
+	r.wr = q[6 * cap]; r.wg = q[7 * cap]; r.wb = q[8 * cap];
+	r.fr = q[9 * cap]; r.fg = q[10 * cap]; r.fb = q[11 * cap];
+	r.rng.state = (uint64_t)asU32(q[12 * cap]) | ((uint64_t)asU32(q[13 * cap]) << 32);
+	r.depth = (int)asU32(q[14 * cap]);
+	item = asU32(q[15 * cap]);
+}
+
+/* rank of this lane among the set bits of a ballot mask below it */
+__device__ __forceinline__ uint32_t laneRank(unsigned long long m) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
 #ifndef CRH_WPS_OVERRIDE
@@ -114,7 +147,7 @@ struct Sched { int wNode, wTri, wCtrl, serveMin, unused; };
 template <int LEVEL, int WPS, bool PROG>
 __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 														   unsigned long long *counters,
-														   float *stage, int chunk, unsigned long long *waveStats, const Sched K) {
+														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
@@ -129,6 +162,16 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
 	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
 	const int passEnd = P.first_pass + P.pass_count;
+	/* per-wave work stacks and their wave-uniform fill levels in LDS (lane 0 writes, every lane reads: as plain
+	 * variables they would be scalar registers live across the whole machine, and the register allocator is past its
+	 * limits there — measured slower, and wrong images in the variant that calls runProgram) */
+	float *const rayQ = queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS;
+	float *const hitQ = rayQ + (size_t)CRH_RAY_FIELDS * CRH_RAY_CAP;
+	float *const missQ = hitQ + (size_t)CRH_HIT_FIELDS * CRH_HIT_CAP;
+	enum { WQ_RAYS, WQ_HITS, WQ_MISSES, WQ_NEXT_ITEM, WQ_WORDS };
+	__shared__ int s_wq[(CRH_BLOCK / 64) * WQ_WORDS];
+	typedef volatile __attribute__((address_space(3))) int lds_int;
+	lds_int *const wq = (lds_int *)&s_wq[(threadIdx.x >> 6) * WQ_WORDS];
 	for (;;) {
 		uint32_t unit = 0;
 		if (lane == 0) unit = atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
@@ -149,36 +192,59 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		for (int c0 = P.first_pass; c0 < passEnd; c0 += chunk) {
 			J.passBegin = c0;
 			J.passCount = min(chunk, passEnd - c0);
-			/* ---- the wave-level scheduler: every iteration, ballot which step each lane needs next and run the ONE
-			 * kind with the best (lanes waiting) x (1 / cost of that step) score for all lanes that want it. Cheap
-			 * steps (node, triangle) therefore run at high lane occupancy while lanes that reached an expensive step
-			 * (shading, item setup, instance change) wait until enough of them have gathered. Each lane's own sequence
-			 * of steps — hence every result — is independent of the schedule. ---- */
+			const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);       /* incl. the padding of ragged tile edges */
+			const uint32_t validItems = (uint32_t)(J.w * J.h * J.passCount);
+			/*
+			 * ---- the wave as a small wavefront machine -----------------------------------------------------------------
+			 * Paths are decoupled from lanes. Two per-wave ring queues in global memory (L2-resident) hold RAYS waiting
+			 * for a walk and HITS waiting for shading, each record carrying its path state (weight, radiance, RNG, depth,
+			 * item). Lanes are workers: every iteration the wave ballots what its lanes need and runs ONE kind of step:
+			 *   NODE / TRI / CTRL  walk steps (state machine of pt_device.h), picked by lanes x weight;
+			 *   SWAP   lanes whose walk ended append their hit (compacted with ballot + mbcnt) and, together with idle
+			 *          lanes, take the next rays from the ray queue — a cheap step, so walkers are refilled early and
+			 *          never wait for their own shading;
+			 *   GEN    all 64 lanes start the next 64 items (initSampler + getCameraRay) into the ray queue;
+			 *   SHADE  all 64 lanes shade 64 queued hits (finishHit, emission, bsdf sample, roulette / background):
+			 *          continuing paths are appended to the ray queue, finished samples staged.
+			 * The expensive steps therefore always run at (close to) full occupancy and the walk steps always have rays.
+			 * Each path's own sequence of operations — hence every result — is independent of the schedule.
+			 */
+			if (lane == 0) { wq[WQ_RAYS] = 0; wq[WQ_HITS] = 0; wq[WQ_MISSES] = 0; wq[WQ_NEXT_ITEM] = 0; }
 			Walk w;
-			Item it;
 			memset(&w, 0, sizeof(w));
-			w.phase = PH_SETUP;
-			it.next = lane; it.cur = 0;
+			w.phase = PH_IDLE;
+			uint32_t myItem = 0;
 			for (;;) {
 				const uint32_t ph = w.phase;
 				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL));
-				const int nR = __popcll(__ballot(ph == PH_SHADE || ph == PH_SETUP));      /* lanes waiting to be served */
-				if ((nN | nT | nC | nR) == 0) break;                         /* every lane is PH_DONE */
-				/* expensive steps (shading, item setup) are served together, and only once enough lanes wait for them
-				 * (or nothing else can run); the cheap walk steps compete by lanes x weight */
+				const int nF = __popcll(__ballot(ph == PH_SHADE));           /* walks that ended, result not yet queued */
+				const int nE = 64 - nN - nT - nC - nF;                        /* idle lanes */
+				const int raysQ = wq[WQ_RAYS], hitsQ = wq[WQ_HITS], missQn = wq[WQ_MISSES];
+				const uint32_t nextItem = (uint32_t)wq[WQ_NEXT_ITEM];
+				const bool itemsLeft = nextItem < nItems;
+				const int walkers = nN + nT + nC;
+				enum { ST_NODE, ST_TRI, ST_CTRL, ST_SWAP, ST_GEN, ST_SHADE, ST_MISS, ST_END };
 				int pick;
-				if (nR >= K.serveMin || (nN | nT | nC) == 0) {
-					pick = PH_SHADE;
-				} else {
+				if (hitsQ >= 64) pick = ST_SHADE;
+				else if (missQn >= 64) pick = ST_MISS;
+				else if (nF + nE >= K.swapMin && (nF > 0 || (nE > 0 && raysQ > 0))) pick = ST_SWAP;
+				else if (itemsLeft && raysQ < 64 && nE + nF > 0 && raysQ < nE + nF) pick = ST_GEN;
+				else if (walkers > 0) {
 					int best = nN * K.wNode;
-					pick = PH_NODE;
-					if (nT * K.wTri > best) { best = nT * K.wTri; pick = PH_TRI; }
-					if (nC * K.wCtrl > best) { best = nC * K.wCtrl; pick = PH_CTRL; }
+					pick = ST_NODE;
+					if (nT * K.wTri > best) { best = nT * K.wTri; pick = ST_TRI; }
+					if (nC * K.wCtrl > best) { best = nC * K.wCtrl; pick = ST_CTRL; }
 				}
+				else if (nF > 0 || (nE > 0 && raysQ > 0)) pick = ST_SWAP;
+				else if (hitsQ > 0) pick = ST_SHADE;
+				else if (itemsLeft) pick = ST_GEN;
+				else if (missQn > 0) pick = ST_MISS;
+				else pick = ST_END;
+				if (pick == ST_END) break;
 				uint32_t tk = 0;
 				if constexpr (LEVEL >= 2) tk = CRH_TICK();
 				switch (pick) {
-					case PH_NODE: {          /* keep stepping while at least 3/4 of the lanes that started this run still want node steps */
+					case ST_NODE: {          /* keep stepping while at least 3/4 of the lanes that started this run still want node steps */
 						int now = nN;
 						do {
 							if (w.phase == PH_NODE) stepNode(S, w, stk, cnt);
@@ -187,32 +253,124 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						} while (now * 4 >= nN * 3);
 						break;
 					}
-					case PH_TRI: {
+					case ST_TRI: {
 						int now = nT;
 						do {
 							if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
-							if constexpr (LEVEL >= 2) { if (lane == 0) cnt.w_tri += 1; }
+							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_tri += 1; cnt.u_tri += (uint32_t)now; } }
 							now = __popcll(__ballot(w.phase == PH_TRI));
 						} while (now * 4 >= nT * 3);
 						break;
 					}
-					case PH_CTRL: if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt); break;
-					default:
-						if (ph == PH_SHADE) stepShade(S, P, w, it, stk, myStage, cnt);
-						if (w.phase == PH_SETUP) stepSetup(S, P, J, 64u, w, it, stk, myStage, cnt);
+					case ST_CTRL: if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt); break;
+					case ST_SWAP: {
+						/* retire: walks that ended push their result (compacted) on the hit or the miss stack */
+						const bool fin = (ph == PH_SHADE);
+						const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
+						const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
+						if (fin) {
+							const PathRec r = unparkPath(stk);
+							if (finHit) {
+								float *q = hitQ + ((uint32_t)hitsQ + laneRank(hm));
+								putRay(q, CRH_HIT_CAP, w.ro, w.rd, r, myItem);
+								q[16 * CRH_HIT_CAP] = w.hit.t; q[17 * CRH_HIT_CAP] = w.hit.u; q[18 * CRH_HIT_CAP] = w.hit.v;
+								q[19 * CRH_HIT_CAP] = asF32((uint32_t)w.hit.slot); q[20 * CRH_HIT_CAP] = asF32((uint32_t)w.hit.inst);
+							} else {
+								float *q = missQ + ((uint32_t)missQn + laneRank(mm));
+								q[0 * CRH_HIT_CAP] = w.rd.x; q[1 * CRH_HIT_CAP] = w.rd.y; q[2 * CRH_HIT_CAP] = w.rd.z;
+								q[3 * CRH_HIT_CAP] = r.wr; q[4 * CRH_HIT_CAP] = r.wg; q[5 * CRH_HIT_CAP] = r.wb;
+								q[6 * CRH_HIT_CAP] = r.fr; q[7 * CRH_HIT_CAP] = r.fg; q[8 * CRH_HIT_CAP] = r.fb;
+								q[9 * CRH_HIT_CAP] = asF32(myItem); q[10 * CRH_HIT_CAP] = w.hit.t;
+							}
+							w.phase = PH_IDLE;
+						}
+						/* refill: idle lanes pop the top rays */
+						const bool idle = (w.phase == PH_IDLE);
+						const unsigned long long em = __ballot(idle);
+						const uint32_t er = laneRank(em);
+						const int take = min(raysQ, (int)__popcll(em));
+						if (idle && (int)er < take) {
+							v3 o, d;
+							PathRec r;
+							getRay(rayQ + (uint32_t)(raysQ - take) + er, CRH_RAY_CAP, o, d, r, myItem);
+							parkPath(stk, r);
+							walkBegin(S, w, stk, o, d, cnt);
+						}
+						if (lane == 0) { wq[WQ_HITS] = hitsQ + (int)__popcll(hm); wq[WQ_MISSES] = missQn + (int)__popcll(mm); wq[WQ_RAYS] = raysQ - take; }
+						__threadfence_block();
 						break;
+					}
+					case ST_GEN: {
+						const uint32_t item = nextItem + lane;
+						int x = 0, y = 0, pass = 0;
+						const bool valid = item < nItems && decodeItem(J, item, x, y, pass);
+						const unsigned long long vm = __ballot(valid);
+						if (valid) {
+							v3 o, d;
+							PathRec r;
+							beginPath(S, P, x, y, pass, o, d, r, cnt);
+							putRay(rayQ + ((uint32_t)raysQ + laneRank(vm)), CRH_RAY_CAP, o, d, r, item);
+						}
+						if (lane == 0) { wq[WQ_RAYS] = raysQ + (int)__popcll(vm); wq[WQ_NEXT_ITEM] = (int)(nextItem + 64u); }
+						__threadfence_block();
+						break;
+					}
+					case ST_MISS: {          /* pathtrace.c:39-42 for up to 64 rays that left the scene: background, then the sample is complete */
+						const int n = min(missQn, 64);
+						if ((int)lane < n) {
+							const float *q = missQ + (uint32_t)(missQn - n) + lane;
+							v3 o{0.0f, 0.0f, 0.0f}, d{q[0 * CRH_HIT_CAP], q[1 * CRH_HIT_CAP], q[2 * CRH_HIT_CAP]};
+							PathRec r;
+							r.wr = q[3 * CRH_HIT_CAP]; r.wg = q[4 * CRH_HIT_CAP]; r.wb = q[5 * CRH_HIT_CAP];
+							r.fr = q[6 * CRH_HIT_CAP]; r.fg = q[7 * CRH_HIT_CAP]; r.fb = q[8 * CRH_HIT_CAP];
+							r.rng.state = 0; r.depth = 0;
+							const uint32_t item = asU32(q[9 * CRH_HIT_CAP]);
+							TravHit h;
+							h.t = q[10 * CRH_HIT_CAP]; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
+							(void)shadeCore(S, P, o, d, h, r, cnt);
+							float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+						}
+						if (lane == 0) wq[WQ_MISSES] = missQn - n;
+						__threadfence_block();
+						break;
+					}
+					default: {   /* ST_SHADE: up to 64 surface hits */
+						const int n = min(hitsQ, 64);
+						bool cont = false;
+						v3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, 0.0f};
+						PathRec r;
+						uint32_t item = 0;
+						if ((int)lane < n) {
+							const float *q = hitQ + (uint32_t)(hitsQ - n) + lane;
+							getRay(q, CRH_HIT_CAP, o, d, r, item);
+							TravHit h;
+							h.t = q[16 * CRH_HIT_CAP]; h.u = q[17 * CRH_HIT_CAP]; h.v = q[18 * CRH_HIT_CAP];
+							h.slot = (int32_t)asU32(q[19 * CRH_HIT_CAP]); h.inst = (int32_t)asU32(q[20 * CRH_HIT_CAP]);
+							__builtin_assume(h.inst >= 0);
+							cont = shadeCore(S, P, o, d, h, r, cnt);
+							if (!cont) { float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb; }
+						}
+						const unsigned long long cm = __ballot(cont);
+						if (cont) putRay(rayQ + ((uint32_t)raysQ + laneRank(cm)), CRH_RAY_CAP, o, d, r, item);
+						if (lane == 0) { wq[WQ_HITS] = hitsQ - n; wq[WQ_RAYS] = raysQ + (int)__popcll(cm); }
+						__threadfence_block();
+						break;
+					}
 				}
 				if constexpr (LEVEL >= 2) {
 					if (lane == 0) {
 						const uint32_t dt = CRH_TICK() - tk;
 						cnt.w_round += 1;
-						if (pick == PH_NODE) { cnt.t_trav += dt; }
-						else if (pick == PH_TRI) { cnt.t_setup += dt; }
-						else if (pick == PH_CTRL) { cnt.w_ctrl += 1; cnt.w_setup += dt; }
-						else { cnt.w_shade += 1; cnt.t_shade += dt; cnt.u_shade += (uint32_t)nR; }
+						if (pick == ST_NODE) { cnt.t_trav += dt; }
+						else if (pick == ST_TRI) { cnt.t_setup += dt; }
+						else if (pick == ST_CTRL) { cnt.w_ctrl += 1; cnt.w_setup += dt; cnt.u_ctrl += (uint32_t)nC; }
+						else if (pick == ST_SWAP) { cnt.n_swap += 1; cnt.t_swap += dt; cnt.u_swap += (uint32_t)(nF + min(nE + nF, raysQ)); }
+						else if (pick == ST_GEN || pick == ST_MISS) { cnt.n_gen += 1; cnt.t_gen += dt; }
+						else { cnt.w_shade += 1; cnt.t_shade += dt; cnt.u_shade += (uint32_t)min(hitsQ, 64); }
 					}
 				}
 			}
+			(void)validItems;
 			__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
 			for (uint32_t pix = lane; pix < (uint32_t)(Q.bw * Q.bh); pix += 64u) foldBlockPixel(P, J, pix, myStage, fb);
 			__threadfence_block();                 /* ... and read before the next chunk overwrites them */
@@ -247,6 +405,13 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		v = waveSum(cnt.w_setup); if (lead && v) atomicAdd(&counters[16], (unsigned long long)v);
 		v = waveSum(cnt.u_node); if (lead && v) atomicAdd(&counters[17], (unsigned long long)v);
 		v = waveSum(cnt.u_shade); if (lead && v) atomicAdd(&counters[18], (unsigned long long)v);
+		v = waveSum(cnt.t_swap); if (lead && v) atomicAdd(&counters[19], (unsigned long long)v);
+		v = waveSum(cnt.t_gen); if (lead && v) atomicAdd(&counters[20], (unsigned long long)v);
+		v = waveSum(cnt.n_swap); if (lead && v) atomicAdd(&counters[21], (unsigned long long)v);
+		v = waveSum(cnt.n_gen); if (lead && v) atomicAdd(&counters[22], (unsigned long long)v);
+		v = waveSum(cnt.u_swap); if (lead && v) atomicAdd(&counters[23], (unsigned long long)v);
+		v = waveSum(cnt.u_tri); if (lead && v) atomicAdd(&counters[24], (unsigned long long)v);
+		v = waveSum(cnt.u_ctrl); if (lead && v) atomicAdd(&counters[25], (unsigned long long)v);
 	}
 }
 
@@ -279,6 +444,21 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 	}
 }
 
+/* bounces <= 0: pathTrace() returns black (pathtrace.c:36); only the running mean moves (renderer.c:288-291) */
+__global__ void k_fold_black(const crh_render_params P, const crh_tile *tiles, uint32_t ntiles, float *fb) {
+	for (uint32_t t = blockIdx.y; t < ntiles; t += gridDim.y) {
+		const crh_tile r = tiles[t];
+		const int w = r.x1 - r.x0, n = w * (r.y1 - r.y0);
+		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+			const int x = r.x0 + i % w, y = r.y0 + i / w;
+			float *out = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;
+			float a = out[0], b = out[1], c = out[2];
+			for (int k = 0; k < P.pass_count; ++k) foldSample(a, b, c, 0.0f, 0.0f, 0.0f, P.first_pass + k + 1);
+			out[0] = a; out[1] = b; out[2] = c;
+		}
+	}
+}
+
 /* color.h:60-84 + texture.c:18-22 */
 __global__ void k_to_srgb8(const float *fb, size_t n, uint8_t *out) {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -298,7 +478,9 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 80, 40, 0};
+	Sched sched = {70, 160, 80, 40, 24};
+	float *dQueues = nullptr;
+	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;
@@ -388,8 +570,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 		if (stream) c->stream = (hipStream_t)stream;
 		else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->ownStream = (e == hipSuccess); }
 	}
-	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, 24 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, 24 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, CRH_NCOUNTERS * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, CRH_NCOUNTERS * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
 	if (e != hipSuccess) {
 		const std::string msg = std::string("crh_context_create: ") + hipGetErrorString(e);
@@ -413,6 +595,7 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dCounters) (void)hipFree(c->dCounters);
 	if (c->dWork) (void)hipFree(c->dWork);
 	if (c->dStage) (void)hipFree(c->dStage);
+	if (c->dQueues) (void)hipFree(c->dQueues);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return CRH_OK;
@@ -437,6 +620,7 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_SCHED_WEIGHTS:   /* four 12-bit fields, low to high: node, tri, ctrl weights; lanes that must wait before shading / setup is served */
 			c->sched.wNode = (int)(value & 0xFFF); c->sched.wTri = (int)((value >> 12) & 0xFFF); c->sched.wCtrl = (int)((value >> 24) & 0xFFF);
 			c->sched.serveMin = (int)((value >> 36) & 0xFFF);
+			if ((value >> 48) & 0xFFF) c->sched.swapMin = (int)((value >> 48) & 0xFFF);
 			if (c->sched.wNode < 1 || c->sched.wTri < 1 || c->sched.wCtrl < 1 || c->sched.serveMin < 1 || c->sched.serveMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
 			return CRH_OK;
 		case CRH_OPT_UNITS_PER_WAVE:
@@ -595,6 +779,17 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		}
 	}
 
+	{
+		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_WAVE_QUEUE_FLOATS;
+		if (need > c->queueFloats) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (c->dQueues) HIP_TRY(hipFree(c->dQueues));
+			c->dQueues = nullptr; c->queueFloats = 0;
+			HIP_TRY(hipMalloc((void **)&c->dQueues, need * sizeof(float)));
+			c->queueFloats = need;
+		}
+	}
+
 	/* per-launch tile list in HBM (freed once the stream has drained) */
 	void *dTiles = nullptr;
 	const size_t tileBytes = tile_count * sizeof(crh_tile), startBytes = (tile_count + 1) * sizeof(uint32_t);
@@ -612,12 +807,18 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	Q.bw = bw; Q.bh = bh;
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
 
+	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */
+		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(tile_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, tile_count, dev_fb);
+		hipError_t e0 = hipGetLastError();
+		if (e0 != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_fold_black launch: ") + hipGetErrorString(e0));
+		return CRH_OK;
+	}
 	crh_ctx::Timed ev;
 	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
 #define CRH_LAUNCH(LEVEL, WPS, PROG) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
-												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched)
+												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true); else CRH_LAUNCH(LEVEL, WPS, false); } while (0)
 	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
 	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
@@ -723,7 +924,7 @@ int crh_counters_reset(crh_ctx *c) {
 	if (!c) return fail(CRH_ERR_INVALID, "crh_counters_reset: ctx is NULL");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
-	HIP_TRY(hipMemset(c->dCounters, 0, 24 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemset(c->dCounters, 0, CRH_NCOUNTERS * sizeof(unsigned long long)));
 	c->lastMs = 0.0f; c->totalMs = 0.0; c->launches = 0;
 	return CRH_OK;
 }
@@ -745,9 +946,9 @@ int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* 11 values: ticks {setup,
 	if (!c || !out3) return fail(CRH_ERR_INVALID, "crh_debug_phase_ticks: NULL argument");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
-	unsigned long long h[11];
+	unsigned long long h[CRH_NCOUNTERS - 8];
 	HIP_TRY(hipMemcpy(h, c->dCounters + 8, sizeof(h), hipMemcpyDeviceToHost));
-	for (int i = 0; i < 11; ++i) out3[i] = h[i];
+	for (int i = 0; i < CRH_NCOUNTERS - 8; ++i) out3[i] = h[i];
 	return CRH_OK;
 }
 

@@ -123,6 +123,7 @@ template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	uint32_t t_setup, t_trav, t_shade;   /* debug: wall-clock ticks (100 MHz) this wave spent per phase */
 	uint32_t w_node, w_tri, w_ctrl, w_round, w_shade, w_setup;   /* debug: WAVE-level step counts by kind (lane 0 counts) */
 	uint32_t u_node, u_shade;                                     /* debug: lanes served by the node / shade steps */
+	uint32_t t_swap, t_gen, n_swap, n_gen, u_swap, u_tri, u_ctrl;                /* debug: swap / gen step clocks, counts, lanes moved by swaps */
 };
 template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
 	static constexpr int level = 1;
@@ -765,7 +766,7 @@ struct TravHit {
 enum { PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT,
        PK_WR, PK_WG, PK_WB, PK_FR, PK_FG, PK_FB, PK_RNG0, PK_RNG1, PK_DEPTH, CRH_PARK_SLOTS };
 
-enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5 };
+enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6 };   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
 struct Walk {
 	uint32_t phase;
@@ -779,13 +780,27 @@ struct Walk {
 	TravHit hit;
 };
 
-/* after a step that left no pending prims: continue with the next pair, pop one, or hand over to CTRL */
-template <class Stack>
-CRH_DEV void walkAdvance(Walk &w, Stack &stk) {
+/* after a step that left no pending prims: continue with the next pair, pop one, leave the BLAS, or hand over (CTRL / SHADE) */
+template <class Stack, class Cnt>
+CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
 	if (w.pA != w.pAe) { w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
 	if (w.node != CRH_NONE) { w.phase = PH_NODE; return; }
-	w.phase = w.inBlas ? PH_CTRL : PH_SHADE;       /* BLAS exhausted -> leave it; TLAS exhausted -> the walk is over */
+	if (!w.inBlas) { w.phase = PH_SHADE; return; }                /* TLAS exhausted -> the walk is over */
+	/* BLAS exhausted -> back to the TLAS walk (instance.c:176-183): the world ray and the TLAS cursor come back from LDS.
+	 * Done here, at the end of whichever step emptied the BLAS, rather than as a step of its own: a leave is a dozen LDS
+	 * reads, far cheaper than a scheduling round at the occupancy such a step would get. */
+	if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
+	w.inBlas = 0; w.instFound = 0;
+	w.k.o = w.ro; w.k.d = w.rd;
+	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
+	w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
+	w.k.oct = stk.unpark(PK_OCT);
+	w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
+	w.spBase = 0;
+	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
+	if (w.node == CRH_NONE && w.sp > 0u) w.node = stk.pop(--w.sp);
+	w.phase = (w.node != CRH_NONE) ? PH_NODE : PH_SHADE;
 }
 
 template <class Stack, class Cnt>
@@ -805,7 +820,7 @@ CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v
 	} else {
 		w.node = S.tlas_root;
 	}
-	walkAdvance(w, stk);
+	walkAdvance(w, stk, cnt);
 }
 
 /* NODE: bvh.c:391-436 */
@@ -831,7 +846,7 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	const bool swap = tL > tR;
 	if (inL && inR) stk.push(w.sp++, swap ? fl : fr);
 	w.node = (inL && inR) ? (swap ? fr : fl) : (inL ? fl : (inR ? fr : CRH_NONE));
-	walkAdvance(w, stk);
+	walkAdvance(w, stk, cnt);
 }
 
 /* TRI: poly.c:17-53 on the prepared record (one triangle per step) */
@@ -851,23 +866,12 @@ CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 		const float t = vdot(n, c) * invDet;
 		if (t >= 0.0f && t < w.hit.t) { w.hit.t = t; w.hit.u = u; w.hit.v = v; w.hit.slot = (int32_t)slot; w.instFound = 1; }
 	}
-	walkAdvance(w, stk);
+	walkAdvance(w, stk, cnt);
 }
 
 /* CTRL: leave a finished BLAS (bvh.c:468-486 loop body tail) and / or visit the next instance of a TLAS leaf (bvh.c:472-484) */
 template <class Stack, class Cnt>
 CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
-	if (w.inBlas) {
-		if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
-		w.inBlas = 0; w.instFound = 0;
-		w.k.o = w.ro; w.k.d = w.rd;
-		w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
-		w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
-		w.k.oct = stk.unpark(PK_OCT);
-		w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
-		w.spBase = 0;
-		if (w.pA == w.pAe) { walkAdvance(w, stk); return; }
-	}
 	/* next instance */
 	const uint32_t slot = w.pA++;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
@@ -922,7 +926,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 			w.spBase = w.sp; w.inBlas = 1; w.instFound = 0; w.curInst = idx; w.k = ko;
 		}
 	}
-	walkAdvance(w, stk);
+	walkAdvance(w, stk, cnt);
 }
 
 /* The whole walk for one lane (k_trace_rays, host emulation): run steps until the walk hands over to shading. */
@@ -1021,102 +1025,120 @@ CRH_DEV void foldSample(float &r, float &g, float &b, float sr, float sg, float 
 
 struct Item { uint32_t next, cur; };    /* next item this lane will take / the item of the path in flight */
 
+/* What a path carries from bounce to bounce besides its ray (pathtrace.c:33-35 + the sampler). */
+struct PathRec { float wr, wg, wb; float fr, fg, fb; Rng rng; int depth; };
+
+/* Item index -> pixel / pass of a block chunk. Items are numbered pixel-major, so consecutive items are passes of
+ * the same pixel (coherent primary rays). Returns false for the padding items of a ragged tile edge. */
+CRH_DEV bool decodeItem(const BlockJob &J, uint32_t item, int &x, int &y, int &pass) {
+	const uint32_t pc = (uint32_t)J.passCount, bw = (uint32_t)J.bw;       /* bw is a power of two; pc usually is */
+	const bool pcPow2 = (pc & (pc - 1u)) == 0u;
+	const uint32_t pcShift = 31u - (uint32_t)__builtin_clz(pc | 1u), bwShift = 31u - (uint32_t)__builtin_clz(bw | 1u);
+	const uint32_t pix = pcPow2 ? (item >> pcShift) : (item / pc);
+	const int px = (int)(pix & (bw - 1u)), py = (int)(pix >> bwShift);
+	x = J.x0 + px; y = J.y0 + py;
+	pass = J.passBegin + (int)(pcPow2 ? (item & (pc - 1u)) : (item - pix * pc));
+	return px < J.w && py < J.h;
+}
+
+/* A new path: initSampler + getCameraRay (renderer.c:280-284). Needs P.bounces > 0. */
+template <class Cnt>
+CRH_DEV void beginPath(const DScene &S, const crh_render_params &P, int x, int y, int pass, v3 &ro, v3 &rd, PathRec &r, Cnt &cnt) {
+	CRH_COUNT1(cnt, paths, 1);
+	const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
+	initSampler(r.rng, pass, P.max_passes, pixIdx);                       /* :281 */
+	getCameraRay(S.camera, r.rng, x, y, ro, rd);                          /* :284 */
+	r.wr = r.wg = r.wb = 1.0f; r.fr = r.fg = r.fb = 0.0f; r.depth = 0;
+}
+
 /*
- * SETUP: the lane's next (pixel, pass) item of the block chunk, or PH_DONE. Items are numbered pixel-major and
- * lane l takes items l, l+stride, ...: the 64 lanes of a wave trace different passes of the same few pixels.
- * initSampler + getCameraRay (renderer.c:280-284), path state parked, walk started.
+ * One iteration of the pathTrace() loop body after getClosestIsect (pathtrace.c:39-57), on explicit records: the
+ * ray (ro, rd) and its closest hit go in; either the path continues (true: ro / rd are the next ray, r updated) or it
+ * is complete (false: r.fr/fg/fb is the sample).
  */
+template <class Cnt>
+CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &rd, const TravHit &hit, PathRec &r, Cnt &cnt) {
+	ShadeRec rec;
+	rec.dir = rd;
+	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */
+		rec.point = v3{0.0f, 0.0f, 0.0f}; rec.normal = v3{0.0f, 0.0f, 0.0f}; rec.uv = v2{0.0f, 0.0f};
+		rec.distance = hit.t; rec.ior = 0.0f;
+		const rgba bg = sampleBackground(S, rec, cnt);
+		r.fr = r.fr + (r.wr * bg.r); r.fg = r.fg + (r.wg * bg.g); r.fb = r.fb + (r.wb * bg.b);
+		return false;
+	}
+	const HitInfo h = finishHit(S, ro, rd, hit);
+	const crh_material mat = S.materials[h.material];
+	r.fr = r.fr + (r.wr * mat.emission[0]); r.fg = r.fg + (r.wg * mat.emission[1]); r.fb = r.fb + (r.wb * mat.emission[2]);   /* :44 */
+	rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = hit.t; rec.ior = mat.ior;
+	const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, r.rng, cnt);     /* :46 */
+	float probability = 1.0f;
+	if (r.depth >= 4) {                                                /* :51-55 */
+		probability = rmax(s.r, rmax(s.g, s.b));
+		if (getDimension(r.rng) > probability) return false;
+	}
+	const float ip = 1.0f / probability;                             /* :57 */
+	r.wr = (s.r * r.wr) * ip; r.wg = (s.g * r.wg) * ip; r.wb = (s.b * r.wb) * ip;
+	++r.depth;
+	if (r.depth >= P.bounces) return false;
+	ro = h.point; rd = s.out;                                        /* :47 */
+	return true;
+}
+
+template <class Stack>
+CRH_DEV void parkPath(Stack &stk, const PathRec &r) {
+	stk.park(PK_WR, asU32(r.wr)); stk.park(PK_WG, asU32(r.wg)); stk.park(PK_WB, asU32(r.wb));
+	stk.park(PK_FR, asU32(r.fr)); stk.park(PK_FG, asU32(r.fg)); stk.park(PK_FB, asU32(r.fb));
+	stk.park(PK_RNG0, (uint32_t)r.rng.state); stk.park(PK_RNG1, (uint32_t)(r.rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)r.depth);
+}
+template <class Stack>
+CRH_DEV PathRec unparkPath(Stack &stk) {
+	PathRec r;
+	r.wr = asF32(stk.unpark(PK_WR)); r.wg = asF32(stk.unpark(PK_WG)); r.wb = asF32(stk.unpark(PK_WB));
+	r.fr = asF32(stk.unpark(PK_FR)); r.fg = asF32(stk.unpark(PK_FG)); r.fb = asF32(stk.unpark(PK_FB));
+	r.rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32);
+	r.depth = (int)stk.unpark(PK_DEPTH);
+	return r;
+}
+
+/* SETUP / SHADE for a lane that owns its paths from start to end (host emulation): */
 template <class Stack, class Cnt>
 CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, Item &it,
 					   Stack &stk, float *stage, Cnt &cnt) {
-	const uint32_t pc = (uint32_t)J.passCount, bw = (uint32_t)J.bw;       /* bw is a power of two; pc usually is */
-	const uint32_t nItems = (uint32_t)(J.bw * J.bh) * pc;
-	const bool pcPow2 = (pc & (pc - 1u)) == 0u;
-	const uint32_t pcShift = 31u - (uint32_t)__builtin_clz(pc | 1u), bwShift = 31u - (uint32_t)__builtin_clz(bw | 1u);
+	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
 	for (;;) {
+		if (it.next >= nItems) { w.phase = PH_DONE; return; }
 		int x = 0, y = 0, pass = 0;
-		bool found = false;
-		while (it.next < nItems) {
-			const uint32_t pix = pcPow2 ? (it.next >> pcShift) : (it.next / pc);
-			const int px = (int)(pix & (bw - 1u)), py = (int)(pix >> bwShift);
-			if (px < J.w && py < J.h) {
-				x = J.x0 + px; y = J.y0 + py;
-				pass = J.passBegin + (int)(pcPow2 ? (it.next & (pc - 1u)) : (it.next - pix * pc));
-				found = true;
-				break;
-			}
-			it.next += laneStride;
-		}
-		if (!found) { w.phase = PH_DONE; return; }
+		const bool valid = decodeItem(J, it.next, x, y, pass);
 		it.cur = it.next;
 		it.next += laneStride;
-		CRH_COUNT1(cnt, paths, 1);
+		if (!valid) continue;
 		if (P.bounces <= 0) {                      /* pathTrace() with maxDepth 0 returns black */
+			CRH_COUNT1(cnt, paths, 1);
 			float *o = stage + (size_t)it.cur * 3;
 			o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
 			continue;
 		}
-		Rng rng;
-		const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
-		initSampler(rng, pass, P.max_passes, pixIdx);                         /* :281 */
+		PathRec r;
 		v3 ro, rd;
-		getCameraRay(S.camera, rng, x, y, ro, rd);                            /* :284 */
-		stk.park(PK_WR, asU32(1.0f)); stk.park(PK_WG, asU32(1.0f)); stk.park(PK_WB, asU32(1.0f));
-		stk.park(PK_FR, 0u); stk.park(PK_FG, 0u); stk.park(PK_FB, 0u);
-		stk.park(PK_RNG0, (uint32_t)rng.state); stk.park(PK_RNG1, (uint32_t)(rng.state >> 32)); stk.park(PK_DEPTH, 0u);
+		beginPath(S, P, x, y, pass, ro, rd, r, cnt);
+		parkPath(stk, r);
 		walkBegin(S, w, stk, ro, rd, cnt);
 		return;
 	}
 }
 
-/*
- * SHADE: one iteration of the pathTrace() loop body after getClosestIsect (pathtrace.c:39-57). Either the path goes
- * on (next ray, walk restarted) or its radiance is staged and the lane goes back to SETUP.
- */
 template <class Stack, class Cnt>
 CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, Item &it, Stack &stk, float *stage, Cnt &cnt) {
-	float wr = asF32(stk.unpark(PK_WR)), wg = asF32(stk.unpark(PK_WG)), wb = asF32(stk.unpark(PK_WB));
-	float fr = asF32(stk.unpark(PK_FR)), fg = asF32(stk.unpark(PK_FG)), fb = asF32(stk.unpark(PK_FB));
-	bool done;
-	ShadeRec rec;
-	rec.dir = w.rd;
-	if (w.hit.inst < 0) {                                            /* pathtrace.c:39-42 */
-		rec.point = v3{0.0f, 0.0f, 0.0f}; rec.normal = v3{0.0f, 0.0f, 0.0f}; rec.uv = v2{0.0f, 0.0f};
-		rec.distance = w.hit.t; rec.ior = 0.0f;
-		const rgba bg = sampleBackground(S, rec, cnt);
-		fr = fr + (wr * bg.r); fg = fg + (wg * bg.g); fb = fb + (wb * bg.b);
-		done = true;
-	} else {
-		Rng rng;
-		rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32);
-		int depth = (int)stk.unpark(PK_DEPTH);
-		const HitInfo h = finishHit(S, w.ro, w.rd, w.hit);
-		const crh_material mat = S.materials[h.material];
-		fr = fr + (wr * mat.emission[0]); fg = fg + (wg * mat.emission[1]); fb = fb + (wb * mat.emission[2]);   /* :44 */
-		rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = w.hit.t; rec.ior = mat.ior;
-		const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, rng, cnt);     /* :46 */
-		done = false;
-		float probability = 1.0f;
-		if (depth >= 4) {                                                /* :51-55 */
-			probability = rmax(s.r, rmax(s.g, s.b));
-			if (getDimension(rng) > probability) done = true;
-		}
-		if (!done) {
-			const float ip = 1.0f / probability;                         /* :57 */
-			wr = (s.r * wr) * ip; wg = (s.g * wg) * ip; wb = (s.b * wb) * ip;
-			++depth;
-			done = depth >= P.bounces;
-		}
-		if (!done) {
-			stk.park(PK_WR, asU32(wr)); stk.park(PK_WG, asU32(wg)); stk.park(PK_WB, asU32(wb));
-			stk.park(PK_FR, asU32(fr)); stk.park(PK_FG, asU32(fg)); stk.park(PK_FB, asU32(fb));
-			stk.park(PK_RNG0, (uint32_t)rng.state); stk.park(PK_RNG1, (uint32_t)(rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)depth);
-			walkBegin(S, w, stk, h.point, s.out, cnt);                   /* :47 */
-			return;
-		}
+	PathRec r = unparkPath(stk);
+	v3 ro = w.ro, rd = w.rd;
+	if (shadeCore(S, P, ro, rd, w.hit, r, cnt)) {
+		parkPath(stk, r);
+		walkBegin(S, w, stk, ro, rd, cnt);
+		return;
 	}
 	float *o = stage + (size_t)it.cur * 3;
-	o[0] = fr; o[1] = fg; o[2] = fb;
+	o[0] = r.fr; o[1] = r.fg; o[2] = r.fb;
 	w.phase = PH_SETUP;
 }
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""gpu_probe7.py — dev probe: per-step-kind clocks of the wave scheduler (counter level 2)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from __graft_entry__ import load_package, BUILT
+pkg = load_package(); api = pkg.api; abi = pkg.abi
+ctx = api.Context(0)
+ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("soup_1m", 2560, 1440, 16, 8)):
+    scene = api.Scene(os.path.join(BUILT, name + ".blob"))
+    ctx.upload(scene)
+    fb = ctx.framebuffer(w, h)
+    ctx.clear(fb, w, h); ctx.reset_counters()
+    ctx.render_region(fb, w, h, spp, b); ctx.synchronize()
+    ms = ctx.kernel_time_ms()[0]; c = ctx.counters(); t = ctx.phase_ticks()
+    rays = c["rays"]
+    print(f"{name}: {ms:.1f} ms {rays/ms/1e3:.0f} Mray/s  rays {rays} node_tests/ray {c['node_tests']/rays:.1f} tri/ray {c['tri_tests']/rays:.2f}")
+    tot = t["traverse"] + t["setup"] + t["w_setup"] + t["shade"] + t["t_swap"] + t["t_gen"]
+    def line(k, ticks, n, lanes=None):
+        s = f"  {k:6s} {100.0*ticks/max(tot,1):5.1f}% of step time, {n} steps, {ticks*10.0/max(n,1):8.1f} ns/step"
+        if lanes is not None: s += f", {lanes/max(n,1):5.1f} lanes/step"
+        print(s)
+    line("node", t["traverse"], t["w_node"], t["u_node"])
+    line("tri", t["setup"], t["w_tri"], t["u_tri"])
+    line("ctrl", t["w_setup"], t["w_ctrl"], t["u_ctrl"])
+    line("swap", t["t_swap"], t["n_swap"], t["u_swap"])
+    line("gen", t["t_gen"], t["n_gen"])
+    line("shade", t["shade"], t["w_shade"], t["u_shade"])
+    print(f"  rounds {t['w_round']}  steps per ray: node {t['u_node']/rays:.1f} lane-steps; node_tests/lane-step {c['node_tests']/max(t['u_node'],1):.2f}", flush=True)

@@ -850,11 +850,8 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 }
 
 /* TRI: poly.c:17-53 on the prepared record (one triangle per step) */
-template <class Stack, class Cnt>
-CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
-	const uint32_t slot = w.pA++;
-	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
-	const f4 q0 = S.tris[3u * slot], q1 = S.tris[3u * slot + 1u], q2 = S.tris[3u * slot + 2u];
+template <class Cnt>
+CRH_DEV void testTriangle(const f4 q0, const f4 q1, const f4 q2, uint32_t slot, Walk &w, Cnt &cnt) {
 	const v3 v0 = v3{q0.x, q0.y, q0.z}, e1 = v3{q0.w, q1.x, q1.y}, e2 = v3{q1.z, q1.w, q2.x}, n = v3{q2.y, q2.z, q2.w};
 	CRH_COUNT(cnt, tri_tests, 1);
 	const v3 c = vsub(v0, w.k.o);
@@ -866,6 +863,20 @@ CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 		const float t = vdot(n, c) * invDet;
 		if (t >= 0.0f && t < w.hit.t) { w.hit.t = t; w.hit.u = u; w.hit.v = v; w.hit.slot = (int32_t)slot; w.instFound = 1; }
 	}
+}
+/* One triangle step = the next TWO triangles of the pending leaf range when it holds two (in order, the second sees the
+ * first's hit distance: poly.c:17-36 via bvh.c:449-458); both records are requested before either is used. */
+template <class Stack, class Cnt>
+CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+	const uint32_t slot = w.pA;
+	const bool two = slot + 1u < w.pAe;
+	const uint32_t slot2 = two ? slot + 1u : slot;
+	const f4 a0 = S.tris[3u * slot], a1 = S.tris[3u * slot + 1u], a2 = S.tris[3u * slot + 2u];
+	const f4 b0 = S.tris[3u * slot2], b1 = S.tris[3u * slot2 + 1u], b2 = S.tris[3u * slot2 + 2u];
+	w.pA = slot2 + 1u;
+	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
+	testTriangle(a0, a1, a2, slot, w, cnt);
+	if (two) testTriangle(b0, b1, b2, slot2, w, cnt);
 	walkAdvance(w, stk, cnt);
 }
 

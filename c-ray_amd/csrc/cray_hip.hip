@@ -91,9 +91,8 @@ __device__ __forceinline__ const T *asGlobal(const T *p) {
 }
 __device__ __forceinline__ DScene globalize(const DScene &S) {
 	DScene G = S;
-	G.nodes = asGlobal(S.nodes); G.tris = asGlobal(S.tris); G.prims = asGlobal(S.prims); G.polys = asGlobal(S.polys);
-	G.vertices = asGlobal(S.vertices); G.normals = asGlobal(S.normals); G.texcoords = asGlobal(S.texcoords);
-	G.instances = asGlobal(S.instances); G.meshes = asGlobal(S.meshes); G.materials = asGlobal(S.materials);
+	G.nodes = asGlobal(S.nodes); G.tris = asGlobal(S.tris); G.prims = asGlobal(S.prims); G.shade = asGlobal(S.shade);
+	G.instances = asGlobal(S.instances); G.materials = asGlobal(S.materials);
 	G.bsdfs = asGlobal(S.bsdfs); G.consts = asGlobal(S.consts); G.images = asGlobal(S.images); G.prog = asGlobal(S.prog);
 	G.textures = asGlobal(S.textures); G.texels = asGlobal(S.texels);
 	return G;
@@ -430,12 +429,12 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 		traverse(S, stk, o, d, h, cnt);
 		crh_hit out;
 		memset(&out, 0, sizeof(out));
-		out.inst = h.inst; out.distance = h.t; out.node_tests = cnt.node_tests; out.tri_tests = cnt.tri_tests;
+		out.inst = h.inst < 0 ? -1 : (int32_t)S.instances[h.inst].orig; out.distance = h.t; out.node_tests = cnt.node_tests; out.tri_tests = cnt.tri_tests;
 		if (h.inst < 0) {
 			out.poly = -1; out.material = CRH_NODE_NONE;
 		} else {
 			const HitInfo hi = finishHit(S, o, d, h);
-			out.poly = hi.poly; out.uv[0] = hi.uv.x; out.uv[1] = hi.uv.y;
+			out.poly = hitPoly(S, h); out.uv[0] = hi.uv.x; out.uv[1] = hi.uv.y;
 			out.point[0] = hi.point.x; out.point[1] = hi.point.y; out.point[2] = hi.point.z;
 			out.normal[0] = hi.normal.x; out.normal[1] = hi.normal.y; out.normal[2] = hi.normal.z;
 			out.material = hi.material;
@@ -651,13 +650,9 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 #define UP(field, ptr, count) do { rc = upload(c, ptr, count, &d.field); if (rc) { freeScene(c); return rc; } } while (0)
 	UP(nodes, cs.nodes.data(), cs.nodes.size());
 	UP(tris, cs.tris.data(), cs.tris.size());
+	UP(shade, cs.shade.data(), cs.shade.size());
 	UP(prims, scene->prim_indices, (size_t)scene->prim_index_count);
-	UP(polys, scene->polys, (size_t)scene->poly_count);
-	UP(vertices, scene->vertices, (size_t)scene->vertex_count * 3);
-	UP(normals, scene->normals, (size_t)scene->normal_count * 3);
-	UP(texcoords, scene->texcoords, (size_t)scene->texcoord_count * 2);
 	UP(instances, cs.instances.data(), cs.instances.size());
-	UP(meshes, scene->meshes, (size_t)scene->mesh_count);
 	UP(materials, scene->materials, (size_t)scene->material_count);
 	UP(bsdfs, cs.bsdfs.data(), cs.bsdfs.size());
 	UP(consts, cs.consts.data(), cs.consts.size());

@@ -37,18 +37,35 @@ struct rgba { float r, g, b, a; };
 
 /* ---- device-side scene ----------------------------------------------------------------------- */
 
-/* One instance visit reads exactly this 128-B record (N_instVisit). */
+/* One instance visit (stepCtrl) reads the first 64-B line of this record, finishing a hit both (N_instVisit,
+ * N_instHit). instances[] is in TLAS leaf order: the record of TLAS prim slot s is instances[s - tlas_prim_base], so a
+ * TLAS leaf is walked without the prim-index indirection; `orig` is the reference's instance index (reported by
+ * crh_trace_rays). */
+#define CRH_DINST_SPHERE     0u
+#define CRH_DINST_MESH       1u   /* BLAS with an inner root: root = device index of the root's child pair */
+#define CRH_DINST_MESH_LEAF  2u   /* bvh->nodeCount == 1: root = device index of the root leaf (bvh.c:382-387) */
+#define CRH_DINST_MESH_EMPTY 3u   /* bvh->nodeCount == 0 (bvh.c:362-365) */
 struct alignas(16) DInstance {
 	float Ainv[12];
+	uint32_t kind;        /* CRH_DINST_* */
+	uint32_t root;
+	float    ray_offset;  /* mesh->rayOffset / sphere->rayOffset */
+	float    radius;      /* sphere */
 	float A[12];
-	uint32_t kind;        /* CRH_INSTANCE_* */
-	uint32_t object;      /* mesh / sphere index */
-	uint32_t root;        /* mesh: device index of the BLAS root's child pair (or of the root leaf if node_count == 1) */
-	uint32_t node_count;  /* mesh: bvh->nodeCount                                            */
-	float    ray_offset;  /* mesh->rayOffset / sphere->rayOffset                             */
-	float    radius;      /* sphere                                                          */
-	uint32_t material;    /* sphere: material index; mesh: material_base                     */
-	uint32_t poly_base;   /* mesh: first polygon in polys[]                                  */
+	uint32_t orig;        /* index in crh_scene_desc.instances */
+	uint32_t poly_base;   /* mesh: first polygon in polys[] (crh_trace_rays reports polygon indices) */
+	uint32_t material;    /* sphere: material index; mesh: material_base */
+	uint32_t pad;
+};
+
+/* Per BLAS prim slot, next to tris[]: what finishing a hit on that triangle needs, so that poly.c:37-48 + instance.c:150-167
+ * read ONE 64-B record instead of prim index -> polygon -> three normals / three texture coordinates -> mesh. */
+#define CRH_SHADE_HASNORMALS 0x80000000u   /* n0..n2 are the vertex normals; otherwise n0 = e1 x e2 (poly.c:45-47) */
+#define CRH_SHADE_HASUV      0x40000000u   /* mesh has texture coordinates and the polygon references them (instance.c:152) */
+struct alignas(16) DShadeTri {
+	float n0[3], n1[3], n2[3];
+	float t0[2], t1[2], t2[2];
+	uint32_t flags;       /* CRH_SHADE_* | polygon materialIndex */
 };
 
 /* pure-node operand reference (compiled at upload, see scene_compile.cpp: operand()).
@@ -92,11 +109,9 @@ struct alignas(16) DBsdf { uint32_t kind, a, b, c; };
 struct DScene {
 	const f4 *nodes;            /* 2 x f4 per node; node i of a BVH lives at device index base+1+i (child pairs 64-B aligned) */
 	const f4 *tris;             /* 3 x f4 per BLAS prim slot: v0, e1, e2, n (poly.c:20-22 precomputed with the same fp32 ops) */
-	const int32_t *prims;       /* prim_indices verbatim: TLAS slots -> instance index, BLAS slots -> polygon index in mesh */
-	const crh_poly *polys;
-	const float *vertices, *normals, *texcoords;
-	const DInstance *instances;
-	const crh_mesh *meshes;
+	const DShadeTri *shade;     /* per BLAS prim slot */
+	const int32_t *prims;       /* prim_indices verbatim (BLAS slots -> polygon index in mesh): only crh_trace_rays reads it */
+	const DInstance *instances; /* TLAS leaf order */
 	const crh_material *materials;
 	const DBsdf *bsdfs;         /* indexed by gnode index (only bsdf-kind entries are meaningful) */
 	const f4 *consts;
@@ -886,14 +901,15 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	/* next instance */
 	const uint32_t slot = w.pA++;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
-	const int32_t idx = S.prims[slot];       /* leaf.first is already an absolute prim slot */
+	const int32_t idx = (int32_t)(slot - S.tlas_prim_base);   /* leaf.first is an absolute prim slot; instances[] is in slot order */
 	const DInstance *inst = &S.instances[idx];
 	CRH_COUNT(cnt, inst_visits, 1);
 	/* transformRay(Ainv) + offset: instance.c:46-50 / 170-174 */
 	v3 o = xfPoint(w.k.o, inst->Ainv);
 	const v3 d = xfVector(w.k.d, inst->Ainv);
 	o = vadd(o, vscale(d, inst->ray_offset));
-	if (inst->kind == CRH_INSTANCE_SPHERE) {
+	const uint32_t kind = inst->kind;
+	if (kind == CRH_DINST_SPHERE) {
 		/* sphere.c:20-50 */
 		CRH_COUNT(cnt, sphere_tests, 1);
 		const float A = vdot(d, d);
@@ -910,7 +926,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 				CRH_COUNT(cnt, inst_hits, 1);
 			}
 		}
-	} else if (inst->node_count < 1u) {
+	} else if (kind == CRH_DINST_MESH_EMPTY) {
 		w.hit.inst = -1;                                                     /* bvh.c:362-365 via instance.c:175 */
 	} else if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) {
 		/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
@@ -919,7 +935,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 		const RayK ko = makeRayK(o, d);
 		bool enter = true;
 		uint32_t rootA = 0, rootAe = 0;
-		if (inst->node_count == 1u) {                                      /* bvh.c:382-387 */
+		if (kind == CRH_DINST_MESH_LEAF) {                                 /* bvh.c:382-387 */
 			const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
 			float tE;
 			CRH_COUNT(cnt, node_tests, 1);
@@ -931,7 +947,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
 			stk.park(PK_SX, asU32(w.k.ss.x)); stk.park(PK_SY, asU32(w.k.ss.y)); stk.park(PK_SZ, asU32(w.k.ss.z));
 			stk.park(PK_OCT, w.k.oct);
-			if (inst->node_count == 1u) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
+			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
 			else { w.node = inst->root; w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;
 			w.spBase = w.sp; w.inBlas = 1; w.instFound = 0; w.curInst = idx; w.k = ko;
@@ -958,8 +974,12 @@ struct HitInfo {
 	v3 point, normal;
 	v2 uv;
 	uint32_t material;
-	int32_t poly;       /* index into polys[], -1 for spheres */
 };
+/* polygon index (into crh_scene_desc.polys) of a finished hit, -1 for spheres: reported by crh_trace_rays only */
+CRH_DEV int32_t hitPoly(const DScene &S, const TravHit &hit) {
+	const DInstance *inst = &S.instances[hit.inst];
+	return inst->kind == CRH_DINST_SPHERE ? -1 : (int32_t)inst->poly_base + S.prims[hit.slot];
+}
 CRH_DEV v3 loadV3(const float *base, int64_t i) { const float *p = base + 3 * i; return v3{p[0], p[1], p[2]}; }
 CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravHit &hit) {
 	HitInfo h;
@@ -968,7 +988,7 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 	const v3 d = xfVector(wd, inst->Ainv);
 	o = vadd(o, vscale(d, inst->ray_offset));
 	const v3 objPoint = alongRay(o, d, hit.t);
-	if (inst->kind == CRH_INSTANCE_SPHERE) {
+	if (inst->kind == CRH_DINST_SPHERE) {
 		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
 		/* getTexMapSphere: instance.c:33-43 (object-space normal) */
 		float phi = atan2f(n.z, n.x);
@@ -978,39 +998,29 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 		u = wrap01(u);
 		v = wrap01(v);
 		h.uv = v2{u, v};
-		h.poly = -1;
 		h.material = inst->material;
 		h.point = xfPoint(objPoint, inst->A);
 		h.normal = xfVectorT(n, inst->Ainv);                      /* not renormalised: instance.c:56 */
 		return h;
 	}
-	const int32_t p = (int32_t)inst->poly_base + S.prims[hit.slot];
-	const crh_poly poly = S.polys[p];
+	const DShadeTri *st = &S.shade[hit.slot];
+	const uint32_t flags = st->flags;
 	const float u = hit.u, v = hit.v;
 	const float w = 1.0f - u - v;
-	v3 n;
-	if (CRH_POLY_HASNORMALS(poly)) {                              /* poly.c:40-44 */
-		const v3 upcomp = vscale(loadV3(S.normals, poly.n[1]), u);
-		const v3 vpcomp = vscale(loadV3(S.normals, poly.n[2]), v);
-		const v3 wpcomp = vscale(loadV3(S.normals, poly.n[0]), w);
+	v3 n = v3{st->n0[0], st->n0[1], st->n0[2]};                   /* poly.c:45-47: un-normalised e1 x e2 */
+	if (flags & CRH_SHADE_HASNORMALS) {                           /* poly.c:40-44 */
+		const v3 upcomp = vscale(v3{st->n1[0], st->n1[1], st->n1[2]}, u);
+		const v3 vpcomp = vscale(v3{st->n2[0], st->n2[1], st->n2[2]}, v);
+		const v3 wpcomp = vscale(n, w);
 		n = vadd(vadd(upcomp, vpcomp), wpcomp);
-	} else {                                                      /* poly.c:45-47: un-normalised e1 x e2 */
-		const f4 q2 = S.tris[3u * (uint32_t)hit.slot + 2u];
-		n = v3{q2.y, q2.z, q2.w};
 	}
 	/* getTexMapMesh: instance.c:150-167 */
-	const crh_mesh *mesh = &S.meshes[inst->object];
-	if (mesh->texcoord_count == 0u || poly.t[0] == -1) {
+	if (!(flags & CRH_SHADE_HASUV)) {
 		h.uv = v2{-1.0f, -1.0f};
 	} else {
-		const float *T = S.texcoords;
-		const v2 t1 = v2{T[2 * (int64_t)poly.t[1]], T[2 * (int64_t)poly.t[1] + 1]};
-		const v2 t2 = v2{T[2 * (int64_t)poly.t[2]], T[2 * (int64_t)poly.t[2] + 1]};
-		const v2 t0 = v2{T[2 * (int64_t)poly.t[0]], T[2 * (int64_t)poly.t[0] + 1]};
-		h.uv = v2{((t1.x * u) + (t2.x * v)) + (t0.x * w), ((t1.y * u) + (t2.y * v)) + (t0.y * w)};
+		h.uv = v2{((st->t1[0] * u) + (st->t2[0] * v)) + (st->t0[0] * w), ((st->t1[1] * u) + (st->t2[1] * v)) + (st->t0[1] * w)};
 	}
-	h.poly = p;
-	h.material = inst->material + CRH_POLY_MATERIAL(poly);
+	h.material = inst->material + (flags & 0x3FFFFFFFu);
 	h.point = xfPoint(objPoint, inst->A);
 	h.normal = vnorm(xfVectorT(n, inst->Ainv));                   /* instance.c:180-181 */
 	return h;

@@ -312,6 +312,7 @@ struct Compiler {
 
 		/* BLAS per mesh, prepared triangles */
 		out.tris.assign((size_t)std::max<uint64_t>(s->prim_index_count, 1) * 3, f4{0, 0, 0, 0});
+		{ DShadeTri z; memset(&z, 0, sizeof(z)); out.shade.assign((size_t)std::max<uint64_t>(s->prim_index_count, 1), z); }
 		std::vector<BvhInfo> meshBvh(s->mesh_count);
 		uint32_t maxBlasDepth = 0;
 		for (uint64_t m = 0; m < s->mesh_count; ++m) {
@@ -342,6 +343,20 @@ struct Compiler {
 				q[0] = f4{v0.x, v0.y, v0.z, e1.x};
 				q[1] = f4{e1.y, e1.z, e2.x, e2.y};
 				q[2] = f4{e2.z, n.x, n.y, n.z};
+				DShadeTri &st = out.shade[(size_t)mesh.prim_base + k];
+				st.flags = CRH_POLY_MATERIAL(p);
+				if (CRH_POLY_HASNORMALS(p)) {
+					st.flags |= CRH_SHADE_HASNORMALS;
+					const float *N = s->normals;
+					for (int c = 0; c < 3; ++c) { st.n0[c] = N[3 * (size_t)p.n[0] + c]; st.n1[c] = N[3 * (size_t)p.n[1] + c]; st.n2[c] = N[3 * (size_t)p.n[2] + c]; }
+				} else {
+					st.n0[0] = n.x; st.n0[1] = n.y; st.n0[2] = n.z;
+				}
+				if (mesh.texcoord_count && p.t[0] != -1) {
+					st.flags |= CRH_SHADE_HASUV;
+					const float *T = s->texcoords;
+					for (int c = 0; c < 2; ++c) { st.t0[c] = T[2 * (size_t)p.t[0] + c]; st.t1[c] = T[2 * (size_t)p.t[1] + c]; st.t2[c] = T[2 * (size_t)p.t[2] + c]; }
+				}
 			}
 		}
 
@@ -357,32 +372,42 @@ struct Compiler {
 		}
 		out.max_stack = tlas.depth + CRH_TLAS_SAVE + maxBlasDepth + 1;
 
-		out.instances.resize(std::max<uint64_t>(s->instance_count, 1));
-		for (uint64_t i = 0; i < s->instance_count; ++i) {
+		/* instances in TLAS leaf order: the TLAS prim indices are a permutation of the instances (bvh.c:289-316) */
+		{ DInstance z; memset(&z, 0, sizeof(z)); z.kind = CRH_DINST_MESH_EMPTY; out.instances.assign(std::max<uint64_t>(s->tlas_prim_count, 1), z); }
+		std::vector<uint8_t> seen(s->instance_count, 0);
+		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {
+			const uint32_t i = (uint32_t)s->prim_indices[s->tlas_prim_base + k];
+			CHECK(!seen[i], CRH_ERR_INVALID, "TLAS references instance %u twice", i);
+			seen[i] = 1;
 			const crh_instance &in = s->instances[i];
 			DInstance d;
 			memset(&d, 0, sizeof(d));
 			memcpy(d.Ainv, in.Ainv, sizeof(d.Ainv));
 			memcpy(d.A, in.A, sizeof(d.A));
-			d.kind = in.kind;
-			d.object = in.object;
+			d.orig = i;
 			if (in.kind == CRH_INSTANCE_SPHERE) {
-				CHECK(in.object < s->sphere_count, CRH_ERR_INVALID, "instance %llu: sphere index out of range", (unsigned long long)i);
+				CHECK(in.object < s->sphere_count, CRH_ERR_INVALID, "instance %u: sphere index out of range", i);
 				const crh_sphere &sp = s->spheres[in.object];
 				CHECK(sp.material < s->material_count, CRH_ERR_INVALID, "sphere %u: material out of range", in.object);
+				d.kind = CRH_DINST_SPHERE;
 				d.radius = sp.radius; d.ray_offset = sp.ray_offset; d.material = sp.material;
 			} else if (in.kind == CRH_INSTANCE_MESH) {
-				CHECK(in.object < s->mesh_count, CRH_ERR_INVALID, "instance %llu: mesh index out of range", (unsigned long long)i);
+				CHECK(in.object < s->mesh_count, CRH_ERR_INVALID, "instance %u: mesh index out of range", i);
 				const crh_mesh &mesh = s->meshes[in.object];
+				d.kind = mesh.node_count > 1 ? CRH_DINST_MESH : mesh.node_count == 1 ? CRH_DINST_MESH_LEAF : CRH_DINST_MESH_EMPTY;
 				d.root = meshBvh[in.object].root;
-				d.node_count = mesh.node_count;
 				d.ray_offset = mesh.ray_offset;
 				d.material = mesh.material_base;
 				d.poly_base = mesh.poly_base;
 			} else {
 				throw Fail{CRH_ERR_UNSUPPORTED, "instance kind " + std::to_string(in.kind) + " (volumes) is not supported"};
 			}
-			out.instances[i] = d;
+			out.instances[k] = d;
+		}
+		for (uint64_t i = 0; i < s->instance_count; ++i) {           /* instances outside the TLAS (none with the reference's builder) are still validated */
+			const crh_instance &in = s->instances[i];
+			CHECK(in.kind == CRH_INSTANCE_SPHERE || in.kind == CRH_INSTANCE_MESH, CRH_ERR_UNSUPPORTED, "instance kind %u (volumes) is not supported", in.kind);
+			CHECK(in.kind == CRH_INSTANCE_SPHERE ? in.object < s->sphere_count : in.object < s->mesh_count, CRH_ERR_INVALID, "instance %llu: object index out of range", (unsigned long long)i);
 		}
 		if (out.nodes.empty()) out.nodes.resize(4, f4{0, 0, 0, 0});
 	}

@@ -13,6 +13,9 @@
  *   tris    per BLAS prim slot (leaf order) the prepared triangle v0, e1 = v0-v1, e2 = v2-v0, n = e1 x e2
  *           (poly.c:20-22, same fp32 operations, this TU is built with -ffp-contract=off): 48 B instead of
  *           4 B index + 40 B poly + 3 x 12 B scattered vertices.
+ *   shade   per BLAS prim slot the 64-B record finishing a hit needs (vertex normals or e1 x e2, texture coordinates,
+ *           material index): one load instead of prim index -> polygon -> normals / texcoords -> mesh.
+ *   instances   in TLAS leaf order (slot - tlas_prim_base indexes them directly), enter data in the first 64-B line.
  *   textures / texels   every texture expanded to f4 texels (see DTexture).
  *   bsdfs / consts / images / prog   the node graph: bsdf nodes 1:1, colour/value/vector sub-graphs
  *           compiled to constants, image fetches or short postfix programs (pure functions of the hit).
@@ -27,6 +30,7 @@ namespace crh {
 struct CompiledScene {
 	std::vector<f4> nodes;
 	std::vector<f4> tris;
+	std::vector<DShadeTri> shade;
 	std::vector<DInstance> instances;
 	std::vector<DBsdf> bsdfs;
 	std::vector<f4> consts;

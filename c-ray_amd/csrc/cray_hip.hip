@@ -34,7 +34,7 @@ using namespace crh;
 /* ---- tunables ---------------------------------------------------------------------------------- */
 #define CRH_BLOCK 256            /* 4 waves of 64 */
 #ifndef CRH_STACK_LDS
-#define CRH_STACK_LDS 23         /* traversal stack entries kept in LDS per lane; with the 16 park slots + queue cursors: < 40 KB per block, 4 blocks per CU */
+#define CRH_STACK_LDS 23         /* traversal stack entries kept in LDS per lane; with the 13 park slots, the id stacks and cursors: < 40 KB per block, 4 blocks per CU */
 #endif
 
 /* ---- error plumbing ---------------------------------------------------------------------------- */
@@ -108,30 +108,24 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
 struct Sched { int wNode, wTri, wCtrl, serveMin, swapMin; };
 
-/* Per-wave work stacks in global memory (field-major: field f of slot s at [f * CAP + s]). They are LIFO so that the
- * hot part is only as deep as the live backlog (tens of records): it stays in L2 instead of cycling through a ring. */
-#define CRH_RAY_CAP 256u     /* < 64 waiting + 64 from GEN + 64 from SHADE */
-#define CRH_HIT_CAP 128u     /* < 64 waiting + 64 retired by one SWAP */
-#define CRH_RAY_FIELDS 16    /* o, d, weight, radiance, rng (2), depth, item */
-#define CRH_HIT_FIELDS 21    /* ray record + t, u, v, slot, inst */
-#define CRH_MISS_FIELDS 11   /* d, weight, radiance, item, t */
-#define CRH_WAVE_QUEUE_FLOATS (CRH_RAY_FIELDS * CRH_RAY_CAP + (CRH_HIT_FIELDS + CRH_MISS_FIELDS) * CRH_HIT_CAP)
+/* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
+ * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
+ * slot id (LDS). Record = 8 x f4: {o, depth} {d, item} {weight, rng.lo} {radiance, rng.hi} {t, u, v, slot} {inst, -, -, -} - - */
+#define CRH_PATHS 256u        /* slots per wave = the most paths a wave keeps in flight */
+#define CRH_PATH_F4 8u
+#define CRH_WAVE_QUEUE_FLOATS (CRH_PATHS * CRH_PATH_F4 * 4u)
+/* id stacks (bytes, LDS): rays waiting for a walker, surface hits / misses waiting for shading, free slots */
+#define CRH_IDS_RAYS 0u
+#define CRH_IDS_HITS 256u      /* < 64 waiting + 64 retired by one SWAP */
+#define CRH_IDS_MISSES 384u
+#define CRH_IDS_FREE 512u
+#define CRH_IDS_BYTES 768u
 
-__device__ __forceinline__ void putRay(float *q, uint32_t cap, const v3 &o, const v3 &d, const PathRec &r, uint32_t item) {
-	q[0 * cap] = o.x; q[1 * cap] = o.y; q[2 * cap] = o.z;
-	q[3 * cap] = d.x; q[4 * cap] = d.y; q[5 * cap] = d.z;
-	q[6 * cap] = r.wr; q[7 * cap] = r.wg; q[8 * cap] = r.wb;
-	q[9 * cap] = r.fr; q[10 * cap] = r.fg; q[11 * cap] = r.fb;
-	q[12 * cap] = asF32((uint32_t)r.rng.state); q[13 * cap] = asF32((uint32_t)(r.rng.state >> 32));
-	q[14 * cap] = asF32((uint32_t)r.depth); q[15 * cap] = asF32(item);
-}
-__device__ __forceinline__ void getRay(const float *q, uint32_t cap, v3 &o, v3 &d, PathRec &r, uint32_t &item) {
-	o = v3{q[0 * cap], q[1 * cap], q[2 * cap]}; d = v3{q[3 * cap], q[4 * cap], q[5 * cap]};
-	r.wr = q[6 * cap]; r.wg = q[7 * cap]; r.wb = q[8 * cap];
-	r.fr = q[9 * cap]; r.fg = q[10 * cap]; r.fb = q[11 * cap];
-	r.rng.state = (uint64_t)asU32(q[12 * cap]) | ((uint64_t)asU32(q[13 * cap]) << 32);
-	r.depth = (int)asU32(q[14 * cap]);
-	item = asU32(q[15 * cap]);
+__device__ __forceinline__ void putPathRay(f4 *q, const v3 &o, const v3 &d, const PathRec &r, uint32_t item) {
+	q[0] = f4{o.x, o.y, o.z, asF32((uint32_t)r.depth)};
+	q[1] = f4{d.x, d.y, d.z, asF32(item)};
+	q[2] = f4{r.wr, r.wg, r.wb, asF32((uint32_t)r.rng.state)};
+	q[3] = f4{r.fr, r.fg, r.fb, asF32((uint32_t)(r.rng.state >> 32))};
 }
 
 /* rank of this lane among the set bits of a ballot mask below it */
@@ -149,6 +143,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) <= 40960, "4 blocks per CU share 160 KB of LDS");
 	const DScene S = globalize(Sarg);
 	const unsigned long long tStart = wall_clock64();
 	uint32_t unitsDone = 0;
@@ -161,16 +156,17 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
 	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
 	const int passEnd = P.first_pass + P.pass_count;
-	/* per-wave work stacks and their wave-uniform fill levels in LDS (lane 0 writes, every lane reads: as plain
-	 * variables they would be scalar registers live across the whole machine, and the register allocator is past its
-	 * limits there — measured slower, and wrong images in the variant that calls runProgram) */
-	float *const rayQ = queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS;
-	float *const hitQ = rayQ + (size_t)CRH_RAY_FIELDS * CRH_RAY_CAP;
-	float *const missQ = hitQ + (size_t)CRH_HIT_FIELDS * CRH_HIT_CAP;
-	enum { WQ_RAYS, WQ_HITS, WQ_MISSES, WQ_NEXT_ITEM, WQ_WORDS };
+	/* the wave's path table, its id stacks and their wave-uniform fill levels (LDS: lane 0 writes, every lane reads; as
+	 * plain variables they would be scalar registers live across the whole machine, and the register allocator is past
+	 * its limits there — measured slower, and wrong images in the variant that calls runProgram) */
+	f4 *const ptab = (f4 *)(queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS);
+	enum { WQ_RAYS, WQ_HITS, WQ_MISSES, WQ_FREE, WQ_NEXT_ITEM, WQ_WORDS };
 	__shared__ int s_wq[(CRH_BLOCK / 64) * WQ_WORDS];
+	__shared__ uint8_t s_ids[(CRH_BLOCK / 64) * CRH_IDS_BYTES];
 	typedef volatile __attribute__((address_space(3))) int lds_int;
+	typedef volatile __attribute__((address_space(3))) uint8_t lds_u8;
 	lds_int *const wq = (lds_int *)&s_wq[(threadIdx.x >> 6) * WQ_WORDS];
+	lds_u8 *const ids = (lds_u8 *)&s_ids[(threadIdx.x >> 6) * CRH_IDS_BYTES];
 	for (;;) {
 		uint32_t unit = 0;
 		if (lane == 0) unit = atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
@@ -195,39 +191,42 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 			const uint32_t validItems = (uint32_t)(J.w * J.h * J.passCount);
 			/*
 			 * ---- the wave as a small wavefront machine -----------------------------------------------------------------
-			 * Paths are decoupled from lanes. Two per-wave ring queues in global memory (L2-resident) hold RAYS waiting
-			 * for a walk and HITS waiting for shading, each record carrying its path state (weight, radiance, RNG, depth,
-			 * item). Lanes are workers: every iteration the wave ballots what its lanes need and runs ONE kind of step:
+			 * Paths are decoupled from lanes. A path's state (ray, weight, radiance, RNG, depth, item, last hit) lives in
+			 * one slot of the wave's path table (global memory, cache-resident); three LDS byte stacks hold the slot ids of
+			 * RAYS waiting for a walker, surface HITS and MISSES waiting for shading, a fourth the free slots. Lanes are
+			 * workers: every iteration the wave ballots what its lanes need and runs ONE kind of step:
 			 *   NODE / TRI / CTRL  walk steps (state machine of pt_device.h), picked by lanes x weight;
-			 *   SWAP   lanes whose walk ended append their hit (compacted with ballot + mbcnt) and, together with idle
-			 *          lanes, take the next rays from the ray queue — a cheap step, so walkers are refilled early and
-			 *          never wait for their own shading;
-			 *   GEN    all 64 lanes start the next 64 items (initSampler + getCameraRay) into the ray queue;
-			 *   SHADE  all 64 lanes shade 64 queued hits (finishHit, emission, bsdf sample, roulette / background):
-			 *          continuing paths are appended to the ray queue, finished samples staged.
-			 * The expensive steps therefore always run at (close to) full occupancy and the walk steps always have rays.
-			 * Each path's own sequence of operations — hence every result — is independent of the schedule.
+			 *   SWAP   lanes whose walk ended write the hit into their path's slot and push its id (compacted with
+			 *          ballot + mbcnt); they and the idle lanes pop ray ids and start those walks (6 words each);
+			 *   GEN    all 64 lanes start the next 64 items (initSampler + getCameraRay) in free slots;
+			 *   SHADE  all 64 lanes shade 64 surface hits (finishHit, emission, bsdf sample, roulette): continuing paths
+			 *          are updated in place and their ids pushed on the ray stack, finished samples staged;
+			 *   MISS   all 64 lanes evaluate the background for 64 rays that left the scene (always the end of a path).
+			 * The expensive steps therefore run at (close to) full occupancy, without the divergence between surface and
+			 * background code, and the walk steps always have rays. Each path's own sequence of operations — hence
+			 * every result — is independent of the schedule.
 			 */
-			if (lane == 0) { wq[WQ_RAYS] = 0; wq[WQ_HITS] = 0; wq[WQ_MISSES] = 0; wq[WQ_NEXT_ITEM] = 0; }
+			if (lane == 0) { wq[WQ_RAYS] = 0; wq[WQ_HITS] = 0; wq[WQ_MISSES] = 0; wq[WQ_FREE] = (int)CRH_PATHS; wq[WQ_NEXT_ITEM] = 0; }
+			for (uint32_t i = lane; i < CRH_PATHS; i += 64u) ids[CRH_IDS_FREE + i] = (uint8_t)i;
 			Walk w;
 			memset(&w, 0, sizeof(w));
 			w.phase = PH_IDLE;
-			uint32_t myItem = 0;
+			uint32_t myPath = 0;
 			for (;;) {
 				const uint32_t ph = w.phase;
 				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL));
 				const int nF = __popcll(__ballot(ph == PH_SHADE));           /* walks that ended, result not yet queued */
 				const int nE = 64 - nN - nT - nC - nF;                        /* idle lanes */
-				const int raysQ = wq[WQ_RAYS], hitsQ = wq[WQ_HITS], missQn = wq[WQ_MISSES];
+				const int raysQ = wq[WQ_RAYS], hitsQ = wq[WQ_HITS], missQn = wq[WQ_MISSES], freeQ = wq[WQ_FREE];
 				const uint32_t nextItem = (uint32_t)wq[WQ_NEXT_ITEM];
-				const bool itemsLeft = nextItem < nItems;
+				const bool canGen = nextItem < nItems && freeQ >= 64;
 				const int walkers = nN + nT + nC;
 				enum { ST_NODE, ST_TRI, ST_CTRL, ST_SWAP, ST_GEN, ST_SHADE, ST_MISS, ST_END };
 				int pick;
 				if (hitsQ >= 64) pick = ST_SHADE;
 				else if (missQn >= 64) pick = ST_MISS;
 				else if (nF + nE >= K.swapMin && (nF > 0 || (nE > 0 && raysQ > 0))) pick = ST_SWAP;
-				else if (itemsLeft && raysQ < 64 && nE + nF > 0 && raysQ < nE + nF) pick = ST_GEN;
+				else if (canGen && raysQ < 64 && nE + nF > 0 && raysQ < nE + nF) pick = ST_GEN;
 				else if (walkers > 0) {
 					int best = nN * K.wNode;
 					pick = ST_NODE;
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 				}
 				else if (nF > 0 || (nE > 0 && raysQ > 0)) pick = ST_SWAP;
 				else if (hitsQ > 0) pick = ST_SHADE;
-				else if (itemsLeft) pick = ST_GEN;
+				else if (canGen) pick = ST_GEN;
 				else if (missQn > 0) pick = ST_MISS;
 				else pick = ST_END;
 				if (pick == ST_END) break;
@@ -263,37 +262,31 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 					}
 					case ST_CTRL: if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt); break;
 					case ST_SWAP: {
-						/* retire: walks that ended push their result (compacted) on the hit or the miss stack */
+						/* retire: a walk that ended leaves its result in the path's slot; the id goes on the hit or the miss stack */
 						const bool fin = (ph == PH_SHADE);
 						const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
 						const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
 						if (fin) {
-							const PathRec r = unparkPath(stk);
+							f4 *q = ptab + myPath * CRH_PATH_F4;
+							q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
 							if (finHit) {
-								float *q = hitQ + ((uint32_t)hitsQ + laneRank(hm));
-								putRay(q, CRH_HIT_CAP, w.ro, w.rd, r, myItem);
-								q[16 * CRH_HIT_CAP] = w.hit.t; q[17 * CRH_HIT_CAP] = w.hit.u; q[18 * CRH_HIT_CAP] = w.hit.v;
-								q[19 * CRH_HIT_CAP] = asF32((uint32_t)w.hit.slot); q[20 * CRH_HIT_CAP] = asF32((uint32_t)w.hit.inst);
+								q[5].x = asF32((uint32_t)w.hit.inst);
+								ids[CRH_IDS_HITS + (uint32_t)hitsQ + laneRank(hm)] = (uint8_t)myPath;
 							} else {
-								float *q = missQ + ((uint32_t)missQn + laneRank(mm));
-								q[0 * CRH_HIT_CAP] = w.rd.x; q[1 * CRH_HIT_CAP] = w.rd.y; q[2 * CRH_HIT_CAP] = w.rd.z;
-								q[3 * CRH_HIT_CAP] = r.wr; q[4 * CRH_HIT_CAP] = r.wg; q[5 * CRH_HIT_CAP] = r.wb;
-								q[6 * CRH_HIT_CAP] = r.fr; q[7 * CRH_HIT_CAP] = r.fg; q[8 * CRH_HIT_CAP] = r.fb;
-								q[9 * CRH_HIT_CAP] = asF32(myItem); q[10 * CRH_HIT_CAP] = w.hit.t;
+								ids[CRH_IDS_MISSES + (uint32_t)missQn + laneRank(mm)] = (uint8_t)myPath;
 							}
 							w.phase = PH_IDLE;
 						}
-						/* refill: idle lanes pop the top rays */
+						/* refill: idle lanes pop the top ray ids and start those walks */
 						const bool idle = (w.phase == PH_IDLE);
 						const unsigned long long em = __ballot(idle);
 						const uint32_t er = laneRank(em);
 						const int take = min(raysQ, (int)__popcll(em));
 						if (idle && (int)er < take) {
-							v3 o, d;
-							PathRec r;
-							getRay(rayQ + (uint32_t)(raysQ - take) + er, CRH_RAY_CAP, o, d, r, myItem);
-							parkPath(stk, r);
-							walkBegin(S, w, stk, o, d, cnt);
+							myPath = ids[CRH_IDS_RAYS + (uint32_t)(raysQ - take) + er];
+							const f4 *q = ptab + myPath * CRH_PATH_F4;
+							const f4 q0 = q[0], q1 = q[1];
+							walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt);
 						}
 						if (lane == 0) { wq[WQ_HITS] = hitsQ + (int)__popcll(hm); wq[WQ_MISSES] = missQn + (int)__popcll(mm); wq[WQ_RAYS] = raysQ - take; }
 						__threadfence_block();
@@ -304,54 +297,72 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						int x = 0, y = 0, pass = 0;
 						const bool valid = item < nItems && decodeItem(J, item, x, y, pass);
 						const unsigned long long vm = __ballot(valid);
+						const int n = (int)__popcll(vm);
 						if (valid) {
+							const uint32_t rk = laneRank(vm);
+							const uint32_t id = ids[CRH_IDS_FREE + (uint32_t)(freeQ - 1) - rk];
 							v3 o, d;
 							PathRec r;
 							beginPath(S, P, x, y, pass, o, d, r, cnt);
-							putRay(rayQ + ((uint32_t)raysQ + laneRank(vm)), CRH_RAY_CAP, o, d, r, item);
+							putPathRay(ptab + id * CRH_PATH_F4, o, d, r, item);
+							ids[CRH_IDS_RAYS + (uint32_t)raysQ + rk] = (uint8_t)id;
 						}
-						if (lane == 0) { wq[WQ_RAYS] = raysQ + (int)__popcll(vm); wq[WQ_NEXT_ITEM] = (int)(nextItem + 64u); }
+						if (lane == 0) { wq[WQ_RAYS] = raysQ + n; wq[WQ_FREE] = freeQ - n; wq[WQ_NEXT_ITEM] = (int)(nextItem + 64u); }
 						__threadfence_block();
 						break;
 					}
 					case ST_MISS: {          /* pathtrace.c:39-42 for up to 64 rays that left the scene: background, then the sample is complete */
 						const int n = min(missQn, 64);
 						if ((int)lane < n) {
-							const float *q = missQ + (uint32_t)(missQn - n) + lane;
-							v3 o{0.0f, 0.0f, 0.0f}, d{q[0 * CRH_HIT_CAP], q[1 * CRH_HIT_CAP], q[2 * CRH_HIT_CAP]};
+							const uint32_t id = ids[CRH_IDS_MISSES + (uint32_t)(missQn - n) + lane];
+							const f4 *q = ptab + id * CRH_PATH_F4;
+							const f4 q1 = q[1], q2 = q[2], q3 = q[3];
+							v3 o{0.0f, 0.0f, 0.0f}, d{q1.x, q1.y, q1.z};
 							PathRec r;
-							r.wr = q[3 * CRH_HIT_CAP]; r.wg = q[4 * CRH_HIT_CAP]; r.wb = q[5 * CRH_HIT_CAP];
-							r.fr = q[6 * CRH_HIT_CAP]; r.fg = q[7 * CRH_HIT_CAP]; r.fb = q[8 * CRH_HIT_CAP];
+							r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
+							r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
 							r.rng.state = 0; r.depth = 0;
-							const uint32_t item = asU32(q[9 * CRH_HIT_CAP]);
+							const uint32_t item = asU32(q1.w);
 							TravHit h;
-							h.t = q[10 * CRH_HIT_CAP]; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
+							h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
 							(void)shadeCore(S, P, o, d, h, r, cnt);
 							float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+							ids[CRH_IDS_FREE + (uint32_t)freeQ + lane] = (uint8_t)id;
 						}
-						if (lane == 0) wq[WQ_MISSES] = missQn - n;
+						if (lane == 0) { wq[WQ_MISSES] = missQn - n; wq[WQ_FREE] = freeQ + n; }
 						__threadfence_block();
 						break;
 					}
 					default: {   /* ST_SHADE: up to 64 surface hits */
 						const int n = min(hitsQ, 64);
-						bool cont = false;
-						v3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, 0.0f};
-						PathRec r;
-						uint32_t item = 0;
+						bool cont = false, done = false;
+						uint32_t id = 0;
 						if ((int)lane < n) {
-							const float *q = hitQ + (uint32_t)(hitsQ - n) + lane;
-							getRay(q, CRH_HIT_CAP, o, d, r, item);
+							id = ids[CRH_IDS_HITS + (uint32_t)(hitsQ - n) + lane];
+							f4 *q = ptab + id * CRH_PATH_F4;
+							const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+							v3 o{q0.x, q0.y, q0.z}, d{q1.x, q1.y, q1.z};
+							PathRec r;
+							r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
+							r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
+							r.rng.state = (uint64_t)asU32(q2.w) | ((uint64_t)asU32(q3.w) << 32);
+							r.depth = (int)asU32(q0.w);
+							const uint32_t item = asU32(q1.w);
 							TravHit h;
-							h.t = q[16 * CRH_HIT_CAP]; h.u = q[17 * CRH_HIT_CAP]; h.v = q[18 * CRH_HIT_CAP];
-							h.slot = (int32_t)asU32(q[19 * CRH_HIT_CAP]); h.inst = (int32_t)asU32(q[20 * CRH_HIT_CAP]);
+							h.t = q4.x; h.u = q4.y; h.v = q4.z;
+							h.slot = (int32_t)asU32(q4.w); h.inst = (int32_t)asU32(q[5].x);
 							__builtin_assume(h.inst >= 0);
 							cont = shadeCore(S, P, o, d, h, r, cnt);
-							if (!cont) { float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb; }
+							done = !cont;
+							if (cont) putPathRay(q, o, d, r, item);
+							else {
+								float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+							}
 						}
-						const unsigned long long cm = __ballot(cont);
-						if (cont) putRay(rayQ + ((uint32_t)raysQ + laneRank(cm)), CRH_RAY_CAP, o, d, r, item);
-						if (lane == 0) { wq[WQ_HITS] = hitsQ - n; wq[WQ_RAYS] = raysQ + (int)__popcll(cm); }
+						const unsigned long long cm = __ballot(cont), dm = __ballot(done);
+						if (cont) ids[CRH_IDS_RAYS + (uint32_t)raysQ + laneRank(cm)] = (uint8_t)id;
+						if (done) ids[CRH_IDS_FREE + (uint32_t)freeQ + laneRank(dm)] = (uint8_t)id;
+						if (lane == 0) { wq[WQ_HITS] = hitsQ - n; wq[WQ_RAYS] = raysQ + (int)__popcll(cm); wq[WQ_FREE] = freeQ + (int)__popcll(dm); }
 						__threadfence_block();
 						break;
 					}

@@ -776,17 +776,14 @@ struct TravHit {
  * are parked in fixed LDS slots meanwhile.
  */
 #define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
-/* fixed per-lane park slots (LDS on the device): the world-space slab constants while a lane is inside a BLAS, and
- * the path state (weight, radiance, RNG, depth), which only the shading / setup steps touch */
-enum { PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT,
-       PK_WR, PK_WG, PK_WB, PK_FR, PK_FG, PK_FB, PK_RNG0, PK_RNG1, PK_DEPTH, CRH_PARK_SLOTS };
+/* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside a BLAS */
+enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT, CRH_PARK_SLOTS };
 
 enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6 };   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
 struct Walk {
 	uint32_t phase;
 	RayK k;                                  /* current-level ray: world ray in the TLAS, object-space ray inside a BLAS */
-	v3 ro, rd;                               /* the world ray of this bounce */
 	uint32_t node;                           /* device index of the child PAIR tested next (children are adjacent: bvh.c:393-394) */
 	uint32_t pA, pAe, pB, pBe;               /* pending leaf prim ranges [p, pe) at the current level: left leaf, right leaf */
 	uint32_t sp, spBase;
@@ -807,7 +804,8 @@ CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
 	 * reads, far cheaper than a scheduling round at the occupancy such a step would get. */
 	if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
 	w.inBlas = 0; w.instFound = 0;
-	w.k.o = w.ro; w.k.d = w.rd;
+	w.k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
+	w.k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
 	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
 	w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
 	w.k.oct = stk.unpark(PK_OCT);
@@ -820,7 +818,6 @@ CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
 
 template <class Stack, class Cnt>
 CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v3 d, Cnt &cnt) {
-	w.ro = o; w.rd = d;
 	w.hit.t = FLT_MAX; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -1; w.hit.inst = -1;
 	w.node = CRH_NONE; w.pA = w.pAe = w.pB = w.pBe = 0; w.sp = 0; w.spBase = 0;
 	w.inBlas = 0; w.instFound = 0; w.curInst = -1;
@@ -944,6 +941,8 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 		}
 		if (enter) {
 			stk.push(w.sp++, w.node); stk.push(w.sp++, w.pA); stk.push(w.sp++, w.pAe); stk.push(w.sp++, w.pB); stk.push(w.sp++, w.pBe);
+			stk.park(PK_OX, asU32(w.k.o.x)); stk.park(PK_OY, asU32(w.k.o.y)); stk.park(PK_OZ, asU32(w.k.o.z));
+			stk.park(PK_DX, asU32(w.k.d.x)); stk.park(PK_DY, asU32(w.k.d.y)); stk.park(PK_DZ, asU32(w.k.d.z));
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
 			stk.park(PK_SX, asU32(w.k.ss.x)); stk.park(PK_SY, asU32(w.k.ss.y)); stk.park(PK_SZ, asU32(w.k.ss.z));
 			stk.park(PK_OCT, w.k.oct);
@@ -1106,60 +1105,41 @@ CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &
 	return true;
 }
 
-template <class Stack>
-CRH_DEV void parkPath(Stack &stk, const PathRec &r) {
-	stk.park(PK_WR, asU32(r.wr)); stk.park(PK_WG, asU32(r.wg)); stk.park(PK_WB, asU32(r.wb));
-	stk.park(PK_FR, asU32(r.fr)); stk.park(PK_FG, asU32(r.fg)); stk.park(PK_FB, asU32(r.fb));
-	stk.park(PK_RNG0, (uint32_t)r.rng.state); stk.park(PK_RNG1, (uint32_t)(r.rng.state >> 32)); stk.park(PK_DEPTH, (uint32_t)r.depth);
-}
-template <class Stack>
-CRH_DEV PathRec unparkPath(Stack &stk) {
-	PathRec r;
-	r.wr = asF32(stk.unpark(PK_WR)); r.wg = asF32(stk.unpark(PK_WG)); r.wb = asF32(stk.unpark(PK_WB));
-	r.fr = asF32(stk.unpark(PK_FR)); r.fg = asF32(stk.unpark(PK_FG)); r.fb = asF32(stk.unpark(PK_FB));
-	r.rng.state = (uint64_t)stk.unpark(PK_RNG0) | ((uint64_t)stk.unpark(PK_RNG1) << 32);
-	r.depth = (int)stk.unpark(PK_DEPTH);
-	return r;
-}
+/* A lane that owns its paths from start to end (host emulation; the device driver keeps paths in a per-wave table
+ * instead and lets lanes work on whichever path needs a step): */
+struct LanePath { Item it; PathRec r; v3 ro, rd; };
 
-/* SETUP / SHADE for a lane that owns its paths from start to end (host emulation): */
 template <class Stack, class Cnt>
-CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, Item &it,
+CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, LanePath &lp,
 					   Stack &stk, float *stage, Cnt &cnt) {
 	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
 	for (;;) {
-		if (it.next >= nItems) { w.phase = PH_DONE; return; }
+		if (lp.it.next >= nItems) { w.phase = PH_DONE; return; }
 		int x = 0, y = 0, pass = 0;
-		const bool valid = decodeItem(J, it.next, x, y, pass);
-		it.cur = it.next;
-		it.next += laneStride;
+		const bool valid = decodeItem(J, lp.it.next, x, y, pass);
+		lp.it.cur = lp.it.next;
+		lp.it.next += laneStride;
 		if (!valid) continue;
 		if (P.bounces <= 0) {                      /* pathTrace() with maxDepth 0 returns black */
 			CRH_COUNT1(cnt, paths, 1);
-			float *o = stage + (size_t)it.cur * 3;
+			float *o = stage + (size_t)lp.it.cur * 3;
 			o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
 			continue;
 		}
-		PathRec r;
-		v3 ro, rd;
-		beginPath(S, P, x, y, pass, ro, rd, r, cnt);
-		parkPath(stk, r);
-		walkBegin(S, w, stk, ro, rd, cnt);
+		beginPath(S, P, x, y, pass, lp.ro, lp.rd, lp.r, cnt);
+		walkBegin(S, w, stk, lp.ro, lp.rd, cnt);
 		return;
 	}
 }
 
 template <class Stack, class Cnt>
-CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, Item &it, Stack &stk, float *stage, Cnt &cnt) {
-	PathRec r = unparkPath(stk);
-	v3 ro = w.ro, rd = w.rd;
-	if (shadeCore(S, P, ro, rd, w.hit, r, cnt)) {
-		parkPath(stk, r);
-		walkBegin(S, w, stk, ro, rd, cnt);
+CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, LanePath &lp, Stack &stk, float *stage, Cnt &cnt) {
+	if (shadeCore(S, P, lp.ro, lp.rd, w.hit, lp.r, cnt)) {
+		walkBegin(S, w, stk, lp.ro, lp.rd, cnt);
 		return;
 	}
-	float *o = stage + (size_t)it.cur * 3;
-	o[0] = r.fr; o[1] = r.fg; o[2] = r.fb;
+	float *o = stage + (size_t)lp.it.cur * 3;
+	o[0] = lp.r.fr; o[1] = lp.r.fg; o[2] = lp.r.fb;
 	w.phase = PH_SETUP;
 }
 
@@ -1168,16 +1148,16 @@ template <class Stack, class Cnt>
 CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk, const BlockJob &J, uint32_t lane, uint32_t laneStride,
 						 float *stage, Cnt &cnt) {
 	Walk w;
-	Item it;
-	it.next = lane; it.cur = 0;
+	LanePath lp;
+	lp.it.next = lane; lp.it.cur = 0;
 	w.phase = PH_SETUP;
 	for (;;) {
 		switch (w.phase) {
-			case PH_SETUP: stepSetup(S, P, J, laneStride, w, it, stk, stage, cnt); break;
+			case PH_SETUP: stepSetup(S, P, J, laneStride, w, lp, stk, stage, cnt); break;
 			case PH_NODE: stepNode(S, w, stk, cnt); break;
 			case PH_TRI: stepTri(S, w, stk, cnt); break;
 			case PH_CTRL: stepCtrl(S, w, stk, cnt); break;
-			case PH_SHADE: stepShade(S, P, w, it, stk, stage, cnt); break;
+			case PH_SHADE: stepShade(S, P, w, lp, stk, stage, cnt); break;
 			default: return;
 		}
 	}

@@ -7,6 +7,7 @@ from __graft_entry__ import load_package, BUILT
 pkg = load_package(); api = pkg.api; abi = pkg.abi
 ctx = api.Context(0)
 ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
+if os.environ.get('CRH_BPC'): ctx.set_option(abi.OPT_BLOCKS_PER_CU, int(os.environ['CRH_BPC']))
 for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 256, 8), ("cfg3_venus", 1920, 1080, 64, 32), ("cfg4_statues", 3840, 2160, 16, 30), ("soup_1m", 2560, 1440, 32, 8)):
     scene = api.Scene(os.path.join(BUILT, name + ".blob"))
     ctx.upload(scene)

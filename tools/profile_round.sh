@@ -1,0 +1,24 @@
+#!/bin/bash
+# profile_round.sh TAG — the rocprofv3 passes behind profiles/TAG_rocprof_summary.{txt,json} (run on the GPU box):
+#   one --kernel-trace --stats pass of bench.py, then one --pmc pass per counter group (PMC is never combined with tracing).
+# Afterwards, here:  python tools/parse_prof.py TAG
+TAG=${1:-r01}
+cd "$(dirname "$0")/.." || exit 1
+REPO=$(pwd)
+export TMPDIR=/tmp
+OUT=$REPO/gpurun_out/prof
+mkdir -p "$OUT"
+cd /tmp || exit 1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o "$TAG" -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu > "$OUT/trace_$TAG.log" 2>&1
+echo "trace rc $?"; tail -1 "$OUT/trace_$TAG.log"
+i=0
+for group in "FETCH_SIZE" "WRITE_SIZE" \
+             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
+             "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+             "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_SMEM" \
+             "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
+	i=$((i + 1))
+	# shellcheck disable=SC2086
+	rocprofv3 --pmc $group -d "$OUT/pmc$i" -o "$TAG" -- python "$REPO/bench.py" --steps 2 --warmup 0 --no-cpu > "$OUT/pmc${i}_$TAG.log" 2>&1
+	echo "pmc$i ($group) rc $?"
+done

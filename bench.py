@@ -31,16 +31,25 @@ WORKLOAD = {"scene": "hdr.json", "blob": "cfg2_hdr", "width": 1280, "height": 72
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def algorithmic_bytes(cnt):
-    """Device-layout algorithmic bytes of one launch from its own counters (DESIGN.md §Algorithmic bytes)."""
+PATH_STATE_BYTES_PER_RAY = 152   # SURVEY.md §8(d) B_state: 2 x (28 B ray + 16 B weight + 12 B radiance + 16 B RNG + 4 B pixel)
+
+
+def algorithmic_bytes(cnt, path_state=True):
+    """Device-layout algorithmic bytes of one launch from its own counters (DESIGN.md §Algorithmic bytes).
+
+    path_state adds SURVEY.md §8(d)'s B_state term: the kernel keeps every path in a per-wave table in memory (one
+    record written by the shading step and read back by the walk / next shading step per bounce)."""
     mesh_hits = max(cnt["inst_hits"] - 0, 0)
-    return (32 * cnt["node_tests"]          # one 32-B node record per box test (child pairs are one 64-B load)
-            + 48 * cnt["tri_tests"]         # prepared triangle v0,e1,e2,n
-            + 128 * cnt["inst_visits"]      # instance record (Ainv, A, kind/object/root/offset/radius/material)
-            + 64 * mesh_hits                # finishing a hit: prim index + poly (40 B) + part of the vertex normals
-            + 16 * cnt["tex_fetches"]       # one texel (RGB float 12 B / RGBA8 4 B), rounded up
-            + 32 * cnt["rays"]              # material + bsdf records per shaded ray
-            + 48 * cnt["paths"])            # sample staged (12 B w + 12 B r) + running mean RMW (24 B / pass chunk)
+    b = (32 * cnt["node_tests"]             # one 32-B node record per box test (child pairs are one 64-B load)
+         + 48 * cnt["tri_tests"]            # prepared triangle v0,e1,e2,n
+         + 64 * cnt["inst_visits"]          # enter line of the instance record (Ainv, kind, root, offset, radius)
+         + 128 * mesh_hits                  # finishing a hit: second instance line (A, material) + the 64-B shading record
+         + 16 * cnt["tex_fetches"]          # one texel (RGB float 12 B / RGBA8 4 B), rounded up
+         + 32 * cnt["rays"]                 # material + bsdf records per shaded ray
+         + 48 * cnt["paths"])               # sample staged (12 B w + 12 B r) + running mean RMW (24 B / pass chunk)
+    if path_state:
+        b += PATH_STATE_BYTES_PER_RAY * cnt["rays"]
+    return b
 
 
 def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
@@ -156,6 +165,7 @@ def main():
         value = total_rays / elapsed / 1e6
         avg_kernel_ms = kernel_total_ms / max(launches, 1)
         alg = algorithmic_bytes(full)
+        alg_no_state = algorithmic_bytes(full, path_state=False)
         achieved = alg / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
@@ -176,7 +186,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_pathtrace", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg),
                          "bytes_per_ray": round(alg / max(full["rays"], 1), 1),
-                         "note": "rank 0's launch; scene working set (~70 MB) is Infinity-Cache resident, so HBM traffic << algorithmic bytes"},
+                         "frac_without_path_state": round(alg_no_state / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "note": "rank 0's launch. algorithmic bytes = scene records touched (node/triangle/instance/shading/texel) + SURVEY 8(d) "
+                                 "B_state (152 B/ray: paths live in a per-wave table in memory). traffic = L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE); the "
+                                 "scene (~165 MB) and the path tables sit in the 256 MB Infinity Cache, so most of it never reaches HBM"},
         }
         if world == 1 and not a.no_cpu:
             sys.path.insert(0, os.path.join(REPO, "oracle"))

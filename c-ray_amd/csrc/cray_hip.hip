@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #define CRH_NCOUNTERS 32
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, serveMin, swapMin; };
+struct Sched { int wNode, wTri, wCtrl, swapMin; };
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -488,7 +488,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 80, 40, 24};
+	Sched sched = {70, 160, 120, 32};
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
@@ -627,12 +627,12 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_WAVES_PER_SIMD:
 			if (value != 1 && value != 4) return fail(CRH_ERR_INVALID, "waves per SIMD must be 1 (unconstrained) or 4");
 			c->wavesPerSimd = (int)value; return CRH_OK;
-		case CRH_OPT_SCHED_WEIGHTS:   /* four 12-bit fields, low to high: node, tri, ctrl weights; lanes that must wait before shading / setup is served */
-			c->sched.wNode = (int)(value & 0xFFF); c->sched.wTri = (int)((value >> 12) & 0xFFF); c->sched.wCtrl = (int)((value >> 24) & 0xFFF);
-			c->sched.serveMin = (int)((value >> 36) & 0xFFF);
-			if ((value >> 48) & 0xFFF) c->sched.swapMin = (int)((value >> 48) & 0xFFF);
-			if (c->sched.wNode < 1 || c->sched.wTri < 1 || c->sched.wCtrl < 1 || c->sched.serveMin < 1 || c->sched.serveMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
+		case CRH_OPT_SCHED_WEIGHTS: {  /* four 12-bit fields, low to high: node, tri, ctrl weights; finished + idle lanes that trigger a swap step */
+			const Sched k = {(int)(value & 0xFFF), (int)((value >> 12) & 0xFFF), (int)((value >> 24) & 0xFFF), (int)((value >> 36) & 0xFFF)};
+			if (k.wNode < 1 || k.wTri < 1 || k.wCtrl < 1 || k.swapMin < 1 || k.swapMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
+			c->sched = k;
 			return CRH_OK;
+		}
 		case CRH_OPT_UNITS_PER_WAVE:
 			if (value < 1 || value > 1024) return fail(CRH_ERR_INVALID, "units per wave must be 1..1024");
 			c->unitsPerWave = (int)value; return CRH_OK;

@@ -91,6 +91,13 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
         assert np.array_equal(ctx.download(fb, w, h), full), (items, chunk)
     ctx.set_option(pkg.abi.OPT_UNIT_ITEMS, 1024)
     ctx.set_option(pkg.abi.OPT_PASS_CHUNK, 64)
+    # wave scheduler: which step kind runs when changes nothing a path computes
+    for sched in ((1, 1, 1, 1), (400, 10, 10, 64), (10, 10, 400, 8)):
+        ctx.set_sched(*sched)
+        ctx.clear(fb, w, h)
+        ctx.render_region(fb, w, h, s, b)
+        assert np.array_equal(ctx.download(fb, w, h), full), sched
+    ctx.set_sched(70, 160, 120, 32)
     # both register-budget variants and both counter levels compute the same frame
     for wps, level in ((1, 2), (1, 1), (4, 1)):
         ctx.set_option(pkg.abi.OPT_WAVES_PER_SIMD, wps)

@@ -121,5 +121,10 @@ EXPORTED_SYMBOLS = [
     "crh_scene_upload", "crh_framebuffer_alloc", "crh_framebuffer_free", "crh_framebuffer_clear",
     "crh_framebuffer_download", "crh_framebuffer_to_srgb8", "crh_render_region", "crh_render_tiles",
     "crh_synchronize", "crh_frames_reduce", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
-    "crh_blob_save", "crh_blob_load", "crh_blob_free",
+    "crh_blob_save", "crh_blob_load", "crh_blob_free", "crh_bvh_build_triangles",
 ]
+
+
+class BvhBuildStats(C.Structure):
+    _fields_ = [("upload_ms", C.c_double), ("build_ms", C.c_double), ("download_ms", C.c_double),
+                ("levels", C.c_uint32), ("upper_nodes", C.c_uint32), ("subtrees", C.c_uint32), ("pad", C.c_uint32)]

@@ -64,6 +64,8 @@ def library():
         "crh_counters_reset": (C.c_int, [ctx]),
         "crh_kernel_time_ms": (C.c_int, [ctx, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "crh_trace_rays": (C.c_int, [ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
+        "crh_bvh_build_triangles": (C.c_int, [ctx, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_uint32), C.POINTER(abi.BvhBuildStats)]),
         "crh_blob_save": (C.c_int, [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.BlobPrefs)]),
         "crh_blob_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(abi.SceneDesc)), C.POINTER(abi.BlobPrefs)]),
         "crh_blob_free": (None, [C.POINTER(abi.SceneDesc)]),
@@ -206,6 +208,16 @@ class Context:
         last, total, n = C.c_float(), C.c_double(), C.c_uint64()
         _check(self.L.crh_kernel_time_ms(self.h, C.byref(last), C.byref(total), C.byref(n)), "crh_kernel_time_ms")
         return last.value, total.value, n.value
+
+    def bvh_build_triangles(self, polys_ptr, poly_count, vertices_ptr, vertex_count):
+        """buildBottomLevelBvh on the GPU: (nodes uint32[n, 8] = crh_bvh_node records, prim order int32[count], stats dict)."""
+        nodes = np.zeros((max(2 * poly_count - 1, 1), 8), np.uint32)
+        prims = np.zeros(max(poly_count, 1), np.int32)
+        n = C.c_uint32(0)
+        st = abi.BvhBuildStats()
+        _check(self.L.crh_bvh_build_triangles(self.h, polys_ptr, poly_count, vertices_ptr, vertex_count, nodes.ctypes.data,
+                                              prims.ctypes.data, C.byref(n), C.byref(st)), "crh_bvh_build_triangles")
+        return nodes[:n.value], prims[:poly_count], {k: getattr(st, k) for k, _ in abi.BvhBuildStats._fields_ if k != "pad"}
 
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

@@ -18,10 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "libcray_hip.so")
 
-SOURCES = [os.path.join(CSRC, "cray_hip.hip")]
+SOURCES = [os.path.join(CSRC, "cray_hip.hip"), os.path.join(CSRC, "bvh_build.hip")]
 CXX_SOURCES = [os.path.join(CSRC, "scene_compile.cpp")]      # host-only C++ (g++, -ffp-contract=off: prepared triangles)
 C_SOURCES = [os.path.join(HERE, "host", "scene_blob.c")]
-DEPS = SOURCES + CXX_SOURCES + C_SOURCES + [os.path.join(CSRC, "pt_device.h"), os.path.join(CSRC, "scene_compile.h"),
+DEPS = SOURCES + CXX_SOURCES + C_SOURCES + [os.path.join(CSRC, "pt_device.h"), os.path.join(CSRC, "scene_compile.h"), os.path.join(CSRC, "ctx_access.h"),
                               os.path.join(REPO, "include", "cray_hip.h"), os.path.abspath(__file__)]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

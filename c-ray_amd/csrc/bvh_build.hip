@@ -1,0 +1,715 @@
+/*
+ * bvh_build.hip — SURVEY.md §8(f) row 1: the reference's binned-SAH BVH builder (src/accelerators/bvh.c:87-316) on the
+ * GPU, producing THE SAME tree: node numbering, node bounds (bit patterns) and primitive order are the reference's,
+ * because the hot path's parity (per-ray node / triangle test counts, tie order of equal-distance hits) hangs on them.
+ *
+ * The reference is a depth-first recursion over index ranges; what it computes per node is
+ *   (1) 3 x 32 bins over the NODE bounds (bvh.c:87-93, 158-165): count + box of the primitives whose centre falls in the bin;
+ *   (2) two 31-step sweeps per axis (bvh.c:170-191), the axis / leaf / median-fallback decision (bvh.c:195-215);
+ *   (3) a two-pointer in-place partition of the index range (bvh.c:95-130);
+ *   (4) child boxes = folds of the bin boxes (bvh.c:226-233); children numbered when the parent splits, left subtree first.
+ * (1) and (3) are the work; they are data-parallel once two order dependences are made explicit:
+ *   * box folds use includes.h:20-21 `min(a,b) = a < b ? a : b`: on a tie the LATER operand wins, which is visible only
+ *     for -0 / +0. Boxes are therefore reduced as 64-bit keys {sortable value with -0 == +0, sequence position, sign
+ *     of zero} with atomic min / max: the result is the reference's sequential fold, bit for bit, in any order.
+ *   * the partition swaps the k-th misplaced element from the left with the k-th misplaced element from the right:
+ *     ranks come from prefix sums, the swaps are independent.
+ * Node numbering (depth-first, a pair allocated per split) is a prefix sum over split counts, done last.
+ *
+ * Two phases:
+ *   LARGE  level-synchronous over the nodes that still hold more than CRH_BVH_SMALL primitives: per level four kernels over
+ *          2048-primitive chunks (bin -> decide -> rank -> swap); the host keeps the (small) upper tree.
+ *   SMALL  every remaining subtree is built by ONE WAVE, depth-first like the reference, with its index range, bins and
+ *          rank lists in LDS; it numbers its nodes locally in the reference's allocation order.
+ * Then the host numbers the upper tree + subtrees depth-first and one kernel emits the final node array.
+ * Everything is plain fp32 with the reference's operation order (this TU is built with -ffp-contract=off and
+ * correctly rounded division like the rest of the library); bvh.c:87-93's float -> unsigned conversion is the x86-64
+ * one (64-bit cvttss2si, low word), spelled out in binOf().
+ */
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "cray_hip.h"
+#include "ctx_access.h"
+
+namespace crhb {
+
+#define CRH_BVH_BINS 32
+#define CRH_BVH_MAX_DEPTH 64u
+#define CRH_BVH_MAX_LEAF 16u
+#define CRH_BVH_SMALL 512u          /* subtrees of at most this many primitives are built by one wave */
+#define CRH_BVH_CHUNK 2048u         /* primitives per workgroup in the large phase */
+
+/* ---- order-independent folds with the reference's tie rule ----------------------------------------------------- */
+__host__ __device__ inline uint32_t sortable(float f) {                  /* monotone in the value; -0 and +0 share a key */
+	uint32_t u;
+	memcpy(&u, &f, 4);
+	if (u == 0x80000000u) u = 0u;
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float unsortable(uint32_t s) {
+	const uint32_t u = (s & 0x80000000u) ? (s & 0x7FFFFFFFu) : ~s;
+	float f;
+	memcpy(&f, &u, 4);
+	return f;
+}
+__host__ __device__ inline uint32_t isNegZero(float f) { uint32_t u; memcpy(&u, &f, 4); return u == 0x80000000u ? 1u : 0u; }
+/* min fold: smaller value wins, on a tie the LATER position (atomicMin: smaller low word = later position) */
+__host__ __device__ inline unsigned long long keyLo(float f, uint32_t pos) {
+	return ((unsigned long long)sortable(f) << 32) | (unsigned long long)(((0x7FFFFFFFu - pos) << 1) | isNegZero(f));
+}
+/* max fold: larger value wins, on a tie the LATER position (atomicMax: larger low word = later position) */
+__host__ __device__ inline unsigned long long keyHi(float f, uint32_t pos) {
+	return ((unsigned long long)sortable(f) << 32) | (unsigned long long)((pos << 1) | isNegZero(f));
+}
+__host__ __device__ inline float keyValue(unsigned long long k) {
+	const uint32_t s = (uint32_t)(k >> 32);
+	if (s == 0x80000000u) return (k & 1ull) ? -0.0f : 0.0f;
+	return unsortable(s);
+}
+#define CRH_KEY_LO_EMPTY ((((unsigned long long)0xFF7FFFFFu) << 32) | 0xFFFFFFFFull)   /* sortable(+FLT_MAX), loses every tie */
+#define CRH_KEY_HI_EMPTY ((((unsigned long long)0x00800000u) << 32) | 0ull)            /* sortable(-FLT_MAX), loses every tie */
+
+__host__ __device__ inline float pickLo(float a, float b) { return a < b ? a : b; }   /* includes.h:20 */
+__host__ __device__ inline float pickHi(float a, float b) { return a > b ? a : b; }   /* includes.h:21 */
+
+/* bvh.c:87-93. The (unsigned) cast of the reference is gcc/x86-64's: cvttss2si to 64 bits, low word kept — NaN and
+ * anything >= 2^63 give 0 (0x8000000000000000 truncated), in-range values truncate. */
+__host__ __device__ inline uint32_t binOf(float coord, float lo, float hi) {
+	const float scale = 32.0f / (hi - lo);
+	const float f = (coord - lo) * scale;
+	uint32_t b;
+	if (f < 0.0f) b = 0u;
+	else if (!(f < 9223372036854775808.0f)) b = 0u;
+	else b = (uint32_t)(unsigned long long)f;
+	return b >= CRH_BVH_BINS ? CRH_BVH_BINS - 1u : b;
+}
+
+struct Box { float lo[3], hi[3]; };
+__host__ __device__ inline void boxReset(Box &b) { for (int k = 0; k < 3; ++k) { b.lo[k] = FLT_MAX; b.hi[k] = -FLT_MAX; } }
+__host__ __device__ inline void boxGrow(Box &d, const Box &s) {
+	for (int k = 0; k < 3; ++k) { d.lo[k] = pickLo(d.lo[k], s.lo[k]); d.hi[k] = pickHi(d.hi[k], s.hi[k]); }
+}
+__host__ __device__ inline float boxHalfArea(const Box &b) {              /* bbox.h:25-28 */
+	const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+	return ex * (ey + ez) + ey * ez;
+}
+
+/* one bin: 3 min keys, 3 max keys, count */
+struct BinKeys { unsigned long long lo[3], hi[3]; };
+
+/* per node (large phase) or per wave (small phase): what bvh.c:148-215 decides */
+struct Decision {
+	uint32_t axis, split, leaf, nLeft;
+	float childL[6], childR[6];              /* {minx,maxx,miny,maxy,minz,maxz} like bvhNode.bounds */
+};
+
+/* The sweeps + decision of one node from its bins. `box(ax, b)` / `cnt(ax, b)` read bin b of axis ax. Serial (it is 3 x 62
+ * dependent steps); the callers run the three axes on three lanes and the rest on one. */
+template <class GetBox, class GetCnt>
+__host__ __device__ inline void sweepAxis(int ax, GetBox box, GetCnt cnt, float *costR /* [32] scratch */, float &bestCost, uint32_t &bestBin) {
+	Box acc;
+	uint32_t n = 0;
+	boxReset(acc);
+	for (uint32_t b = CRH_BVH_BINS; b > 1; --b) {                        /* bvh.c:170-177 */
+		n += cnt(ax, b - 1);
+		boxGrow(acc, box(ax, b - 1));
+		costR[b - 1] = n * boxHalfArea(acc);
+	}
+	boxReset(acc);
+	n = 0;
+	bestCost = FLT_MAX; bestBin = 1;
+	for (uint32_t b = 0; b < CRH_BVH_BINS - 1; ++b) {                    /* bvh.c:180-191 */
+		n += cnt(ax, b);
+		boxGrow(acc, box(ax, b));
+		const float cost = n * boxHalfArea(acc) + costR[b + 1];
+		if (cost < bestCost) { bestBin = b + 1; bestCost = cost; }
+	}
+}
+template <class GetBox, class GetCnt>
+__host__ __device__ inline void decide(const float *bounds, uint32_t n, const float *bestCost, const uint32_t *bestBin, GetBox box, GetCnt cnt, Decision &d) {
+	uint32_t ax = 0;                                                     /* bvh.c:195-197 */
+	if (bestCost[1] < bestCost[0]) ax = 1;
+	if (bestCost[2] < bestCost[ax]) ax = 2;
+	uint32_t split = bestBin[ax];
+	Box self;
+	for (int k = 0; k < 3; ++k) { self.lo[k] = bounds[2 * k]; self.hi[k] = bounds[2 * k + 1]; }
+	const float leafCost = boxHalfArea(self) * (n - 1.5f);               /* bvh.c:200 */
+	d.leaf = 0;
+	if (bestCost[ax] > leafCost) {
+		if (n > CRH_BVH_MAX_LEAF) {                                      /* bvh.c:202-211 */
+			uint32_t seen = 0, closest = n;
+			for (uint32_t b = 0; b < CRH_BVH_BINS - 1; ++b) {
+				seen += cnt(ax, b);
+				const int diff = (int)n / 2 - (int)seen;
+				const uint32_t off = (uint32_t)(diff < 0 ? -diff : diff);
+				if (off < closest) { closest = off; split = b + 1; }
+			}
+		} else d.leaf = 1;
+	}
+	d.axis = ax; d.split = split;
+	uint32_t nLeft = 0;
+	Box l, r;
+	boxReset(l); boxReset(r);
+	for (uint32_t b = 0; b < split; ++b) { nLeft += cnt(ax, b); boxGrow(l, box(ax, b)); }              /* bvh.c:226-233 */
+	for (uint32_t b = split; b < CRH_BVH_BINS; ++b) boxGrow(r, box(ax, b));
+	d.nLeft = nLeft;
+	if (nLeft == 0) d.leaf = 1;                                          /* bvh.c:218, 239-241: beginRight == begin */
+	for (int k = 0; k < 3; ++k) { d.childL[2 * k] = l.lo[k]; d.childL[2 * k + 1] = l.hi[k]; d.childR[2 * k] = r.lo[k]; d.childR[2 * k + 1] = r.hi[k]; }
+}
+
+__device__ inline Box binBox(const BinKeys &k) {
+	Box b;
+	for (int c = 0; c < 3; ++c) { b.lo[c] = keyValue(k.lo[c]); b.hi[c] = keyValue(k.hi[c]); }
+	return b;
+}
+
+/* ---- kernels: preparation -------------------------------------------------------------------------------------------- */
+/* bvh.c:264-269 + 289-297: per-triangle box and centre, identity order, root box keys */
+__global__ void k_prepare(const crh_poly *polys, const float *vertices, uint32_t count, float *boxes, float *centers, int32_t *prims, unsigned long long *rootKeys) {
+	__shared__ unsigned long long s_keys[6];
+	if (threadIdx.x < 3) { s_keys[threadIdx.x] = CRH_KEY_LO_EMPTY; s_keys[3 + threadIdx.x] = CRH_KEY_HI_EMPTY; }
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) {
+		const crh_poly p = polys[i];
+		const float *a = vertices + 3 * (size_t)p.v[0], *b = vertices + 3 * (size_t)p.v[1], *c = vertices + 3 * (size_t)p.v[2];
+		for (int k = 0; k < 3; ++k) {
+			const float lo = pickLo(a[k], pickLo(b[k], c[k])), hi = pickHi(a[k], pickHi(b[k], c[k]));
+			centers[3 * (size_t)i + k] = ((a[k] + b[k]) + c[k]) * (1.0f / 3.0f);               /* vector.h:186-188 */
+			boxes[6 * (size_t)i + k] = lo;
+			boxes[6 * (size_t)i + 3 + k] = hi;
+			atomicMin(&s_keys[k], keyLo(lo, i));
+			atomicMax(&s_keys[3 + k], keyHi(hi, i));
+		}
+		prims[i] = (int32_t)i;
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) atomicMin(&rootKeys[threadIdx.x], s_keys[threadIdx.x]);
+	else if (threadIdx.x < 6) atomicMax(&rootKeys[threadIdx.x], s_keys[threadIdx.x]);
+}
+
+/* ---- kernels: large phase ------------------------------------------------------------------------------------------------ */
+struct LargeNode {            /* device mirror of one node of the current level */
+	float bounds[6];
+	uint32_t begin, end;
+};
+struct Chunk { uint32_t node, start, len, pad; };   /* positions [start, start+len) of prims[], all inside level node `node` */
+
+__global__ void k_init_bins(BinKeys *bins, uint32_t *counts, uint32_t nBins) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nBins) return;
+	for (int c = 0; c < 3; ++c) { bins[i].lo[c] = CRH_KEY_LO_EMPTY; bins[i].hi[c] = CRH_KEY_HI_EMPTY; }
+	counts[i] = 0;
+}
+
+/* (1) bins of every large node of the level: workgroup-private bins in LDS, flushed with one atomic per non-empty bin */
+__global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk *chunks, const int32_t *prims, const float *boxes, const float *centers,
+											 BinKeys *gbins, uint32_t *gcounts) {
+	__shared__ BinKeys s_bins[3 * CRH_BVH_BINS];
+	__shared__ uint32_t s_cnt[3 * CRH_BVH_BINS];
+	const Chunk ch = chunks[blockIdx.x];
+	const LargeNode nd = nodes[ch.node];
+	for (uint32_t i = threadIdx.x; i < 3 * CRH_BVH_BINS; i += blockDim.x) {
+		for (int c = 0; c < 3; ++c) { s_bins[i].lo[c] = CRH_KEY_LO_EMPTY; s_bins[i].hi[c] = CRH_KEY_HI_EMPTY; }
+		s_cnt[i] = 0;
+	}
+	__syncthreads();
+	for (uint32_t q = threadIdx.x; q < ch.len; q += blockDim.x) {
+		const uint32_t p = ch.start + q;
+		const int32_t id = prims[p];
+		float lo[3], hi[3], ce[3];
+		for (int k = 0; k < 3; ++k) { lo[k] = boxes[6 * (size_t)id + k]; hi[k] = boxes[6 * (size_t)id + 3 + k]; ce[k] = centers[3 * (size_t)id + k]; }
+		for (int ax = 0; ax < 3; ++ax) {
+			const uint32_t b = ax * CRH_BVH_BINS + binOf(ce[ax], nd.bounds[2 * ax], nd.bounds[2 * ax + 1]);
+			for (int k = 0; k < 3; ++k) { atomicMin(&s_bins[b].lo[k], keyLo(lo[k], p)); atomicMax(&s_bins[b].hi[k], keyHi(hi[k], p)); }
+			atomicAdd(&s_cnt[b], 1u);
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < 3 * CRH_BVH_BINS; i += blockDim.x) {
+		if (!s_cnt[i]) continue;
+		const size_t g = (size_t)ch.node * 3 * CRH_BVH_BINS + i;
+		for (int c = 0; c < 3; ++c) { atomicMin(&gbins[g].lo[c], s_bins[i].lo[c]); atomicMax(&gbins[g].hi[c], s_bins[i].hi[c]); }
+		atomicAdd(&gcounts[g], s_cnt[i]);
+	}
+}
+
+/* (2) one wave per node: lanes 0..2 sweep one axis each, lane 0 decides */
+__global__ __launch_bounds__(64) void k_decide(const LargeNode *nodes, uint32_t nNodes, const BinKeys *gbins, const uint32_t *gcounts, Decision *out) {
+	__shared__ float s_costR[3][CRH_BVH_BINS];
+	__shared__ float s_best[3];
+	__shared__ uint32_t s_bin[3];
+	const uint32_t n = blockIdx.x;
+	if (n >= nNodes) return;
+	const BinKeys *bins = gbins + (size_t)n * 3 * CRH_BVH_BINS;
+	const uint32_t *cnts = gcounts + (size_t)n * 3 * CRH_BVH_BINS;
+	auto box = [&](int ax, uint32_t b) { return binBox(bins[ax * CRH_BVH_BINS + b]); };
+	auto cnt = [&](int ax, uint32_t b) { return cnts[ax * CRH_BVH_BINS + b]; };
+	if (threadIdx.x < 3) {
+		float best; uint32_t bin;
+		sweepAxis((int)threadIdx.x, box, cnt, s_costR[threadIdx.x], best, bin);
+		s_best[threadIdx.x] = best; s_bin[threadIdx.x] = bin;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const LargeNode nd = nodes[n];
+		Decision d;
+		decide(nd.bounds, nd.end - nd.begin, s_best, s_bin, box, cnt, d);
+		out[n] = d;
+	}
+}
+
+/* (3a) per chunk: how many elements sit on the wrong side (bvh.c:95-130 stops exactly at begin + nLeft) */
+__global__ __launch_bounds__(256) void k_count_misplaced(const LargeNode *nodes, const Decision *dec, const Chunk *chunks, const int32_t *prims, const float *centers,
+														 uint32_t *chunkML, uint32_t *chunkMR) {
+	__shared__ uint32_t s_ml, s_mr;
+	if (threadIdx.x == 0) { s_ml = 0; s_mr = 0; }
+	__syncthreads();
+	const Chunk ch = chunks[blockIdx.x];
+	const Decision d = dec[ch.node];
+	if (!d.leaf) {
+		const LargeNode nd = nodes[ch.node];
+		const uint32_t mid = nd.begin + d.nLeft;
+		uint32_t ml = 0, mr = 0;
+		for (uint32_t q = threadIdx.x; q < ch.len; q += blockDim.x) {
+			const uint32_t p = ch.start + q;
+			const bool right = binOf(centers[3 * (size_t)prims[p] + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
+			if (p < mid && right) ++ml;
+			if (p >= mid && !right) ++mr;
+		}
+		if (ml) atomicAdd(&s_ml, ml);
+		if (mr) atomicAdd(&s_mr, mr);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { chunkML[blockIdx.x] = s_ml; chunkMR[blockIdx.x] = s_mr; }
+}
+
+/* (3b) per node: exclusive prefix of its chunks' counts (left-misplaced from the left, right-misplaced from the right) */
+__global__ __launch_bounds__(64) void k_scan_chunks(const uint32_t *nodeChunk0, uint32_t nNodes, uint32_t *chunkML, uint32_t *chunkMR, uint32_t *nodeSwaps) {
+	const uint32_t n = blockIdx.x;
+	if (n >= nNodes || threadIdx.x) return;
+	const uint32_t c0 = nodeChunk0[n], c1 = nodeChunk0[n + 1];
+	uint32_t acc = 0;
+	for (uint32_t c = c0; c < c1; ++c) { const uint32_t v = chunkML[c]; chunkML[c] = acc; acc += v; }
+	uint32_t accR = 0;
+	for (uint32_t c = c1; c > c0; --c) { const uint32_t v = chunkMR[c - 1]; chunkMR[c - 1] = accR; accR += v; }
+	nodeSwaps[n] = acc;        /* == accR: as many left-misplaced as right-misplaced */
+}
+
+/* (3c) per chunk: the k-th left-misplaced position goes to listL[begin + k], the k-th right-misplaced FROM THE RIGHT to listR[begin + k] */
+__global__ __launch_bounds__(256) void k_list_misplaced(const LargeNode *nodes, const Decision *dec, const Chunk *chunks, const int32_t *prims, const float *centers,
+														const uint32_t *chunkML, const uint32_t *chunkMR, uint32_t *listL, uint32_t *listR) {
+	__shared__ uint32_t s_scan[256];
+	const Chunk ch = chunks[blockIdx.x];
+	const Decision d = dec[ch.node];
+	if (d.leaf) return;
+	const LargeNode nd = nodes[ch.node];
+	const uint32_t mid = nd.begin + d.nLeft;
+	/* each thread owns a contiguous run so that ranks follow positions */
+	const uint32_t per = (ch.len + blockDim.x - 1) / blockDim.x;
+	const uint32_t q0 = min(threadIdx.x * per, ch.len), q1 = min(q0 + per, ch.len);
+	uint32_t ml = 0, mr = 0;
+	for (uint32_t q = q0; q < q1; ++q) {
+		const uint32_t p = ch.start + q;
+		const bool right = binOf(centers[3 * (size_t)prims[p] + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
+		if (p < mid && right) ++ml;
+		if (p >= mid && !right) ++mr;
+	}
+	/* exclusive scan of ml (ascending threads) */
+	s_scan[threadIdx.x] = ml;
+	__syncthreads();
+	for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+		const uint32_t v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+		__syncthreads();
+		s_scan[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t kL = chunkML[blockIdx.x] + s_scan[threadIdx.x] - ml;
+	__syncthreads();
+	/* exclusive scan of mr from the right (descending threads) */
+	s_scan[threadIdx.x] = mr;
+	__syncthreads();
+	for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+		const uint32_t v = threadIdx.x + off < blockDim.x ? s_scan[threadIdx.x + off] : 0u;
+		__syncthreads();
+		s_scan[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t kR = chunkMR[blockIdx.x] + s_scan[threadIdx.x];        /* inclusive from the right: rank of this thread's LAST position + 1 ... */
+	for (uint32_t q = q0; q < q1; ++q) {
+		const uint32_t p = ch.start + q;
+		const bool right = binOf(centers[3 * (size_t)prims[p] + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
+		if (p < mid && right) listL[nd.begin + kL++] = p;
+		if (p >= mid && !right) listR[nd.begin + --kR] = p;          /* ... so ascending positions get descending ranks */
+	}
+}
+
+/* (3d) the swaps of bvh.c:121-123, all independent */
+__global__ __launch_bounds__(256) void k_swap(const LargeNode *nodes, const Decision *dec, const Chunk *chunks, const uint32_t *nodeSwaps, const uint32_t *listL, const uint32_t *listR, int32_t *prims) {
+	const Chunk ch = chunks[blockIdx.x];
+	if (dec[ch.node].leaf) return;
+	const LargeNode nd = nodes[ch.node];
+	const uint32_t m = nodeSwaps[ch.node];
+	for (uint32_t q = threadIdx.x; q < ch.len; q += blockDim.x) {
+		const uint32_t k = ch.start + q - nd.begin;
+		if (k >= m) continue;
+		const uint32_t a = listL[nd.begin + k], b = listR[nd.begin + k];
+		const int32_t t = prims[a]; prims[a] = prims[b]; prims[b] = t;
+	}
+}
+
+/* ---- kernel: small phase ------------------------------------------------------------------------------------------------- */
+struct SmallRoot { float bounds[6]; uint32_t begin, end, depth, forceLeaf; uint32_t localOff, pad[3]; };
+
+/* One wave builds one subtree depth-first (left first), exactly like the recursion it replaces. Its nodes go to
+ * local[localOff ...] (a subtree over n primitives has at most max(2n-1, 1) nodes); local index 0 is the subtree root, child
+ * pairs are appended in allocation order, inner nodes point at LOCAL indices. Roots that are leaves by rule (depth limit,
+ * fewer than two primitives, or a large node whose split left nothing on the left: forceLeaf) are emitted directly. */
+__global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t nRoots, int32_t *prims, const float *boxes, const float *centers,
+											  crh_bvh_node *local, uint32_t *localCount) {
+	__shared__ int32_t s_prim[CRH_BVH_SMALL];
+	__shared__ BinKeys s_bins[3 * CRH_BVH_BINS];
+	__shared__ uint32_t s_cnt[3 * CRH_BVH_BINS];
+	__shared__ float s_costR[3][CRH_BVH_BINS];
+	__shared__ float s_best[3];
+	__shared__ uint32_t s_bin[3];
+	__shared__ Decision s_dec;
+	__shared__ uint16_t s_listL[CRH_BVH_SMALL], s_listR[CRH_BVH_SMALL];
+	struct Job { uint32_t node, first, last, depth; };
+	__shared__ Job s_stack[2 * CRH_BVH_MAX_DEPTH + 4];
+	const uint32_t r = blockIdx.x;
+	if (r >= nRoots) return;
+	const uint32_t lane = threadIdx.x;
+	const SmallRoot root = roots[r];
+	const uint32_t base = root.begin, total = root.end - root.begin;
+	crh_bvh_node *out = local + root.localOff;
+	if (root.forceLeaf || root.depth >= CRH_BVH_MAX_DEPTH || total < 2 || total > CRH_BVH_SMALL) {   /* > SMALL only arrives with one of the former */
+		if (lane == 0) {
+			crh_bvh_node n0;
+			memset(&n0, 0, sizeof(n0));
+			for (int k = 0; k < 6; ++k) n0.bounds[k] = root.bounds[k];
+			n0.first = base; n0.count_leaf = (total & 0x3FFFFFFFu) | (1u << 30);
+			out[0] = n0;
+			localCount[r] = 1;
+		}
+		return;
+	}
+	for (uint32_t i = lane; i < total; i += 64) s_prim[i] = prims[base + i];
+	if (lane == 0) {
+		crh_bvh_node n0;
+		memset(&n0, 0, sizeof(n0));
+		for (int k = 0; k < 6; ++k) n0.bounds[k] = root.bounds[k];
+		out[0] = n0;
+		s_stack[0] = Job{0u, 0u, total, root.depth};
+	}
+	__syncthreads();
+	uint32_t sp = 1, used = 1;
+	while (sp) {
+		const Job j = s_stack[--sp];
+		const uint32_t n = j.last - j.first;
+		float bounds[6];
+		for (int k = 0; k < 6; ++k) bounds[k] = out[j.node].bounds[k];
+		bool leaf = (j.depth >= CRH_BVH_MAX_DEPTH || n < 2);                 /* bvh.c:143-146 */
+		if (!leaf) {
+			for (uint32_t i = lane; i < 3 * CRH_BVH_BINS; i += 64) {
+				for (int c = 0; c < 3; ++c) { s_bins[i].lo[c] = CRH_KEY_LO_EMPTY; s_bins[i].hi[c] = CRH_KEY_HI_EMPTY; }
+				s_cnt[i] = 0;
+			}
+			__syncthreads();
+			for (uint32_t q = j.first + lane; q < j.last; q += 64) {         /* bvh.c:158-165 */
+				const int32_t id = s_prim[q];
+				float lo[3], hi[3], ce[3];
+				for (int k = 0; k < 3; ++k) { lo[k] = boxes[6 * (size_t)id + k]; hi[k] = boxes[6 * (size_t)id + 3 + k]; ce[k] = centers[3 * (size_t)id + k]; }
+				for (int ax = 0; ax < 3; ++ax) {
+					const uint32_t b = ax * CRH_BVH_BINS + binOf(ce[ax], bounds[2 * ax], bounds[2 * ax + 1]);
+					for (int k = 0; k < 3; ++k) { atomicMin(&s_bins[b].lo[k], keyLo(lo[k], q)); atomicMax(&s_bins[b].hi[k], keyHi(hi[k], q)); }
+					atomicAdd(&s_cnt[b], 1u);
+				}
+			}
+			__syncthreads();
+			auto box = [&](int ax, uint32_t b) { return binBox(s_bins[ax * CRH_BVH_BINS + b]); };
+			auto cnt = [&](int ax, uint32_t b) { return s_cnt[ax * CRH_BVH_BINS + b]; };
+			if (lane < 3) {
+				float best; uint32_t bin;
+				sweepAxis((int)lane, box, cnt, s_costR[lane], best, bin);
+				s_best[lane] = best; s_bin[lane] = bin;
+			}
+			__syncthreads();
+			if (lane == 0) { Decision d; decide(bounds, n, s_best, s_bin, box, cnt, d); s_dec = d; }
+			__syncthreads();
+			leaf = s_dec.leaf != 0;
+		}
+		if (leaf) {
+			if (lane == 0) { out[j.node].first = base + j.first; out[j.node].count_leaf = (n & 0x3FFFFFFFu) | (1u << 30); }
+			__syncthreads();
+			continue;
+		}
+		const Decision d = s_dec;
+		const uint32_t mid = j.first + d.nLeft;
+		/* bvh.c:95-130: k-th misplaced from the left <-> k-th misplaced from the right */
+		uint32_t kL = 0, kR = 0;
+		for (uint32_t q0 = j.first; q0 < mid; q0 += 64) {
+			const uint32_t q = q0 + lane;
+			const bool mis = q < mid && binOf(centers[3 * (size_t)s_prim[q < mid ? q : j.first] + d.axis], bounds[2 * d.axis], bounds[2 * d.axis + 1]) >= d.split;
+			const unsigned long long m = __ballot(mis);
+			if (mis) s_listL[kL + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)q;
+			kL += (uint32_t)__popcll(m);
+		}
+		for (uint32_t done = 0; mid + done < j.last; done += 64) {           /* from the right end downwards */
+			const uint32_t off = done + lane;
+			const bool in = mid + off < j.last;
+			const uint32_t q = in ? j.last - 1u - off : mid;
+			const bool mis = in && binOf(centers[3 * (size_t)s_prim[q] + d.axis], bounds[2 * d.axis], bounds[2 * d.axis + 1]) < d.split;
+			const unsigned long long m = __ballot(mis);
+			if (mis) s_listR[kR + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)q;
+			kR += (uint32_t)__popcll(m);
+		}
+		__syncthreads();
+		for (uint32_t k = lane; k < kL; k += 64) {
+			const uint32_t a = s_listL[k], b = s_listR[k];
+			const int32_t t = s_prim[a]; s_prim[a] = s_prim[b]; s_prim[b] = t;
+		}
+		if (lane == 0) {                                                     /* bvh.c:219-238 */
+			crh_bvh_node l, rr;
+			memset(&l, 0, sizeof(l)); memset(&rr, 0, sizeof(rr));
+			for (int k = 0; k < 6; ++k) { l.bounds[k] = d.childL[k]; rr.bounds[k] = d.childR[k]; }
+			out[used] = l; out[used + 1] = rr;
+			out[j.node].first = used;
+			out[j.node].count_leaf = 0;
+			s_stack[sp] = Job{used + 1, mid, j.last, j.depth + 1};          /* right waits ... */
+			s_stack[sp + 1] = Job{used, j.first, mid, j.depth + 1};         /* ... left is built first */
+		}
+		sp += 2; used += 2;
+		__syncthreads();
+	}
+	for (uint32_t i = lane; i < total; i += 64) prims[base + i] = s_prim[i];
+	if (lane == 0) localCount[r] = used;
+}
+
+/* final numbering: subtree r's local node 0 is global node rootId[r]; local node j >= 1 is global node firstId[r] + j - 1 */
+__global__ __launch_bounds__(256) void k_emit(const SmallRoot *roots, uint32_t nRoots, const uint32_t *localCount, const uint32_t *rootId, const uint32_t *firstId,
+											  const crh_bvh_node *local, crh_bvh_node *nodes) {
+	for (uint32_t r = blockIdx.x; r < nRoots; r += gridDim.x) {
+		const crh_bvh_node *src = local + roots[r].localOff;
+		const uint32_t cnt = localCount[r], first = firstId[r];
+		for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+			crh_bvh_node n = src[j];
+			if (!((n.count_leaf >> 30) & 1u)) n.first = first + n.first - 1u;
+			nodes[j == 0 ? rootId[r] : first + j - 1u] = n;
+		}
+	}
+}
+
+}  // namespace crhb
+
+/* ---- host driver -------------------------------------------------------------------------------------------------------- */
+using namespace crhb;
+
+namespace {
+struct UpperNode {
+	float bounds[6];
+	uint32_t begin, end, depth;
+	int32_t left = -1, right = -1;     /* upper-tree indices of the children when split */
+	int32_t small = -1;                /* index into the small-root list when handed to the small phase */
+	uint32_t id = 0;                   /* final node index */
+};
+template <class T> struct DevBuf {
+	T *p = nullptr;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+#define BVH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return crh_internal_fail(CRH_ERR_HIP, (std::string("crh_bvh_build_triangles: ") + #expr + ": " + hipGetErrorString(e_)).c_str()); } while (0)
+}  // namespace
+
+extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint32_t poly_count, const float *vertices, uint64_t vertex_count,
+										crh_bvh_node *nodes_out, int32_t *prim_indices_out, uint32_t *node_count_out, crh_bvh_build_stats *stats) {
+	if (!ctx || !node_count_out || (poly_count && (!polys || !vertices || !nodes_out || !prim_indices_out)))
+		return crh_internal_fail(CRH_ERR_INVALID, "crh_bvh_build_triangles: NULL argument");
+	if (stats) memset(stats, 0, sizeof(*stats));
+	if (poly_count < 1) { *node_count_out = 0; return CRH_OK; }                               /* bvh.c:250-256 */
+	if (poly_count >= 0x40000000u) return crh_internal_fail(CRH_ERR_UNSUPPORTED, "crh_bvh_build_triangles: more than 2^30 primitives");
+	for (uint32_t i = 0; i < poly_count; ++i)
+		for (int k = 0; k < 3; ++k)
+			if (polys[i].v[k] < 0 || (uint64_t)polys[i].v[k] >= vertex_count) return crh_internal_fail(CRH_ERR_INVALID, "crh_bvh_build_triangles: vertex index out of range");
+	BVH_TRY(hipSetDevice(crh_internal_device(ctx)));
+	hipStream_t st = (hipStream_t)crh_internal_stream(ctx);
+	const auto t0 = std::chrono::steady_clock::now();
+	const uint32_t N = poly_count;
+
+	DevBuf<crh_poly> dPolys; DevBuf<float> dVerts, dBoxes, dCenters; DevBuf<int32_t> dPrims; DevBuf<unsigned long long> dRootKeys;
+	DevBuf<uint32_t> dListL, dListR; DevBuf<crh_bvh_node> dLocal, dNodes;
+	BVH_TRY(dPolys.alloc(N)); BVH_TRY(dVerts.alloc((size_t)vertex_count * 3)); BVH_TRY(dBoxes.alloc((size_t)N * 6)); BVH_TRY(dCenters.alloc((size_t)N * 3));
+	BVH_TRY(dPrims.alloc(N)); BVH_TRY(dRootKeys.alloc(6)); BVH_TRY(dListL.alloc(N)); BVH_TRY(dListR.alloc(N));
+	BVH_TRY(dNodes.alloc(2 * (size_t)N));
+	BVH_TRY(hipMemcpyAsync(dPolys.p, polys, (size_t)N * sizeof(crh_poly), hipMemcpyHostToDevice, st));
+	BVH_TRY(hipMemcpyAsync(dVerts.p, vertices, (size_t)vertex_count * 3 * sizeof(float), hipMemcpyHostToDevice, st));
+	const unsigned long long rootInit[6] = {CRH_KEY_LO_EMPTY, CRH_KEY_LO_EMPTY, CRH_KEY_LO_EMPTY, CRH_KEY_HI_EMPTY, CRH_KEY_HI_EMPTY, CRH_KEY_HI_EMPTY};
+	BVH_TRY(hipMemcpyAsync(dRootKeys.p, rootInit, sizeof(rootInit), hipMemcpyHostToDevice, st));
+	BVH_TRY(hipStreamSynchronize(st));
+	const auto t1 = std::chrono::steady_clock::now();
+
+	hipLaunchKernelGGL(k_prepare, dim3((N + 255) / 256), dim3(256), 0, st, dPolys.p, dVerts.p, N, dBoxes.p, dCenters.p, dPrims.p, dRootKeys.p);
+	unsigned long long rootKeys[6];
+	BVH_TRY(hipMemcpyAsync(rootKeys, dRootKeys.p, sizeof(rootKeys), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipStreamSynchronize(st));
+
+	std::vector<UpperNode> upper;
+	upper.reserve(1024);
+	{
+		UpperNode r;
+		for (int k = 0; k < 3; ++k) { r.bounds[2 * k] = keyValue(rootKeys[k]); r.bounds[2 * k + 1] = keyValue(rootKeys[3 + k]); }
+		r.begin = 0; r.end = N; r.depth = 0;
+		upper.push_back(r);
+	}
+	std::vector<SmallRoot> smallRoots;
+	std::vector<uint32_t> level;          /* upper indices of the large nodes of the current level */
+	size_t localNodes = 0;
+	auto route = [&](uint32_t u, bool forceLeaf) {   /* a new node is either large (next level) or the root of a wave-built subtree */
+		const UpperNode &n = upper[u];
+		const uint32_t cnt = n.end - n.begin;
+		if (!forceLeaf && cnt > CRH_BVH_SMALL && n.depth < CRH_BVH_MAX_DEPTH) { level.push_back(u); return; }
+		SmallRoot s;
+		memset(&s, 0, sizeof(s));
+		memcpy(s.bounds, n.bounds, sizeof(s.bounds));
+		s.begin = n.begin; s.end = n.end; s.depth = n.depth; s.forceLeaf = forceLeaf ? 1u : 0u;
+		s.localOff = (uint32_t)localNodes;
+		localNodes += (cnt > CRH_BVH_SMALL || cnt < 2) ? 1 : 2 * (size_t)cnt - 1;
+		upper[u].small = (int32_t)smallRoots.size();
+		smallRoots.push_back(s);
+	};
+	route(0, false);
+
+	uint32_t levels = 0;
+	std::vector<uint32_t> level_leaves;
+	DevBuf<LargeNode> dLevel; DevBuf<Chunk> dChunks; DevBuf<BinKeys> dBins; DevBuf<uint32_t> dCounts, dChunkML, dChunkMR, dNodeChunk0, dNodeSwaps; DevBuf<Decision> dDec;
+	size_t capNodes = 0, capChunks = 0;
+	while (!level.empty()) {
+		++levels;
+		const std::vector<uint32_t> cur = level;
+		level.clear();
+		const uint32_t nNodes = (uint32_t)cur.size();
+		std::vector<LargeNode> hNodes(nNodes);
+		std::vector<Chunk> hChunks;
+		std::vector<uint32_t> hChunk0(nNodes + 1);
+		for (uint32_t i = 0; i < nNodes; ++i) {
+			const UpperNode &u = upper[cur[i]];
+			memcpy(hNodes[i].bounds, u.bounds, sizeof(u.bounds));
+			hNodes[i].begin = u.begin; hNodes[i].end = u.end;
+			hChunk0[i] = (uint32_t)hChunks.size();
+			for (uint32_t s = u.begin; s < u.end; s += CRH_BVH_CHUNK) hChunks.push_back(Chunk{i, s, std::min(CRH_BVH_CHUNK, u.end - s), 0u});
+		}
+		hChunk0[nNodes] = (uint32_t)hChunks.size();
+		const uint32_t nChunks = (uint32_t)hChunks.size();
+		if (nNodes > capNodes) {
+			capNodes = (size_t)nNodes * 2;
+			dLevel = DevBuf<LargeNode>(); dBins = DevBuf<BinKeys>(); dCounts = DevBuf<uint32_t>(); dDec = DevBuf<Decision>(); dNodeChunk0 = DevBuf<uint32_t>(); dNodeSwaps = DevBuf<uint32_t>();
+			BVH_TRY(dLevel.alloc(capNodes)); BVH_TRY(dBins.alloc(capNodes * 3 * CRH_BVH_BINS)); BVH_TRY(dCounts.alloc(capNodes * 3 * CRH_BVH_BINS));
+			BVH_TRY(dDec.alloc(capNodes)); BVH_TRY(dNodeChunk0.alloc(capNodes + 1)); BVH_TRY(dNodeSwaps.alloc(capNodes));
+		}
+		if (nChunks > capChunks) {
+			capChunks = (size_t)nChunks * 2;
+			dChunks = DevBuf<Chunk>(); dChunkML = DevBuf<uint32_t>(); dChunkMR = DevBuf<uint32_t>();
+			BVH_TRY(dChunks.alloc(capChunks)); BVH_TRY(dChunkML.alloc(capChunks)); BVH_TRY(dChunkMR.alloc(capChunks));
+		}
+		BVH_TRY(hipMemcpyAsync(dLevel.p, hNodes.data(), nNodes * sizeof(LargeNode), hipMemcpyHostToDevice, st));
+		BVH_TRY(hipMemcpyAsync(dChunks.p, hChunks.data(), nChunks * sizeof(Chunk), hipMemcpyHostToDevice, st));
+		BVH_TRY(hipMemcpyAsync(dNodeChunk0.p, hChunk0.data(), (nNodes + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+		const uint32_t nBins = nNodes * 3 * CRH_BVH_BINS;
+		hipLaunchKernelGGL(k_init_bins, dim3((nBins + 255) / 256), dim3(256), 0, st, dBins.p, dCounts.p, nBins);
+		hipLaunchKernelGGL(k_bin, dim3(nChunks), dim3(256), 0, st, dLevel.p, dChunks.p, dPrims.p, dBoxes.p, dCenters.p, dBins.p, dCounts.p);
+		hipLaunchKernelGGL(k_decide, dim3(nNodes), dim3(64), 0, st, dLevel.p, nNodes, dBins.p, dCounts.p, dDec.p);
+		hipLaunchKernelGGL(k_count_misplaced, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dPrims.p, dCenters.p, dChunkML.p, dChunkMR.p);
+		hipLaunchKernelGGL(k_scan_chunks, dim3(nNodes), dim3(64), 0, st, dNodeChunk0.p, nNodes, dChunkML.p, dChunkMR.p, dNodeSwaps.p);
+		hipLaunchKernelGGL(k_list_misplaced, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dPrims.p, dCenters.p, dChunkML.p, dChunkMR.p, dListL.p, dListR.p);
+		hipLaunchKernelGGL(k_swap, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dNodeSwaps.p, dListL.p, dListR.p, dPrims.p);
+		BVH_TRY(hipGetLastError());
+		std::vector<Decision> hDec(nNodes);
+		BVH_TRY(hipMemcpyAsync(hDec.data(), dDec.p, nNodes * sizeof(Decision), hipMemcpyDeviceToHost, st));
+		BVH_TRY(hipStreamSynchronize(st));
+		for (uint32_t i = 0; i < nNodes; ++i) {
+			const uint32_t u = cur[i];
+			const Decision &d = hDec[i];
+			if (d.leaf) {          /* bvh.c:239-241: nothing ended up on the left — the node stays a leaf whatever its size */
+				level_leaves.push_back(u);
+				continue;
+			}
+			UpperNode l, r;
+			memcpy(l.bounds, d.childL, sizeof(l.bounds)); memcpy(r.bounds, d.childR, sizeof(r.bounds));
+			l.begin = upper[u].begin; l.end = upper[u].begin + d.nLeft; l.depth = upper[u].depth + 1;
+			r.begin = l.end; r.end = upper[u].end; r.depth = l.depth;
+			const uint32_t li = (uint32_t)upper.size();
+			upper.push_back(l); upper.push_back(r);
+			upper[u].left = (int32_t)li; upper[u].right = (int32_t)li + 1;
+			route(li, false); route(li + 1, false);
+		}
+		for (uint32_t u : level_leaves) route(u, true);
+		level_leaves.clear();
+	}
+
+	/* small phase: one wave per subtree */
+	const uint32_t nRoots = (uint32_t)smallRoots.size();
+	DevBuf<SmallRoot> dRoots; DevBuf<uint32_t> dLocalCount, dRootId, dFirstId;
+	BVH_TRY(dLocal.alloc(localNodes)); BVH_TRY(dRoots.alloc(nRoots)); BVH_TRY(dLocalCount.alloc(nRoots)); BVH_TRY(dRootId.alloc(nRoots)); BVH_TRY(dFirstId.alloc(nRoots));
+	BVH_TRY(hipMemcpyAsync(dRoots.p, smallRoots.data(), nRoots * sizeof(SmallRoot), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_small, dim3(nRoots), dim3(64), 0, st, dRoots.p, nRoots, dPrims.p, dBoxes.p, dCenters.p, dLocal.p, dLocalCount.p);
+	BVH_TRY(hipGetLastError());
+	std::vector<uint32_t> localCount(nRoots);
+	BVH_TRY(hipMemcpyAsync(localCount.data(), dLocalCount.p, nRoots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipStreamSynchronize(st));
+
+	/* numbering (bvh.c:221-223, 237-238): depth-first, a pair per split, left subtree before the right one */
+	std::vector<uint32_t> rootId(nRoots), firstId(nRoots);
+	uint32_t next = 1;
+	{
+		std::vector<uint32_t> stack{0u};
+		upper[0].id = 0;
+		while (!stack.empty()) {
+			const uint32_t u = stack.back();
+			stack.pop_back();
+			UpperNode &n = upper[u];
+			if (n.small >= 0) {
+				rootId[n.small] = n.id;
+				firstId[n.small] = next;
+				next += localCount[n.small] - 1;
+				continue;
+			}
+			upper[n.left].id = next; upper[n.right].id = next + 1;
+			next += 2;
+			stack.push_back((uint32_t)n.right);
+			stack.push_back((uint32_t)n.left);
+		}
+	}
+	const uint32_t nodeCount = next;
+	BVH_TRY(hipMemcpyAsync(dRootId.p, rootId.data(), nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	BVH_TRY(hipMemcpyAsync(dFirstId.p, firstId.data(), nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_emit, dim3(std::min<uint32_t>(nRoots, 65535u)), dim3(256), 0, st, dRoots.p, nRoots, dLocalCount.p, dRootId.p, dFirstId.p, dLocal.p, dNodes.p);
+	BVH_TRY(hipGetLastError());
+	BVH_TRY(hipStreamSynchronize(st));
+	const auto t2 = std::chrono::steady_clock::now();
+	BVH_TRY(hipMemcpyAsync(nodes_out, dNodes.p, (size_t)nodeCount * sizeof(crh_bvh_node), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipMemcpyAsync(prim_indices_out, dPrims.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipStreamSynchronize(st));
+	for (const UpperNode &n : upper) {            /* the split nodes of the upper tree (a few thousand) are written by the host */
+		if (n.small >= 0) continue;
+		crh_bvh_node o;
+		memset(&o, 0, sizeof(o));
+		memcpy(o.bounds, n.bounds, sizeof(o.bounds));
+		o.first = upper[n.left].id;
+		nodes_out[n.id] = o;
+	}
+	const auto t3 = std::chrono::steady_clock::now();
+	*node_count_out = nodeCount;
+	if (stats) {
+		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		stats->upload_ms = ms(t0, t1); stats->build_ms = ms(t1, t2); stats->download_ms = ms(t2, t3);
+		stats->levels = levels; stats->upper_nodes = (uint32_t)upper.size(); stats->subtrees = nRoots;
+	}
+	return CRH_OK;
+}

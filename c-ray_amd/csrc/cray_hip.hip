@@ -28,6 +28,7 @@
 #include "cray_hip.h"
 #include "pt_device.h"
 #include "scene_compile.h"
+#include "ctx_access.h"
 
 using namespace crh;
 
@@ -967,6 +968,10 @@ int crh_debug_wave_stats(crh_ctx *c, uint64_t *out, uint32_t max_waves) {
 	HIP_TRY(hipMemcpy(out, c->dWaveStats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	return (int)n;
 }
+
+int crh_internal_device(crh_ctx *c) { return c->device; }
+void *crh_internal_stream(crh_ctx *c) { return (void *)c->stream; }
+int crh_internal_fail(int code, const char *message) { return fail(code, message); }
 
 int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits_host) {
 	if (!c || (!rays_host && n) || (!hits_host && n)) return fail(CRH_ERR_INVALID, "crh_trace_rays: NULL argument");

@@ -1,0 +1,8 @@
+/* ctx_access.h — what the other translation units of libcray_hip.so may know about a crh_ctx (hidden symbols). */
+#pragma once
+#include "cray_hip.h"
+extern "C" {
+__attribute__((visibility("hidden"))) int crh_internal_device(crh_ctx *ctx);
+__attribute__((visibility("hidden"))) void *crh_internal_stream(crh_ctx *ctx);
+__attribute__((visibility("hidden"))) int crh_internal_fail(int code, const char *message);   /* sets crh_last_error(), returns code */
+}

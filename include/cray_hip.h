@@ -267,6 +267,19 @@ int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);
 int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out3);
 
+/* SURVEY.md 8(f) row 1 — replaces buildBottomLevelBvh() (src/accelerators/bvh.c:299-301 -> buildBvhGeneric, bvh.c:245-287,
+ * with getPolyBBoxAndCenter, bvh.c:289-297): the reference's binned-SAH builder on the GPU. The result is THE reference's
+ * tree: nodes_out[0 .. *node_count_out) equal its struct bvhNode array (bounds bit for bit, child / first-prim indices,
+ * leaf flags and leaf sizes; inner nodes carry primCount 0 where the reference leaves heap garbage) and
+ * prim_indices_out[0 .. poly_count) equals bvh->primIndices. Host pointers in and out; polys[i].v[] index `vertices`
+ * (3 floats each). nodes_out needs room for 2 * poly_count - 1 nodes. poly_count == 0 gives the empty BVH (node count 0). */
+typedef struct crh_bvh_build_stats {
+	double   upload_ms, build_ms, download_ms;   /* host->device copies; every kernel + the host's level bookkeeping; results back */
+	uint32_t levels, upper_nodes, subtrees, pad;  /* level-synchronous passes; nodes kept by the host; subtrees built by one wave each */
+} crh_bvh_build_stats;
+int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint32_t poly_count, const float *vertices, uint64_t vertex_count,
+                            crh_bvh_node *nodes_out, int32_t *prim_indices_out, uint32_t *node_count_out, crh_bvh_build_stats *stats /* may be NULL */);
+
 /* Replaces "the CPU reads struct world directly": copies the flattened scene to HBM, derives the
  * device-side acceleration layout (leaf-ordered prepared triangles) and validates the node graph. */
 int crh_scene_upload(crh_ctx *ctx, const crh_scene_desc *scene);

@@ -46,6 +46,10 @@ def lib():
         L.oracle_sampler_draws.restype = None
         L.oracle_camera_ray.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_camera_ray.restype = None
+        L.orc_bvh_triangle_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_bvh_triangle_bounds.restype = None
+        L.orc_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_bvh_build.restype = C.c_int
         L.crh_blob_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(abi.SceneDesc)), C.POINTER(abi.BlobPrefs)]
         L.crh_blob_load.restype = C.c_int
         L.crh_blob_free.argtypes = [C.POINTER(abi.SceneDesc)]
@@ -121,3 +125,18 @@ def camera_ray(scene, x, y, pass_, max_passes):
     out = np.zeros(6, dtype=np.float32)
     lib().oracle_camera_ray(scene.ptr, x, y, pass_, max_passes, out.ctypes.data)
     return out
+
+
+def bvh_build_triangles(polys_ptr, vertices_ptr, count):
+    """Restated reference builder (bvh.c:87-316) over `count` triangles: (nodes uint32[n, 8], prim order int32[count])."""
+    import numpy as np
+    boxes = np.empty((max(count, 1), 6), np.float32)
+    centers = np.empty((max(count, 1), 3), np.float32)
+    lib().orc_bvh_triangle_bounds(polys_ptr, vertices_ptr, count, boxes.ctypes.data, centers.ctypes.data)
+    nodes = np.zeros((max(2 * count - 1, 1), 8), np.uint32)
+    prims = np.zeros(max(count, 1), np.int32)
+    n = C.c_uint32(0)
+    rc = lib().orc_bvh_build(boxes.ctypes.data, centers.ctypes.data, count, nodes.ctypes.data, prims.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise MemoryError("orc_bvh_build")
+    return nodes[:n.value], prims[:count]

@@ -1,5 +1,14 @@
 /* Wrapper TU: compiles the UNMODIFIED reference src/accelerators/bvh.c (builder + traversal) and
- * appends read-only accessors for the file-private `struct bvh` (bvh.c:44-48). See describe.h. */
+ * appends read-only accessors for the file-private `struct bvh` (bvh.c:44-48). See describe.h.
+ *
+ * With -DCRH_GPU_BVH (the c-ray-hip host; NOT the oracle's crh-flatten, whose blobs must stay the reference's own
+ * output) buildBottomLevelBvh() (bvh.c:299-301) is replaced by the GPU builder behind crh_bvh_build_triangles()
+ * (SURVEY.md 8(f) row 1): same struct bvh out, same tree bit for bit, one mutex because the reference builds every
+ * mesh on its own thread (scene.c:50-78) and a crh_ctx belongs to one thread at a time. The reference's function
+ * stays in the object under another name; nothing calls it. */
+#ifdef CRH_GPU_BVH
+#define buildBottomLevelBvh crh_reference_buildBottomLevelBvh
+#endif
 #include "accelerators/bvh.c"
 #include "describe.h"
 
@@ -8,3 +17,32 @@ const int  *crh_access_bvh_prims(const struct bvh *b) { return b ? b->primIndice
 unsigned    crh_access_bvh_node_count(const struct bvh *b) { return b ? b->nodeCount : 0; }
 
 _Static_assert(sizeof(struct bvhNode) == sizeof(crh_bvh_node), "crh_bvh_node must mirror struct bvhNode (32 B)");
+
+#ifdef CRH_GPU_BVH
+#undef buildBottomLevelBvh
+#include <pthread.h>
+#include "datatypes/vertexbuffer.h"
+#include "utils/logging.h"
+_Static_assert(sizeof(struct poly) == sizeof(crh_poly), "crh_poly must mirror struct poly (40 B)");
+
+static pthread_mutex_t g_bvh_lock = PTHREAD_MUTEX_INITIALIZER;
+static crh_ctx *g_bvh_ctx;
+
+struct bvh *buildBottomLevelBvh(struct poly *polys, unsigned count) {
+	struct bvh *bvh = malloc(sizeof(*bvh));
+	bvh->nodeCount = 0; bvh->nodes = NULL; bvh->primIndices = NULL;
+	if (count < 1) return bvh;                                  /* bvh.c:250-256 */
+	bvh->nodes = malloc(sizeof(struct bvhNode) * (2 * (size_t)count - 1));
+	bvh->primIndices = malloc(sizeof(int) * count);
+	pthread_mutex_lock(&g_bvh_lock);
+	int rc = CRH_OK;
+	if (!g_bvh_ctx) rc = crh_context_create(0, NULL, &g_bvh_ctx);
+	if (rc == CRH_OK)
+		rc = crh_bvh_build_triangles(g_bvh_ctx, (const crh_poly *)polys, count, (const float *)g_vertices, (uint64_t)vertexCount,
+		                             (crh_bvh_node *)bvh->nodes, bvh->primIndices, &bvh->nodeCount, NULL);
+	pthread_mutex_unlock(&g_bvh_lock);
+	if (rc != CRH_OK) logr(error, "c-ray-hip: GPU BVH build failed (%i): %s\n", rc, crh_last_error());   /* exits: no CPU path here */
+	bvh->nodes = realloc(bvh->nodes, sizeof(struct bvhNode) * bvh->nodeCount);   /* bvh.c:283 */
+	return bvh;
+}
+#endif

@@ -153,6 +153,47 @@ def test_error_paths(pkg, ctx, golden_blob):
     fresh.close()
 
 
+def test_edge_cases_empty_ragged_single_pixel(pkg, ctx, oracle, manifest, golden_blob):
+    """Empty tile list, 1x1 regions, a ragged 3-tile cover, and a scene whose TLAS is empty (every ray leaves the scene)."""
+    api = pkg.api
+    m = manifest["glowmetal"]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob("glowmetal"), w, h, s, b)
+    # nothing to do
+    ctx.render_tiles(fb, w, h, s, b, [])
+    assert np.array_equal(ctx.download(fb, w, h), full)
+    # single pixels (first, last, middle) and single rows / columns reproduce the full frame's values
+    ctx.clear(fb, w, h)
+    regions = [(0, 0, 1, 1), (w - 1, h - 1, w, h), (w // 2, h // 2, w // 2 + 1, h // 2 + 1), (0, 3, w, 4), (5, 0, 6, h)]
+    for r in regions:
+        ctx.render_region(fb, w, h, s, b, region=r)
+    img = ctx.download(fb, w, h)
+    mask = np.zeros((h, w), bool)
+    for x0, y0, x1, y1 in regions:
+        mask[h - y1:h - y0, x0:x1] = True          # framebuffer rows are stored top-down (texture.c:24-28)
+    assert np.array_equal(img[mask], full[mask]) and not img[~mask].any()
+    # ragged cover: three tiles of unequal shape, one of them a single column
+    ctx.clear(fb, w, h)
+    ctx.reset_counters()
+    ctx.render_tiles(fb, w, h, s, b, [(0, 0, w - 1, h // 3), (0, h // 3, w - 1, h), (w - 1, 0, w, h)])
+    assert np.array_equal(ctx.download(fb, w, h), full)
+    assert ctx.counters() == cnt_full
+    # a world without instances: the TLAS has no nodes (bvh.c:362-365), every path is one ray into the background
+    scene = api.Scene(golden_blob("glowmetal"))
+    oscene = oracle.OracleScene(golden_blob("glowmetal"))
+    for d in (scene.desc, oscene.desc):
+        d.instance_count = 0; d.tlas_node_count = 0; d.tlas_prim_count = 0
+    ctx.upload(scene)
+    ctx.clear(fb, w, h)
+    ctx.reset_counters()
+    ctx.render_region(fb, w, h, s, b)
+    img, cnt = ctx.download(fb, w, h), ctx.counters()
+    ref, ocnt = oracle.render(oscene, w, h, s, b)
+    assert cnt["rays"] == cnt["paths"] == ocnt["rays"] == w * h * s and cnt["node_tests"] == 0
+    st = image_stats(img, ref)
+    assert st["rmse"] <= 1e-4 and st["frac_gt_1e-3"] == 0.0, st
+
+
 def test_full_size_properties_cfg2(pkg, ctx, oracle):
     """BASELINE.json configs[1] at full resolution (needs scenes/_built/cfg2_hdr.blob, made by build()):
     deterministic, tile decomposition exact, ray count within 0.2 % of the oracle, image within tolerance —

@@ -30,6 +30,8 @@
 #include <float.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <chrono>
 #include <string>
@@ -110,58 +112,104 @@ struct Decision {
 	float childL[6], childR[6];              /* {minx,maxx,miny,maxy,minz,maxz} like bvhNode.bounds */
 };
 
-/* The sweeps + decision of one node from its bins. `box(ax, b)` / `cnt(ax, b)` read bin b of axis ax. Serial (it is 3 x 62
- * dependent steps); the callers run the three axes on three lanes and the rest on one. */
-template <class GetBox, class GetCnt>
-__host__ __device__ inline void sweepAxis(int ax, GetBox box, GetCnt cnt, float *costR /* [32] scratch */, float &bestCost, uint32_t &bestBin) {
-	Box acc;
-	uint32_t n = 0;
-	boxReset(acc);
-	for (uint32_t b = CRH_BVH_BINS; b > 1; --b) {                        /* bvh.c:170-177 */
-		n += cnt(ax, b - 1);
-		boxGrow(acc, box(ax, b - 1));
-		costR[b - 1] = n * boxHalfArea(acc);
-	}
-	boxReset(acc);
-	n = 0;
-	bestCost = FLT_MAX; bestBin = 1;
-	for (uint32_t b = 0; b < CRH_BVH_BINS - 1; ++b) {                    /* bvh.c:180-191 */
-		n += cnt(ax, b);
-		boxGrow(acc, box(ax, b));
-		const float cost = n * boxHalfArea(acc) + costR[b + 1];
-		if (cost < bestCost) { bestBin = b + 1; bestCost = cost; }
-	}
+/* ---- the sweeps + decision of one node, by one wave -------------------------------------------------------------------
+ * bvh.c:170-191 are folds over the 32 bins in a fixed order; folds with pickLo / pickHi are associative as long as the operand
+ * order is kept (on a tie the later operand wins), so they are inclusive scans: lane b (b = lane & 31; both halves of the
+ * wave compute the same) holds bin b and combines with lane b -/+ 1, 2, 4, 8, 16. */
+struct LaneBin { float lo[3], hi[3]; uint32_t n; };
+__device__ inline LaneBin binJoin(const LaneBin &earlier, const LaneBin &later) {
+	LaneBin r;
+	for (int k = 0; k < 3; ++k) { r.lo[k] = pickLo(earlier.lo[k], later.lo[k]); r.hi[k] = pickHi(earlier.hi[k], later.hi[k]); }
+	r.n = earlier.n + later.n;
+	return r;
 }
-template <class GetBox, class GetCnt>
-__host__ __device__ inline void decide(const float *bounds, uint32_t n, const float *bestCost, const uint32_t *bestBin, GetBox box, GetCnt cnt, Decision &d) {
+__device__ inline LaneBin binFrom(const LaneBin &v, int srcBin) {        /* the value lane `srcBin` of this half holds */
+	LaneBin r;
+	for (int k = 0; k < 3; ++k) { r.lo[k] = __shfl(v.lo[k], srcBin, 32); r.hi[k] = __shfl(v.hi[k], srcBin, 32); }
+	r.n = __shfl(v.n, srcBin, 32);
+	return r;
+}
+__device__ inline float binHalfArea(const LaneBin &v) {
+	const float ex = v.hi[0] - v.lo[0], ey = v.hi[1] - v.lo[1], ez = v.hi[2] - v.lo[2];
+	return ex * (ey + ez) + ey * ez;                                     /* bbox.h:25-28 */
+}
+/* fold(bin 0, ..., bin b) in ascending order */
+__device__ inline LaneBin scanAscPrefix(LaneBin v, int b) {
+	for (int off = 1; off < CRH_BVH_BINS; off <<= 1) { const LaneBin o = binFrom(v, (b - off) & 31); if (b >= off) v = binJoin(o, v); }
+	return v;
+}
+/* fold(bin 31, bin 30, ..., bin b) — the right-to-left sweep's order (bvh.c:170-177) */
+__device__ inline LaneBin scanDescSuffix(LaneBin v, int b) {
+	for (int off = 1; off < CRH_BVH_BINS; off <<= 1) { const LaneBin o = binFrom(v, (b + off) & 31); if (b + off < CRH_BVH_BINS) v = binJoin(o, v); }
+	return v;
+}
+/* fold(bin b, bin b+1, ..., bin 31) in ascending order — the right child's box (bvh.c:231-232) */
+__device__ inline LaneBin scanAscSuffix(LaneBin v, int b) {
+	for (int off = 1; off < CRH_BVH_BINS; off <<= 1) { const LaneBin o = binFrom(v, (b + off) & 31); if (b + off < CRH_BVH_BINS) v = binJoin(v, o); }
+	return v;
+}
+
+/* All 64 lanes call this with the node's 3 x 32 bins readable through bins / cnts (LDS or global). Returns bvh.c:148-233's
+ * outcome in every lane. */
+__device__ inline Decision waveDecide(const BinKeys *bins, const uint32_t *cnts, const float *bounds, uint32_t n) {
+	const int b = (int)(threadIdx.x & 31u);
+	float bestCost[3];
+	uint32_t bestBin[3];
+	LaneBin mine[3];
+	for (int ax = 0; ax < 3; ++ax) {
+		const BinKeys k = bins[ax * CRH_BVH_BINS + b];
+		for (int c = 0; c < 3; ++c) { mine[ax].lo[c] = keyValue(k.lo[c]); mine[ax].hi[c] = keyValue(k.hi[c]); }
+		mine[ax].n = cnts[ax * CRH_BVH_BINS + b];
+		const LaneBin right = scanDescSuffix(mine[ax], b);                /* bvh.c:170-177: bins[b].cost for b >= 1 */
+		const float costR = right.n * binHalfArea(right);
+		const LaneBin left = scanAscPrefix(mine[ax], b);                  /* bvh.c:180-191 */
+		const float costRnext = __shfl(costR, (b + 1) & 31, 32);
+		const float cost = left.n * binHalfArea(left) + costRnext;
+		/* first b in 0..30 with the smallest cost below FLT_MAX (strict <, NaN never wins); none -> (FLT_MAX, bin 1) */
+		float c = (b <= 30 && cost < FLT_MAX) ? cost : __builtin_inff();
+		int at = b;
+		for (int off = 16; off > 0; off >>= 1) {
+			const float c2 = __shfl_xor(c, off, 32);
+			const int at2 = __shfl_xor(at, off, 32);
+			if (c2 < c || (c2 == c && at2 < at)) { c = c2; at = at2; }
+		}
+		if (c < FLT_MAX) { bestCost[ax] = c; bestBin[ax] = (uint32_t)at + 1u; }
+		else { bestCost[ax] = FLT_MAX; bestBin[ax] = 1u; }
+	}
+	Decision d;
 	uint32_t ax = 0;                                                     /* bvh.c:195-197 */
 	if (bestCost[1] < bestCost[0]) ax = 1;
 	if (bestCost[2] < bestCost[ax]) ax = 2;
 	uint32_t split = bestBin[ax];
+	const LaneBin own = ax == 0 ? mine[0] : (ax == 1 ? mine[1] : mine[2]);
+	const LaneBin left = scanAscPrefix(own, b);
 	Box self;
 	for (int k = 0; k < 3; ++k) { self.lo[k] = bounds[2 * k]; self.hi[k] = bounds[2 * k + 1]; }
 	const float leafCost = boxHalfArea(self) * (n - 1.5f);               /* bvh.c:200 */
 	d.leaf = 0;
 	if (bestCost[ax] > leafCost) {
-		if (n > CRH_BVH_MAX_LEAF) {                                      /* bvh.c:202-211 */
-			uint32_t seen = 0, closest = n;
-			for (uint32_t b = 0; b < CRH_BVH_BINS - 1; ++b) {
-				seen += cnt(ax, b);
-				const int diff = (int)n / 2 - (int)seen;
-				const uint32_t off = (uint32_t)(diff < 0 ? -diff : diff);
-				if (off < closest) { closest = off; split = b + 1; }
+		if (n > CRH_BVH_MAX_LEAF) {                                      /* bvh.c:202-211: first bin boundary nearest the median, if nearer than n */
+			const int diff = (int)n / 2 - (int)left.n;
+			uint32_t off = (b <= 30) ? (uint32_t)(diff < 0 ? -diff : diff) : 0xFFFFFFFFu;
+			int at = b;
+			for (int sh = 16; sh > 0; sh >>= 1) {
+				const uint32_t o2 = __shfl_xor(off, sh, 32);
+				const int at2 = __shfl_xor(at, sh, 32);
+				if (o2 < off || (o2 == off && at2 < at)) { off = o2; at = at2; }
 			}
+			if (off < n) split = (uint32_t)at + 1u;
 		} else d.leaf = 1;
 	}
 	d.axis = ax; d.split = split;
-	uint32_t nLeft = 0;
-	Box l, r;
-	boxReset(l); boxReset(r);
-	for (uint32_t b = 0; b < split; ++b) { nLeft += cnt(ax, b); boxGrow(l, box(ax, b)); }              /* bvh.c:226-233 */
-	for (uint32_t b = split; b < CRH_BVH_BINS; ++b) boxGrow(r, box(ax, b));
-	d.nLeft = nLeft;
-	if (nLeft == 0) d.leaf = 1;                                          /* bvh.c:218, 239-241: beginRight == begin */
-	for (int k = 0; k < 3; ++k) { d.childL[2 * k] = l.lo[k]; d.childL[2 * k + 1] = l.hi[k]; d.childR[2 * k] = r.lo[k]; d.childR[2 * k + 1] = r.hi[k]; }
+	const LaneBin l = binFrom(left, (int)split - 1);                     /* bvh.c:226-233 */
+	const LaneBin r = binFrom(scanAscSuffix(own, b), (int)(split & 31u));
+	d.nLeft = l.n;
+	if (l.n == 0) d.leaf = 1;                                            /* bvh.c:218, 239-241: beginRight == begin */
+	for (int k = 0; k < 3; ++k) {
+		d.childL[2 * k] = l.lo[k]; d.childL[2 * k + 1] = l.hi[k];
+		d.childR[2 * k] = split < CRH_BVH_BINS ? r.lo[k] : FLT_MAX; d.childR[2 * k + 1] = split < CRH_BVH_BINS ? r.hi[k] : -FLT_MAX;
+	}
+	return d;
 }
 
 __device__ inline Box binBox(const BinKeys &k) {
@@ -243,27 +291,11 @@ __global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk
 
 /* (2) one wave per node: lanes 0..2 sweep one axis each, lane 0 decides */
 __global__ __launch_bounds__(64) void k_decide(const LargeNode *nodes, uint32_t nNodes, const BinKeys *gbins, const uint32_t *gcounts, Decision *out) {
-	__shared__ float s_costR[3][CRH_BVH_BINS];
-	__shared__ float s_best[3];
-	__shared__ uint32_t s_bin[3];
 	const uint32_t n = blockIdx.x;
 	if (n >= nNodes) return;
-	const BinKeys *bins = gbins + (size_t)n * 3 * CRH_BVH_BINS;
-	const uint32_t *cnts = gcounts + (size_t)n * 3 * CRH_BVH_BINS;
-	auto box = [&](int ax, uint32_t b) { return binBox(bins[ax * CRH_BVH_BINS + b]); };
-	auto cnt = [&](int ax, uint32_t b) { return cnts[ax * CRH_BVH_BINS + b]; };
-	if (threadIdx.x < 3) {
-		float best; uint32_t bin;
-		sweepAxis((int)threadIdx.x, box, cnt, s_costR[threadIdx.x], best, bin);
-		s_best[threadIdx.x] = best; s_bin[threadIdx.x] = bin;
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const LargeNode nd = nodes[n];
-		Decision d;
-		decide(nd.bounds, nd.end - nd.begin, s_best, s_bin, box, cnt, d);
-		out[n] = d;
-	}
+	const LargeNode nd = nodes[n];
+	const Decision d = waveDecide(gbins + (size_t)n * 3 * CRH_BVH_BINS, gcounts + (size_t)n * 3 * CRH_BVH_BINS, nd.bounds, nd.end - nd.begin);
+	if (threadIdx.x == 0) out[n] = d;
 }
 
 /* (3a) per chunk: how many elements sit on the wrong side (bvh.c:95-130 stops exactly at begin + nLeft) */
@@ -377,9 +409,6 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 	__shared__ int32_t s_prim[CRH_BVH_SMALL];
 	__shared__ BinKeys s_bins[3 * CRH_BVH_BINS];
 	__shared__ uint32_t s_cnt[3 * CRH_BVH_BINS];
-	__shared__ float s_costR[3][CRH_BVH_BINS];
-	__shared__ float s_best[3];
-	__shared__ uint32_t s_bin[3];
 	__shared__ Decision s_dec;
 	__shared__ uint16_t s_listL[CRH_BVH_SMALL], s_listR[CRH_BVH_SMALL];
 	struct Job { uint32_t node, first, last, depth; };
@@ -434,15 +463,10 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 				}
 			}
 			__syncthreads();
-			auto box = [&](int ax, uint32_t b) { return binBox(s_bins[ax * CRH_BVH_BINS + b]); };
-			auto cnt = [&](int ax, uint32_t b) { return s_cnt[ax * CRH_BVH_BINS + b]; };
-			if (lane < 3) {
-				float best; uint32_t bin;
-				sweepAxis((int)lane, box, cnt, s_costR[lane], best, bin);
-				s_best[lane] = best; s_bin[lane] = bin;
+			{
+				const Decision dd = waveDecide(s_bins, s_cnt, bounds, n);
+				if (lane == 0) s_dec = dd;
 			}
-			__syncthreads();
-			if (lane == 0) { Decision d; decide(bounds, n, s_best, s_bin, box, cnt, d); s_dec = d; }
 			__syncthreads();
 			leaf = s_dec.leaf != 0;
 		}
@@ -588,6 +612,8 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 
 	uint32_t levels = 0;
 	std::vector<uint32_t> level_leaves;
+	const bool trace = getenv("CRH_BVH_TRACE") != nullptr;
+	auto tl = std::chrono::steady_clock::now();
 	DevBuf<LargeNode> dLevel; DevBuf<Chunk> dChunks; DevBuf<BinKeys> dBins; DevBuf<uint32_t> dCounts, dChunkML, dChunkMR, dNodeChunk0, dNodeSwaps; DevBuf<Decision> dDec;
 	size_t capNodes = 0, capChunks = 0;
 	while (!level.empty()) {
@@ -651,6 +677,7 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 		}
 		for (uint32_t u : level_leaves) route(u, true);
 		level_leaves.clear();
+		if (trace) { const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh level %u: %u nodes %u chunks %.3f ms\n", levels, nNodes, nChunks, std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
 	}
 
 	/* small phase: one wave per subtree */
@@ -663,6 +690,7 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	std::vector<uint32_t> localCount(nRoots);
 	BVH_TRY(hipMemcpyAsync(localCount.data(), dLocalCount.p, nRoots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	BVH_TRY(hipStreamSynchronize(st));
+	if (trace) { const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh small phase: %u subtrees %.3f ms\n", nRoots, std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
 
 	/* numbering (bvh.c:221-223, 237-238): depth-first, a pair per split, left subtree before the right one */
 	std::vector<uint32_t> rootId(nRoots), firstId(nRoots);

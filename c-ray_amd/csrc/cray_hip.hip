@@ -215,7 +215,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 			uint32_t myPath = 0;
 			for (;;) {
 				const uint32_t ph = w.phase;
-				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL));
+				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
 				const int nF = __popcll(__ballot(ph == PH_SHADE));           /* walks that ended, result not yet queued */
 				const int nE = 64 - nN - nT - nC - nF;                        /* idle lanes */
 				const int raysQ = wq[WQ_RAYS], hitsQ = wq[WQ_HITS], missQn = wq[WQ_MISSES], freeQ = wq[WQ_FREE];
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 					case ST_NODE: {          /* keep stepping while at least 3/4 of the lanes that started this run still want node steps */
 						int now = nN;
 						do {
-							if (w.phase == PH_NODE) stepNode(S, w, stk, cnt);
+							if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
 							now = __popcll(__ballot(w.phase == PH_NODE));
 						} while (now * 4 >= nN * 3);
@@ -261,7 +261,10 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						} while (now * 4 >= nT * 3);
 						break;
 					}
-					case ST_CTRL: if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt); break;
+					case ST_CTRL:
+						if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt);
+						if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt); }   /* degenerate rays: rare */
+						break;
 					case ST_SWAP: {
 						/* retire: a walk that ended leaves its result in the path's slot; the id goes on the hit or the miss stack */
 						const bool fin = (ph == PH_SHADE);

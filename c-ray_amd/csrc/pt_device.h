@@ -717,11 +717,13 @@ CRH_DEV float hwmax(float a, float b) { return fmaxf(a, b); }
 CRH_DEV float hwmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 CRH_DEV float hwmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
 #endif
+/* FAST = true: the caller knows the ray is regular (no zero / non-finite direction component: !(oct & CRH_RAY_SLOW)) */
+template <bool FAST = false>
 CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDist, float &tEntry) {
 	const float xa = __builtin_fmaf(n0.x, k.inv.x, k.ss.x), xb = __builtin_fmaf(n0.y, k.inv.x, k.ss.x);
 	const float ya = __builtin_fmaf(n0.z, k.inv.y, k.ss.y), yb = __builtin_fmaf(n0.w, k.inv.y, k.ss.y);
 	const float za = __builtin_fmaf(n1.x, k.inv.z, k.ss.z), zb = __builtin_fmaf(n1.y, k.inv.z, k.ss.z);
-	if (!(k.oct & CRH_RAY_SLOW)) {
+	if (FAST || !(k.oct & CRH_RAY_SLOW)) {
 		const float tMin = hwmax3(hwmax(hwmin(xa, xb), hwmin(ya, yb)), hwmin(za, zb), 0.0f);
 		const float tMax = hwmin3(hwmin(hwmax(xa, xb), hwmax(ya, yb)), hwmax(za, zb), maxDist);
 		tEntry = tMin;
@@ -779,7 +781,7 @@ struct TravHit {
 /* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside a BLAS */
 enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT, CRH_PARK_SLOTS };
 
-enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6 };   /* PH_IDLE: a worker lane without a ray (queue driver) */
+enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6, PH_NODE_SLOW = 7 };   /* PH_NODE_SLOW: a node step for a degenerate ray (rare; served with the control steps) */   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
 struct Walk {
 	uint32_t phase;
@@ -797,7 +799,7 @@ template <class Stack, class Cnt>
 CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
 	if (w.pA != w.pAe) { w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
-	if (w.node != CRH_NONE) { w.phase = PH_NODE; return; }
+	if (w.node != CRH_NONE) { w.phase = (w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE; return; }
 	if (!w.inBlas) { w.phase = PH_SHADE; return; }                /* TLAS exhausted -> the walk is over */
 	/* BLAS exhausted -> back to the TLAS walk (instance.c:176-183): the world ray and the TLAS cursor come back from LDS.
 	 * Done here, at the end of whichever step emptied the BLAS, rather than as a step of its own: a leave is a dozen LDS
@@ -813,7 +815,7 @@ CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
 	w.spBase = 0;
 	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > 0u) w.node = stk.pop(--w.sp);
-	w.phase = (w.node != CRH_NONE) ? PH_NODE : PH_SHADE;
+	w.phase = (w.node != CRH_NONE) ? ((w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE) : PH_SHADE;
 }
 
 template <class Stack, class Cnt>
@@ -836,14 +838,15 @@ CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v
 }
 
 /* NODE: bvh.c:391-436 */
-template <class Stack, class Cnt>
+/* FAST = true serves PH_NODE lanes (regular rays: no degenerate-slab code in the step at all), FAST = false PH_NODE_SLOW lanes */
+template <bool FAST = true, class Stack, class Cnt>
 CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	const uint32_t node = w.node;
 	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
 	float tL, tR;
 	CRH_COUNT(cnt, node_tests, 2);
-	const bool hitL = intersectNode(l0, l1, w.k, w.hit.t, tL);
-	const bool hitR = intersectNode(r0, r1, w.k, w.hit.t, tR);
+	const bool hitL = intersectNode<FAST>(l0, l1, w.k, w.hit.t, tL);
+	const bool hitR = intersectNode<FAST>(r0, r1, w.k, w.hit.t, tR);
 	const bool leafL = CRH_DNODE_ISLEAF(l1), leafR = CRH_DNODE_ISLEAF(r1);
 	const uint32_t fl = CRH_DNODE_FIRST(l1), fr = CRH_DNODE_FIRST(r1);
 	/* pending leaf ranges (none are pending when a node step runs): left leaf first, then the right one */
@@ -961,7 +964,8 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 	Walk w;
 	walkBegin(S, w, stk, rayO, rayD, cnt);
 	while (w.phase != PH_SHADE) {
-		if (w.phase == PH_NODE) stepNode(S, w, stk, cnt);
+		if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
+		else if (w.phase == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt);
 		else if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
 		else stepCtrl(S, w, stk, cnt);
 	}
@@ -1154,7 +1158,8 @@ CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk
 	for (;;) {
 		switch (w.phase) {
 			case PH_SETUP: stepSetup(S, P, J, laneStride, w, lp, stk, stage, cnt); break;
-			case PH_NODE: stepNode(S, w, stk, cnt); break;
+			case PH_NODE: stepNode<true>(S, w, stk, cnt); break;
+			case PH_NODE_SLOW: stepNode<false>(S, w, stk, cnt); break;
 			case PH_TRI: stepTri(S, w, stk, cnt); break;
 			case PH_CTRL: stepCtrl(S, w, stk, cnt); break;
 			case PH_SHADE: stepShade(S, P, w, lp, stk, stage, cnt); break;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpu_probe8.py — dev probe: run each kernel variant (waves/SIMD x counter level) in its own process, report faults."""
+"""probe_kernel_variants.py — dev probe: run each kernel variant (waves/SIMD x counter level) in its own process, report faults."""
 import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpu_probe5.py — dev probe: timed kernel (counter level 1) on the three reference scenes."""
+"""probe_scenes.py — dev probe: timed kernel (counter level 1) on the three reference scenes."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)

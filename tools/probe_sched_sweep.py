@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpu_probe6.py — dev probe: scheduler parameter sweep (weights / swapMin) on cfg2 and the 1M soup."""
+"""probe_sched_sweep.py — dev probe: scheduler parameter sweep (weights / swapMin) on cfg2 and the 1M soup."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)

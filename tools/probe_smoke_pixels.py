@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpu_probe9.py — dev probe: the smoke() comparison with the offending pixels listed."""
+"""probe_smoke_pixels.py — dev probe: the smoke() comparison with the offending pixels listed."""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

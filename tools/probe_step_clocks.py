@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpu_probe7.py — dev probe: per-step-kind clocks of the wave scheduler (counter level 2)."""
+"""probe_step_clocks.py — dev probe: per-step-kind clocks of the wave scheduler (counter level 2)."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)

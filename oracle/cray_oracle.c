@@ -51,6 +51,8 @@ typedef struct {
 typedef struct {
 	const crh_scene_desc *s;
 	pcg32 rng;
+	int halton;                  /* sampler type: 0 = Random (renderThread), 1 = Halton (renderThreadInteractive) */
+	float h_offset; int h_pass; unsigned h_prime;     /* haltonSampler: halton.h */
 	crh_counters cnt;
 	uint32_t ray_node_tests, ray_tri_tests;
 } ctx_t;
@@ -152,12 +154,52 @@ static inline uint64_t hash64(uint64_t x) {
 	x = x ^ (x >> 31);
 	return x;
 }
-/* initSampler(.., Random, pass, maxPasses, pixelIndex): the multiply-add is 32-bit and wraps. */
+/* samplers/common.h:14-20, 30-57 + halton.c:16-31: the sampler of renderThreadInteractive (renderer.c:204) */
+static inline uint32_t hash32(uint32_t x) {
+	x = (x ^ 12345391u) * 2654435769u;
+	x ^= (x << 6) ^ (x >> 26);
+	x *= 2654435769u;
+	x += (x << 5) ^ (x >> 12);
+	return x;
+}
+static inline float radicalInverse(int pass, int base) {
+	const float invBase = 1.0f / base;
+	int reversedDigits = 0;
+	float invBaseN = 1.0f;
+	while (pass) {
+		const int next = pass / base;
+		const int digit = pass - base * next;
+		reversedDigits = reversedDigits * base + digit;
+		invBaseN *= invBase;
+		pass = next;
+	}
+	const float v = reversedDigits * invBaseN;
+	return v < 0.99999994f ? v : 0.99999994f;
+}
+static inline float uintToUnitReal(uint32_t v) {
+	union { uint32_t u; float f; } x;
+	x.u = (v >> 9) | 0x3f800000u;
+	return x.f - 1.0f;
+}
+/* initSampler(.., Random, pass, maxPasses, pixelIndex): the multiply-add is 32-bit and wraps.
+ * initSampler(.., Halton, pass, ..): renderThreadInteractive passes state.finishedPasses, which starts at 1
+ * (renderer.c:333): interactive pass p (0-based here, like completedSamples - 1) is Halton index p + 1. */
 static inline void initSampler(ctx_t *c, int pass, int maxPasses, uint32_t pixelIndex) {
+	if (c->halton) {
+		c->h_offset = uintToUnitReal(hash32(pixelIndex));
+		c->h_pass = pass + 1;
+		c->h_prime = 0;
+		return;
+	}
 	uint32_t key = pixelIndex * (uint32_t)maxPasses + (uint32_t)pass;
 	pcg32_srandom_r(&c->rng, hash64((uint64_t)key), 0);
 }
 static inline float getDimension(ctx_t *c) {
+	if (c->halton) {
+		static const int primes[6] = {2, 3, 5, 7, 11, 13};
+		const float u = radicalInverse(c->h_pass, primes[c->h_prime++ % 6u]);
+		return (u + c->h_offset < 1.0f) ? u + c->h_offset : u + c->h_offset - 1.0f;     /* wrapAdd, common.h:30-32 */
+	}
 	return (1.0f / (1ull << 32)) * pcg32_random_r(&c->rng);
 }
 
@@ -842,6 +884,9 @@ static color pathTrace(ctx_t *c, const ray_t *incidentRay, int maxDepth) {
 /* ---- public entry points ----------------------------------------------------------------------- */
 
 /* renderer.c:275-301, per pixel: running mean over passes in pass order */
+static int g_sampler;   /* 0 Random, 1 Halton: what renderThread / renderThreadInteractive pass to initSampler */
+void oracle_set_sampler(int halton) { g_sampler = halton ? 1 : 0; }
+
 int oracle_render_region(const crh_scene_desc *scene, const crh_render_params *p, float *fb, crh_counters *counters_out, int threads) {
 	if (!scene || !p || !fb) return CRH_ERR_INVALID;
 	const int W = p->image_width, H = p->image_height;
@@ -858,6 +903,7 @@ int oracle_render_region(const crh_scene_desc *scene, const crh_render_params *p
 		ctx_t c;
 		memset(&c, 0, sizeof(c));
 		c.s = scene;
+		c.halton = g_sampler;
 		#pragma omp for schedule(dynamic, 1)
 		for (int y = p->y1 - 1; y >= p->y0; --y) {
 			for (int x = p->x0; x < p->x1; ++x) {
@@ -928,6 +974,7 @@ void oracle_to_srgb8(const float *fb, int width, int height, uint8_t *rgb8) {
 void oracle_sampler_draws(uint32_t pixel_index, int pass, int max_passes, int n, float *out) {
 	ctx_t c;
 	memset(&c, 0, sizeof(c));
+	c.halton = g_sampler;
 	initSampler(&c, pass, max_passes, pixel_index);
 	for (int i = 0; i < n; ++i) out[i] = getDimension(&c);
 }

@@ -46,6 +46,8 @@ def lib():
         L.oracle_sampler_draws.restype = None
         L.oracle_camera_ray.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_camera_ray.restype = None
+        L.oracle_set_sampler.argtypes = [C.c_int]
+        L.oracle_set_sampler.restype = None
         L.orc_bvh_triangle_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_bvh_triangle_bounds.restype = None
         L.orc_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
@@ -84,8 +86,9 @@ class OracleScene:
             pass
 
 
-def render(scene, width, height, samples, bounces, region=None, first_pass=0, pass_count=None, fb=None, threads=0):
-    """renderThread() restated. Returns (float32 [H, W, 3] in stored row order, counters dict)."""
+def render(scene, width, height, samples, bounces, region=None, first_pass=0, pass_count=None, fb=None, threads=0, halton=False):
+    """renderThread() (halton=True: renderThreadInteractive(), run single-threaded: with more threads the reference
+    races on state.finishedPasses and is not reproducible) restated. Returns (float32 [H, W, 3] in stored row order, counters dict)."""
     x0, y0, x1, y1 = region if region else (0, 0, width, height)
     p = abi.RenderParams(x0, y0, x1, y1, width, height, first_pass,
                          samples - first_pass if pass_count is None else pass_count, samples, bounces)
@@ -93,7 +96,11 @@ def render(scene, width, height, samples, bounces, region=None, first_pass=0, pa
         fb = np.zeros((height, width, 3), dtype=np.float32)
     assert fb.dtype == np.float32 and fb.flags["C_CONTIGUOUS"]
     cnt = abi.Counters()
-    rc = lib().oracle_render_region(scene.ptr, C.byref(p), fb.ctypes.data, C.byref(cnt), threads)
+    lib().oracle_set_sampler(1 if halton else 0)
+    try:
+        rc = lib().oracle_render_region(scene.ptr, C.byref(p), fb.ctypes.data, C.byref(cnt), threads)
+    finally:
+        lib().oracle_set_sampler(0)
     if rc != 0:
         raise RuntimeError(f"oracle_render_region failed: {rc}")
     return fb, cnt.as_dict()

@@ -18,6 +18,22 @@ def test_oracle_bit_exact_vs_reference(name, oracle, manifest, golden_blob, gold
     assert cnt["paths"] == m["width"] * m["height"] * m["samples"]
 
 
+def test_oracle_interactive_mode_bit_exact_vs_reference(oracle, manifest, golden_blob, golden_ref):
+    """renderThreadInteractive (renderer.c:184-250) = Halton sampler seeded with
+    state.finishedPasses (1-based), passes 1 .. samples-1. Fixture: c-ray-ref-strict --iterative -j 1."""
+    m = manifest["cfg1_scene_iterative"]
+    scene = oracle.OracleScene(golden_blob(m["blob"]))
+    img, cnt = oracle.render(scene, m["width"], m["height"], m["samples"], m["bounces"], pass_count=m["passes"], halton=True)
+    ref = golden_ref("cfg1_scene_iterative")
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{(img != ref).sum()} floats differ"
+    assert cnt["paths"] == m["width"] * m["height"] * m["passes"]
+    # progressive display: pass by pass into the same buffer is the same image
+    fb = np.zeros_like(img)
+    for p in range(m["passes"]):
+        oracle.render(scene, m["width"], m["height"], m["samples"], m["bounces"], first_pass=p, pass_count=1, fb=fb, halton=True)
+    assert np.array_equal(fb, ref)
+
+
 def test_oracle_region_and_pass_splits_compose(oracle, manifest, golden_blob, golden_ref):
     """Tiles are disjoint and passes fold in order: any tiling / pass split reproduces the frame exactly."""
     m = manifest["fence"]

@@ -61,6 +61,16 @@ def main():
                           "rays": cst["rays"], "node_tests": cst["node_tests"], "tri_tests": cst["tri_tests"],
                           "mean": float(buf.mean())}
         print(name, manifest[name], len(blob))
+        if name == "cfg1_scene":
+            # the interactive mode (renderThreadInteractive: Halton sampler, passes 1..samples-1),
+            # same scene blob, reference run with --iterative on one thread (the only reproducible way to run it)
+            ispp = 6
+            ibuf, _ = refrun.render_reference(scene, w, h, ispp, bounces, "strict", iterative=True)
+            gz_write(os.path.join(GOLDEN, name + "_iterative.ref.f32.gz"), ibuf.tobytes())
+            manifest[name + "_iterative"] = {"scene": scene, "blob": name, "width": w, "height": h, "samples": ispp, "passes": ispp - 1,
+                                             "bounces": bounces, "ref_flavour": "c-ray-ref-strict --iterative -j 1",
+                                             "ref_md5": hashlib.md5(ibuf.tobytes()).hexdigest(), "mean": float(ibuf.mean())}
+            print(name + "_iterative", manifest[name + "_iterative"])
     with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

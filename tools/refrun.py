@@ -40,7 +40,7 @@ def rewrite_scene(scene_name, width=None, height=None, samples=None, bounces=Non
     return scene
 
 
-def _run(binary, scene_json, threads, env_extra, timeout):
+def _run(binary, scene_json, threads, env_extra, timeout, extra_args=()):
     env = dict(os.environ)
     env.update(env_extra)
     exe = os.path.join(REF_DIR, binary)
@@ -49,6 +49,7 @@ def _run(binary, scene_json, threads, env_extra, timeout):
     args = [exe]
     if threads:
         args += ["-j", str(int(threads))]
+    args += list(extra_args)
     proc = subprocess.run(args, input=json.dumps(scene_json).encode(), cwd=INPUT_DIR, env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     if proc.returncode != 0:
@@ -57,15 +58,18 @@ def _run(binary, scene_json, threads, env_extra, timeout):
 
 
 def render_reference(scene_name, width, height, samples, bounces, flavour="strict", threads=None, timeout=3600,
-                     tile=None):
-    """Run the real reference; returns (float32 array [H, W, 3] in the reference's stored row order, stats dict)."""
+                     tile=None, iterative=False):
+    """Run the real reference; returns (float32 array [H, W, 3] in the reference's stored row order, stats dict).
+    iterative=True: `--iterative` (renderThreadInteractive, Halton sampler) on ONE thread — with more threads the
+    reference races on state.finishedPasses and its output changes from run to run."""
     binary = {"default": "c-ray-ref", "strict": "c-ray-ref-strict", "count": "c-ray-ref-count"}[flavour]
     with tempfile.TemporaryDirectory() as tmp:
         scene = rewrite_scene(scene_name, width, height, samples, bounces, tile=tile, out_dir=tmp)
         f32 = os.path.join(tmp, "buffer.f32")
         stats = os.path.join(tmp, "stats.json")
-        log = _run(binary, scene, threads or os.cpu_count(),
-                   {"CRH_DUMP_F32": f32, "CRH_DUMP_STATS": stats, "CRH_NO_IMAGE": "1"}, timeout)
+        log = _run(binary, scene, 1 if iterative else (threads or os.cpu_count()),
+                   {"CRH_DUMP_F32": f32, "CRH_DUMP_STATS": stats, "CRH_NO_IMAGE": "1"}, timeout,
+                   extra_args=("--iterative",) if iterative else ())
         buf = np.fromfile(f32, dtype=np.float32).reshape(height, width, 3)
         with open(stats) as f:
             st = json.load(f)

@@ -122,7 +122,8 @@ struct Sched { int wNode, wTri, wCtrl, swapMin; };
 #define CRH_IDS_FREE 512u
 #define CRH_IDS_BYTES 768u
 
-__device__ __forceinline__ void putPathRay(f4 *q, const v3 &o, const v3 &d, const PathRec &r, uint32_t item) {
+template <class PR>
+__device__ __forceinline__ void putPathRay(f4 *q, const v3 &o, const v3 &d, const PR &r, uint32_t item) {
 	q[0] = f4{o.x, o.y, o.z, asF32((uint32_t)r.depth)};
 	q[1] = f4{d.x, d.y, d.z, asF32(item)};
 	q[2] = f4{r.wr, r.wg, r.wb, asF32((uint32_t)r.rng.state)};
@@ -138,7 +139,8 @@ __device__ __forceinline__ uint32_t laneRank(unsigned long long m) {
 #ifndef CRH_WPS_OVERRIDE
 #define CRH_WPS_OVERRIDE WPS
 #endif
-template <int LEVEL, int WPS, bool PROG>
+/* SAMP: 0 = Random sampler (renderThread), 1 = Halton (renderThreadInteractive) */
+template <int LEVEL, int WPS, bool PROG, int SAMP>
 __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 														   unsigned long long *counters,
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues) {
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							const uint32_t rk = laneRank(vm);
 							const uint32_t id = ids[CRH_IDS_FREE + (uint32_t)(freeQ - 1) - rk];
 							v3 o, d;
-							PathRec r;
+							PathRecT<RngT<SAMP>> r;
 							beginPath(S, P, x, y, pass, o, d, r, cnt);
 							putPathRay(ptab + id * CRH_PATH_F4, o, d, r, item);
 							ids[CRH_IDS_RAYS + (uint32_t)raysQ + rk] = (uint8_t)id;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							const f4 *q = ptab + id * CRH_PATH_F4;
 							const f4 q1 = q[1], q2 = q[2], q3 = q[3];
 							v3 o{0.0f, 0.0f, 0.0f}, d{q1.x, q1.y, q1.z};
-							PathRec r;
+							PathRecT<RngT<SAMP>> r;
 							r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
 							r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
 							r.rng.state = 0; r.depth = 0;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							f4 *q = ptab + id * CRH_PATH_F4;
 							const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
 							v3 o{q0.x, q0.y, q0.z}, d{q1.x, q1.y, q1.z};
-							PathRec r;
+							PathRecT<RngT<SAMP>> r;
 							r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
 							r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
 							r.rng.state = (uint64_t)asU32(q2.w) | ((uint64_t)asU32(q3.w) << 32);
@@ -496,6 +498,7 @@ struct crh_ctx {
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
+	int sampler = CRH_SAMPLER_RANDOM;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;
 	float *dStage = nullptr;
@@ -637,6 +640,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			c->sched = k;
 			return CRH_OK;
 		}
+		case CRH_OPT_SAMPLER:
+			if (value != CRH_SAMPLER_RANDOM && value != CRH_SAMPLER_HALTON) return fail(CRH_ERR_INVALID, "sampler must be CRH_SAMPLER_RANDOM or CRH_SAMPLER_HALTON");
+			c->sampler = (int)value; return CRH_OK;
 		case CRH_OPT_UNITS_PER_WAVE:
 			if (value < 1 || value > 1024) return fail(CRH_ERR_INVALID, "units per wave must be 1..1024");
 			c->unitsPerWave = (int)value; return CRH_OK;
@@ -827,10 +833,14 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
-#define CRH_LAUNCH(LEVEL, WPS, PROG) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+#define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
-#define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true); else CRH_LAUNCH(LEVEL, WPS, false); } while (0)
-	if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
+#define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
+	if (c->sampler == CRH_SAMPLER_HALTON) {          /* interactive mode: the 128-register variants only */
+		if (c->counterLevel >= 2) { if (c->hasPrograms) CRH_LAUNCH(2, 4, true, 1); else CRH_LAUNCH(2, 4, false, 1); }
+		else { if (c->hasPrograms) CRH_LAUNCH(1, 4, true, 1); else CRH_LAUNCH(1, 4, false, 1); }
+	}
+	else if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
 	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
 #undef CRH_LAUNCH2
 #undef CRH_LAUNCH

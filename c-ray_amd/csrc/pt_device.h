@@ -232,8 +232,15 @@ CRH_DEV rgba colorForKelvin(float kelvin) {
 	return rgba{r / 255.0f, g / 255.0f, b / 255.0f, 0.0f};
 }
 
-/* ---- sampler: pcg_basic.c:42-68, samplers/common.h:22-27, sampler.c:41-44, random.c:12-21 ----- */
-struct Rng { uint64_t state; };   /* inc is always 1 (stream 0) */
+CRH_DEV uint32_t asU32(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+CRH_DEV float asF32(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
+/* ---- samplers: sampler.c:31-58. KIND 0 = Random (pcg_basic.c:42-68, samplers/common.h:22-27, random.c:12-21): the
+ * sampler of renderThread. KIND 1 = Halton (halton.c:16-31, common.h:14-57): the sampler of renderThreadInteractive.
+ * The kind is a compile-time parameter of everything that draws (no branch per draw); both keep their state in 64 bits. */
+template <int KIND> struct RngT { uint64_t state; };
+typedef RngT<0> Rng;              /* PCG32: state; inc is always 1 (stream 0) */
+typedef RngT<1> HaltonRng;        /* bits 0..31 rndOffset (float bits), 32..39 currPrime mod 6, 40..63 currPass */
 CRH_DEV uint32_t pcg32_next(Rng &r) {
 	uint64_t old = r.state;
 	r.state = old * 6364136223846793005ULL + 1ULL;
@@ -247,6 +254,26 @@ CRH_DEV uint64_t hash64(uint64_t x) {
 	x = x ^ (x >> 31);
 	return x;
 }
+CRH_DEV uint32_t hash32(uint32_t x) {                       /* common.h:14-20 */
+	x = (x ^ 12345391u) * 2654435769u;
+	x ^= (x << 6) ^ (x >> 26);
+	x *= 2654435769u;
+	x += (x << 5) ^ (x >> 12);
+	return x;
+}
+CRH_DEV float radicalInverse(int pass, int base) {          /* common.h:34-46 */
+	const float invBase = 1.0f / (float)base;
+	int reversedDigits = 0;
+	float invBaseN = 1.0f;
+	while (pass) {
+		const int next = pass / base;
+		const int digit = pass - base * next;
+		reversedDigits = reversedDigits * base + digit;
+		invBaseN *= invBase;
+		pass = next;
+	}
+	return rmin((float)reversedDigits * invBaseN, 0.99999994f);
+}
 CRH_DEV void initSampler(Rng &r, int pass, int maxPasses, uint32_t pixelIndex) {
 	uint32_t key = pixelIndex * (uint32_t)maxPasses + (uint32_t)pass;   /* 32-bit wrap: sampler.c:42 */
 	r.state = 0u;
@@ -254,16 +281,31 @@ CRH_DEV void initSampler(Rng &r, int pass, int maxPasses, uint32_t pixelIndex) {
 	r.state += hash64((uint64_t)key);
 	pcg32_next(r);
 }
+/* renderThreadInteractive seeds with state.finishedPasses, which starts at 1 (renderer.c:204, 333): pass p (0-based, like
+ * completedSamples - 1 everywhere else here) is Halton index p + 1. uintToUnitReal: common.h:48-57. */
+CRH_DEV void initSampler(HaltonRng &r, int pass, int, uint32_t pixelIndex) {
+	const uint32_t offsetBits = asU32(asF32((hash32(pixelIndex) >> 9) | 0x3f800000u) - 1.0f);
+	r.state = (uint64_t)offsetBits | ((uint64_t)(uint32_t)(pass + 1) << 40);
+}
 CRH_DEV float getDimension(Rng &r) { return (1.0f / 4294967296.0f) * (float)pcg32_next(r); }
+CRH_DEV float getDimension(HaltonRng &r) {                  /* halton.c:25-31 */
+	const uint32_t prime = (uint32_t)(r.state >> 32) & 0xFFu;
+	const int base = prime == 0u ? 2 : prime == 1u ? 3 : prime == 2u ? 5 : prime == 3u ? 7 : prime == 4u ? 11 : 13;
+	r.state = (r.state & ~(0xFFull << 32)) | ((uint64_t)(prime == 5u ? 0u : prime + 1u) << 32);
+	const float u = radicalInverse((int)(r.state >> 40), base), v = asF32((uint32_t)r.state);
+	return (u + v < 1.0f) ? u + v : u + v - 1.0f;           /* wrapAdd, common.h:30-32 */
+}
 
 /* vector.h:190-198 */
-CRH_DEV v2 randomCoordOnUnitDisc(Rng &rng) {
+template <class R>
+CRH_DEV v2 randomCoordOnUnitDisc(R &rng) {
 	float r = sqrtf(getDimension(rng));
 	float theta = ((getDimension(rng)) * ((2.0f * CRH_PI) - 0.0f)) + 0.0f;
 	return v2{r * cosf(theta), r * sinf(theta)};
 }
 /* vector.h:243-249 */
-CRH_DEV v3 randomOnUnitSphere(Rng &rng) {
+template <class R>
+CRH_DEV v3 randomOnUnitSphere(R &rng) {
 	const float sample_x = getDimension(rng);
 	const float sample_y = getDimension(rng);
 	const float a = sample_x * (2.0f * CRH_PI);
@@ -318,7 +360,8 @@ CRH_DEV float triangleDistribution(float v) {
 	v = v - ((orig >= 0.0f) ? 1.0f : -1.0f);
 	return v;
 }
-CRH_DEV void getCameraRay(const crh_camera &cam, Rng &rng, int x, int y, v3 &ro, v3 &rd) {
+template <class R>
+CRH_DEV void getCameraRay(const crh_camera &cam, R &rng, int x, int y, v3 &ro, v3 &rd) {
 	const v3 right = v3{cam.right[0], cam.right[1], cam.right[2]};
 	const v3 up = v3{cam.up[0], cam.up[1], cam.up[2]};
 	const v3 forward = v3{cam.forward[0], cam.forward[1], cam.forward[2]};
@@ -532,8 +575,8 @@ CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt 
 struct BsdfSample { v3 out; float r, g, b; };   /* bsdfnode.h:19-23; colour alpha never reaches RGB (pathtrace.c:51-57) */
 #define CRH_ADD_DEPTH 4
 
-template <class Cnt>
-CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &rec, Rng &rng, Cnt &cnt) {
+template <class R, class Cnt>
+CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &rec, R &rng, Cnt &cnt) {
 	uint32_t addStack[CRH_ADD_DEPTH];      /* pending add.c frames: gnode index | (A done ? 1<<31 : 0) */
 	BsdfSample resStack[CRH_ADD_DEPTH];
 	int asp = 0, rsp = 0;
@@ -748,8 +791,6 @@ CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDis
 	tEntry = tMin;
 	return tMin <= tMax;
 }
-CRH_DEV uint32_t asU32(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
-CRH_DEV float asF32(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
 #define CRH_DNODE_FIRST(n1) asU32((n1).z)
 #define CRH_DNODE_COUNT(n1) (asU32((n1).w) & 0x3FFFFFFFu)
 #define CRH_DNODE_ISLEAF(n1) ((asU32((n1).w) >> 30) & 1u)
@@ -1050,7 +1091,8 @@ CRH_DEV void foldSample(float &r, float &g, float &b, float sr, float sg, float 
 struct Item { uint32_t next, cur; };    /* next item this lane will take / the item of the path in flight */
 
 /* What a path carries from bounce to bounce besides its ray (pathtrace.c:33-35 + the sampler). */
-struct PathRec { float wr, wg, wb; float fr, fg, fb; Rng rng; int depth; };
+template <class R> struct PathRecT { float wr, wg, wb; float fr, fg, fb; R rng; int depth; };
+typedef PathRecT<Rng> PathRec;
 
 /* Item index -> pixel / pass of a block chunk. Items are numbered pixel-major, so consecutive items are passes of
  * the same pixel (coherent primary rays). Returns false for the padding items of a ragged tile edge. */
@@ -1066,8 +1108,8 @@ CRH_DEV bool decodeItem(const BlockJob &J, uint32_t item, int &x, int &y, int &p
 }
 
 /* A new path: initSampler + getCameraRay (renderer.c:280-284). Needs P.bounces > 0. */
-template <class Cnt>
-CRH_DEV void beginPath(const DScene &S, const crh_render_params &P, int x, int y, int pass, v3 &ro, v3 &rd, PathRec &r, Cnt &cnt) {
+template <class PR, class Cnt>
+CRH_DEV void beginPath(const DScene &S, const crh_render_params &P, int x, int y, int pass, v3 &ro, v3 &rd, PR &r, Cnt &cnt) {
 	CRH_COUNT1(cnt, paths, 1);
 	const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
 	initSampler(r.rng, pass, P.max_passes, pixIdx);                       /* :281 */
@@ -1080,8 +1122,8 @@ CRH_DEV void beginPath(const DScene &S, const crh_render_params &P, int x, int y
  * ray (ro, rd) and its closest hit go in; either the path continues (true: ro / rd are the next ray, r updated) or it
  * is complete (false: r.fr/fg/fb is the sample).
  */
-template <class Cnt>
-CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &rd, const TravHit &hit, PathRec &r, Cnt &cnt) {
+template <class PR, class Cnt>
+CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &rd, const TravHit &hit, PR &r, Cnt &cnt) {
 	ShadeRec rec;
 	rec.dir = rd;
 	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */
@@ -1111,10 +1153,10 @@ CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &
 
 /* A lane that owns its paths from start to end (host emulation; the device driver keeps paths in a per-wave table
  * instead and lets lanes work on whichever path needs a step): */
-struct LanePath { Item it; PathRec r; v3 ro, rd; };
+template <class R> struct LanePathT { Item it; PathRecT<R> r; v3 ro, rd; };
 
-template <class Stack, class Cnt>
-CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, LanePath &lp,
+template <class LP, class Stack, class Cnt>
+CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, LP &lp,
 					   Stack &stk, float *stage, Cnt &cnt) {
 	const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);
 	for (;;) {
@@ -1136,8 +1178,8 @@ CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJ
 	}
 }
 
-template <class Stack, class Cnt>
-CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, LanePath &lp, Stack &stk, float *stage, Cnt &cnt) {
+template <class LP, class Stack, class Cnt>
+CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, LP &lp, Stack &stk, float *stage, Cnt &cnt) {
 	if (shadeCore(S, P, lp.ro, lp.rd, w.hit, lp.r, cnt)) {
 		walkBegin(S, w, stk, lp.ro, lp.rd, cnt);
 		return;
@@ -1148,11 +1190,11 @@ CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, Lan
 }
 
 /* One lane, all steps in sequence (host emulation and any non-scheduled use): the block chunk's items of this lane. */
-template <class Stack, class Cnt>
+template <class R = Rng, class Stack, class Cnt>
 CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk, const BlockJob &J, uint32_t lane, uint32_t laneStride,
 						 float *stage, Cnt &cnt) {
 	Walk w;
-	LanePath lp;
+	LanePathT<R> lp;
 	lp.it.next = lane; lp.it.cur = 0;
 	w.phase = PH_SETUP;
 	for (;;) {

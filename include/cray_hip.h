@@ -262,6 +262,10 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_UNIT_ITEMS    6   /* paths per work unit (pixel block x passes) the block shape aims for (default 2048) */
 #define CRH_OPT_SCHED_WEIGHTS 7   /* wave scheduler, four 12-bit fields: node | tri<<12 | ctrl<<24 step weights, finished+idle lanes that trigger a swap step <<36 (default 70,160,120,32) */
 #define CRH_OPT_UNITS_PER_WAVE 8  /* shrink the pixel blocks until every wave gets at least this many work units (default 8) */
+#define CRH_OPT_SAMPLER       9   /* which sampler seeds a (pixel, pass): CRH_SAMPLER_RANDOM = renderThread (sampler.c:41-44, default),
+                                   * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */
+#define CRH_SAMPLER_RANDOM 0
+#define CRH_SAMPLER_HALTON 1
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);

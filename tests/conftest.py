@@ -75,6 +75,8 @@ def emu(oracle):
     L.emu_trace_rays.argtypes = [C.POINTER(abi.SceneDesc), C.c_void_p, C.c_uint64, C.c_void_p]
     L.emu_compile_check.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.emu_last_error.restype = C.c_char_p
+    L.emu_set_sampler.argtypes = [C.c_int]
+    L.emu_set_sampler.restype = None
     return L
 
 

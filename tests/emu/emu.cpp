@@ -59,6 +59,9 @@ int emu_compile_check(const crh_scene_desc *scene, uint32_t *max_stack, uint32_t
 
 /* The kernel's schedule, one "wave" at a time: blocks of bw x bh pixels, chunks of `chunk` passes, 64 lanes
  * striding over the block's items, then the per-pixel fold. */
+static int g_halton;
+void emu_set_sampler(int halton) { g_halton = halton ? 1 : 0; }     /* 0 Random (renderThread), 1 Halton (renderThreadInteractive) */
+
 int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, float *fb, crh_counters *out, uint32_t *stack_high,
 					  int bw, int bh, int chunk) {
 	CompiledScene c;
@@ -89,7 +92,8 @@ int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, f
 				J.passBegin = c0; J.passCount = std::min(chunk, p->first_pass + p->pass_count - c0);
 				for (uint32_t lane = 0; lane < 64; ++lane) {
 					ArrayStack stk;
-					renderItems(d, *p, stk, J, lane, 64u, stage.data(), cnt);
+					if (g_halton) renderItems<HaltonRng>(d, *p, stk, J, lane, 64u, stage.data(), cnt);
+					else renderItems<Rng>(d, *p, stk, J, lane, 64u, stage.data(), cnt);
 					if (stk.high > myHigh) myHigh = stk.high;
 				}
 				for (uint32_t pix = 0; pix < (uint32_t)(bw * bh); ++pix) foldBlockPixel(*p, J, pix, stage.data(), fb);

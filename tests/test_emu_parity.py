@@ -38,6 +38,23 @@ def test_emulated_kernel_bit_exact_vs_reference(name, emu, oracle, manifest, gol
     assert high <= mx.value, "traversal stack bound computed by the scene compiler was exceeded"
 
 
+def test_emulated_kernel_interactive_mode_bit_exact(emu, oracle, manifest, golden_blob, golden_ref):
+    """The Halton-sampler instantiation of the lane code (CRH_OPT_SAMPLER = CRH_SAMPLER_HALTON) against the reference's
+    --iterative -j 1 frame: passes 1 .. samples-1, any chunking."""
+    m = manifest["cfg1_scene_iterative"]
+    scene = oracle.OracleScene(golden_blob(m["blob"]))
+    emu.emu_set_sampler(1)
+    try:
+        p = oracle.abi.RenderParams(0, 0, m["width"], m["height"], m["width"], m["height"], 0, m["passes"], m["samples"], m["bounces"])
+        fb = np.zeros((m["height"], m["width"], 3), np.float32)
+        cnt, hi = oracle.abi.Counters(), C.c_uint32()
+        assert emu.emu_render_region(scene.ptr, C.byref(p), fb.ctypes.data, C.byref(cnt), C.byref(hi), 8, 8, 2) == 0, emu.emu_last_error()
+    finally:
+        emu.emu_set_sampler(0)
+    ref = golden_ref("cfg1_scene_iterative")
+    assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32)), f"{(fb != ref).sum()} floats differ"
+
+
 @pytest.mark.parametrize("shape,chunk", [((8, 8), 3), ((4, 4), 1), ((2, 2), 64), ((16, 16), 2), ((1, 1), 4)])
 def test_block_schedule_is_order_independent(shape, chunk, emu, oracle, manifest, golden_blob, golden_ref):
     """Any block shape / pass chunking folds the samples in pass order -> identical frame (ragged edges included)."""

@@ -194,6 +194,32 @@ def test_edge_cases_empty_ragged_single_pixel(pkg, ctx, oracle, manifest, golden
     assert st["rmse"] <= 1e-4 and st["frac_gt_1e-3"] == 0.0, st
 
 
+def test_interactive_mode_halton_sampler(pkg, ctx, manifest, golden_blob, golden_ref):
+    """CRH_OPT_SAMPLER = HALTON renders renderThreadInteractive's passes; progressive dispatches
+    (one pass at a time, as a preview loop would) give the same frame bit for bit as one dispatch."""
+    abi = pkg.abi
+    m = manifest["cfg1_scene_iterative"]
+    w, h, n, b = m["width"], m["height"], m["samples"], m["bounces"]
+    ctx.upload(pkg.api.Scene(golden_blob(m["blob"])))
+    fb = ctx.framebuffer(w, h)
+    ctx.set_option(abi.OPT_SAMPLER, abi.SAMPLER_HALTON)
+    try:
+        ctx.reset_counters()
+        ctx.render_region(fb, w, h, n, b, pass_count=m["passes"])
+        img, cnt = ctx.download(fb, w, h), ctx.counters()
+        ctx.clear(fb, w, h)
+        for p in range(m["passes"]):
+            ctx.render_region(fb, w, h, n, b, first_pass=p, pass_count=1)
+        assert np.array_equal(ctx.download(fb, w, h), img)
+    finally:
+        ctx.set_option(abi.OPT_SAMPLER, abi.SAMPLER_RANDOM)
+    st = image_stats(img, golden_ref("cfg1_scene_iterative"))
+    assert st["rmse"] <= 5e-3 and st["frac_gt_1e-3"] <= 5e-3, st
+    assert cnt["paths"] == w * h * m["passes"]
+    with pytest.raises(pkg.api.CrhError):
+        ctx.set_option(abi.OPT_SAMPLER, 7)
+
+
 def test_full_size_properties_cfg2(pkg, ctx, oracle):
     """BASELINE.json configs[1] at full resolution (needs scenes/_built/cfg2_hdr.blob, made by build()):
     deterministic, tile decomposition exact, ray count within 0.2 % of the oracle, image within tolerance —

@@ -16,6 +16,12 @@
  * RCCL over xGMI (crh_frames_reduce), downloaded into state.renderBuffer, and converted to the 8-bit sRGB
  * output with the reference's own colorToSRGB()/setPixel() on the host.
  *
+ * --iterative (renderThreadInteractive, renderer.c:184-250): passes 1 .. sampleCount-1 with the Halton sampler, the frame
+ * shown while it converges. Here the main thread drives every GPU pass-chunk by pass-chunk (tile i belongs to GPU i mod G for
+ * the whole frame, so each pixel's running mean stays on one GPU), gathers the tiles on the host after each chunk and redraws.
+ * The result is the reference's single-thread result: with several threads the reference itself races on
+ * state.finishedPasses and is not reproducible.
+ *
  * Environment: CRAY_HIP_DEVICES=<n> caps the number of GPUs used; CRH_DUMP_F32=<path> dumps the float buffer.
  * No GPU => logr(error, ...) (which exits, src/utils/logging.c:69-73): there is no CPU fallback in this file.
  */
@@ -37,6 +43,7 @@
 #include "utils/timer.h"
 #include "utils/platform/thread.h"
 #include "utils/platform/mutex.h"
+#include "utils/args.h"
 
 #include "cray_hip.h"
 #include "flatten.h"
@@ -116,6 +123,80 @@ static void *gpuThread(void *arg) {
 	return NULL;
 }
 
+/* renderer.c:294-300 for the whole frame: colorToSRGB + setPixel truncation on the host */
+static void resolveOutput(struct renderer *r, struct texture *output) {
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	for (int y = 0; y < H; ++y)
+		for (int x = 0; x < W; ++x)
+			setPixel(output, colorToSRGB(textureGetPixel(r->state.renderBuffer, x, y, false)), x, y);
+}
+
+/* --iterative: returns the rays traced, fills state.renderBuffer and output */
+static uint64_t renderInteractive(struct renderer *r, struct texture *output, const crh_scene_desc *scene, int gpus) {
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	const int tileCount = r->state.tileCount;
+	crh_ctx *ctx[MAX_GPUS];
+	float *fb[MAX_GPUS];
+	crh_tile *tiles[MAX_GPUS];
+	uint32_t ntiles[MAX_GPUS];
+	float *gather = malloc(sizeof(float) * (size_t)W * H * 3);
+	for (int g = 0; g < gpus; ++g) {
+		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
+			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK)
+			logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+		tiles[g] = calloc((size_t)tileCount / gpus + 1, sizeof(crh_tile));
+		ntiles[g] = 0;
+	}
+	for (int i = 0; i < tileCount; ++i) {
+		const struct renderTile *t = &r->state.renderTiles[i];
+		tiles[i % gpus][ntiles[i % gpus]++] = (crh_tile){t->begin.x, t->begin.y, t->end.x, t->end.y};
+	}
+	const int passes = r->prefs.sampleCount - 1;             /* finishedPasses runs from 1 while < sampleCount (renderer.c:199, tile.c:52) */
+	crh_render_params p;
+	memset(&p, 0, sizeof(p));
+	p.image_width = W; p.image_height = H; p.max_passes = r->prefs.sampleCount; p.bounces = r->prefs.bounces;
+	int done = 0;
+	while (done < passes && !r->state.renderAborted) {
+		const int chunk = done < 8 ? 1 : (passes - done < 8 ? passes - done : 8);      /* first previews quickly, then fewer round trips */
+		p.first_pass = done; p.pass_count = chunk;
+		for (int g = 0; g < gpus; ++g)
+			if (ntiles[g] && crh_render_tiles(ctx[g], &p, tiles[g], ntiles[g], fb[g]) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+		for (int g = 0; g < gpus; ++g)
+			if (crh_synchronize(ctx[g]) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+		done += chunk;
+		r->state.finishedPasses = done + 1;
+		for (int g = 0; g < gpus; ++g) {                      /* gather: every tile from the GPU that owns it */
+			r->state.threadStates[g].completedSamples = done;
+			r->state.threadStates[g].totalSamples += (uint64_t)chunk;
+			float *dst = r->state.renderBuffer->data.float_p;
+			const float *src = gather;
+			if (gpus == 1) dst = r->state.renderBuffer->data.float_p, src = NULL;
+			if (crh_framebuffer_download(ctx[g], fb[g], W, H, gpus == 1 ? dst : gather) != CRH_OK) logr(error, "c-ray-hip: download: %s\n", crh_last_error());
+			if (!src) continue;
+			for (uint32_t t = 0; t < ntiles[g]; ++t)
+				for (int y = tiles[g][t].y0; y < tiles[g][t].y1; ++y) {
+					const size_t row = ((size_t)(H - (y + 1)) * W + (size_t)tiles[g][t].x0) * 3;      /* texture.c:24-28 row order */
+					memcpy(dst + row, src + row, sizeof(float) * 3 * (size_t)(tiles[g][t].x1 - tiles[g][t].x0));
+				}
+		}
+		resolveOutput(r, output);
+		getKeyboardInput(r);
+		drawWindow(r, output);
+		while (r->state.threadStates[0].paused && !r->state.renderAborted) { getKeyboardInput(r); sleepMSec(100); }
+	}
+	uint64_t rays = 0;
+	for (int g = 0; g < gpus; ++g) {
+		crh_counters c;
+		if (crh_counters_get(ctx[g], &c) == CRH_OK) rays += c.rays;
+		crh_framebuffer_free(ctx[g], fb[g]);
+		crh_context_destroy(ctx[g]);
+		free(tiles[g]);
+		r->state.threadStates[g].threadComplete = true;
+	}
+	free(gather);
+	return rays;
+}
+
 struct texture *renderFrame(struct renderer *r) {
 	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
 	struct texture *output = newTexture(char_p, r->prefs.imageWidth, r->prefs.imageHeight, 3);
@@ -139,6 +220,21 @@ struct texture *renderFrame(struct renderer *r) {
 	r->prefs.threadCount = gpus;              /* ui.c indexes threadStates[0..threadCount) */
 	r->state.threads = calloc((size_t)gpus, sizeof(*r->state.threads));
 	r->state.threadStates = calloc((size_t)gpus, sizeof(*r->state.threadStates));
+	if (isSet("interactive")) {
+		logr(info, "Pathtracing iteratively...\n");
+		for (int g = 0; g < gpus; ++g)
+			r->state.threadStates[g] = (struct renderThreadState){.thread_num = g, .renderer = r, .output = output, .currentTileNum = -1};
+		const uint64_t rays = renderInteractive(r, output, &scene, gpus);
+		r->state.isRendering = false;
+		const char *dumpi = getenv("CRH_DUMP_F32");
+		if (dumpi) {
+			FILE *f = fopen(dumpi, "wb");
+			if (f) { fwrite(r->state.renderBuffer->data.float_p, sizeof(float), (size_t)W * H * 3, f); fclose(f); }
+		}
+		logr(info, "%llu rays traced on %i GPU%s.\n", (unsigned long long)rays, gpus, PLURAL(gpus));
+		crh_flatten_free(&scene);
+		return output;
+	}
 	struct gpuWorker workers[MAX_GPUS];
 	memset(workers, 0, sizeof(workers));
 	for (int g = 0; g < gpus; ++g) {
@@ -178,10 +274,7 @@ struct texture *renderFrame(struct renderer *r) {
 	if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
 		logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
 
-	/* 8-bit output exactly like renderer.c:294-300: colorToSRGB + setPixel truncation, on the host */
-	for (int y = 0; y < H; ++y)
-		for (int x = 0; x < W; ++x)
-			setPixel(output, colorToSRGB(textureGetPixel(buf, x, y, false)), x, y);
+	resolveOutput(r, output);      /* 8-bit output exactly like renderer.c:294-300 */
 
 	const char *dump = getenv("CRH_DUMP_F32");
 	if (dump) {

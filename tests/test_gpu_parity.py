@@ -278,6 +278,23 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     assert bmp, "the reference's encoder wrote no image"
     data = open(tmp_path / bmp[0], "rb").read()
     assert data[:2] == b"BM" and len(data) >= w * h * 3
+    # --iterative: the interactive mode of the same program (Halton sampler, passes 1 .. samples-1, progressive chunks)
+    mi = manifest["cfg1_scene_iterative"]
+    scene = refrun.rewrite_scene("scene.json", w, h, mi["samples"], mi["bounces"], out_dir=str(tmp_path))
+    proc = subprocess.run([exe, "--iterative"], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-2000:]
+    img = np.fromfile(dump, dtype=np.float32).reshape(h, w, 3)
+    ctx.upload(pkg.api.Scene(golden_blob("cfg1_scene")))
+    fb = ctx.framebuffer(w, h)
+    ctx.set_option(pkg.abi.OPT_SAMPLER, pkg.abi.SAMPLER_HALTON)
+    try:
+        ctx.render_region(fb, w, h, mi["samples"], mi["bounces"], pass_count=mi["passes"])
+        assert np.array_equal(img, ctx.download(fb, w, h))
+    finally:
+        ctx.set_option(pkg.abi.OPT_SAMPLER, pkg.abi.SAMPLER_RANDOM)
+    st = image_stats(img, golden_ref("cfg1_scene_iterative"))
+    assert st["rmse"] <= 5e-3 and st["frac_gt_1e-3"] <= 5e-3, st
 
 
 def test_frame_renderer_on_torch_stream(pkg, ctx, manifest, golden_blob):

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 		if (h.inst < 0) {
 			out.poly = -1; out.material = CRH_NODE_NONE;
 		} else {
-			const HitInfo hi = finishHit(S, o, d, h);
+			const HitInfo hi = finishHit<false>(S, o, d, h);
 			out.poly = hitPoly(S, h); out.uv[0] = hi.uv.x; out.uv[1] = hi.uv.y;
 			out.point[0] = hi.point.x; out.point[1] = hi.point.y; out.point[2] = hi.point.z;
 			out.normal[0] = hi.normal.x; out.normal[1] = hi.normal.y; out.normal[2] = hi.normal.z;
@@ -674,7 +674,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(shade, cs.shade.data(), cs.shade.size());
 	UP(prims, scene->prim_indices, (size_t)scene->prim_index_count);
 	UP(instances, cs.instances.data(), cs.instances.size());
-	UP(materials, scene->materials, (size_t)scene->material_count);
+	UP(materials, cs.materials.data(), cs.materials.size());
 	UP(bsdfs, cs.bsdfs.data(), cs.bsdfs.size());
 	UP(consts, cs.consts.data(), cs.consts.size());
 	UP(images, cs.images.data(), cs.images.size());

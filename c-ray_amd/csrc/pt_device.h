@@ -1025,6 +1025,9 @@ CRH_DEV int32_t hitPoly(const DScene &S, const TravHit &hit) {
 	return inst->kind == CRH_DINST_SPHERE ? -1 : (int32_t)inst->poly_base + S.prims[hit.slot];
 }
 CRH_DEV v3 loadV3(const float *base, int64_t i) { const float *p = base + 3 * i; return v3{p[0], p[1], p[2]}; }
+/* LAZY_UV: shading skips a sphere's texture coordinates (atan2f + asinf, instance.c:33-43) when no node of the material's
+ * graph reads them (crh_material.pad[0], set by the scene compiler); crh_trace_rays always reports them. */
+template <bool LAZY_UV = true>
 CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravHit &hit) {
 	HitInfo h;
 	const DInstance *inst = &S.instances[hit.inst];
@@ -1034,14 +1037,16 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 	const v3 objPoint = alongRay(o, d, hit.t);
 	if (inst->kind == CRH_DINST_SPHERE) {
 		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
-		/* getTexMapSphere: instance.c:33-43 (object-space normal) */
-		float phi = atan2f(n.z, n.x);
-		float theta = asinf(n.y);
-		float v = (theta + CRH_PI / 2.0f) / CRH_PI;
-		float u = 1.0f - (phi + CRH_PI) / (CRH_PI * 2.0f);
-		u = wrap01(u);
-		v = wrap01(v);
-		h.uv = v2{u, v};
+		h.uv = v2{0.0f, 0.0f};
+		if (!LAZY_UV || S.materials[inst->material].pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
+			float phi = atan2f(n.z, n.x);
+			float theta = asinf(n.y);
+			float v = (theta + CRH_PI / 2.0f) / CRH_PI;
+			float u = 1.0f - (phi + CRH_PI) / (CRH_PI * 2.0f);
+			u = wrap01(u);
+			v = wrap01(v);
+			h.uv = v2{u, v};
+		}
 		h.material = inst->material;
 		h.point = xfPoint(objPoint, inst->A);
 		h.normal = xfVectorT(n, inst->Ainv);                      /* not renormalised: instance.c:56 */

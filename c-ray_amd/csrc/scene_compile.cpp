@@ -37,6 +37,7 @@ struct Compiler {
 	const crh_scene_desc *s;
 	CompiledScene &out;
 	std::map<uint32_t, uint32_t> oprMemo;
+	std::vector<uint8_t> needUv;          /* per bsdf gnode: its graph reads the hit's uv */
 
 	Compiler(const crh_scene_desc *scene, CompiledScene &o) : s(scene), out(o) {}
 
@@ -224,6 +225,8 @@ struct Compiler {
 		const uint32_t N = (uint32_t)s->gnode_count;
 		out.bsdfs.assign(N ? N : 1, DBsdf{0, CRH_NONE, CRH_NONE, CRH_NONE});
 		std::vector<uint32_t> addDepth(N, 0);
+		needUv.assign(N, 0);
+		auto oprUv = [](uint32_t opr) { const uint32_t k = opr >> 29; return opr != CRH_NONE && (k == CRH_OPR_IMAGE || k == CRH_OPR_IMAGE_ALPHA || k == CRH_OPR_PROGRAM); };
 		for (uint32_t g = 0; g < N; ++g) {
 			const crh_gnode &n = s->gnodes[g];
 			if (!isBsdfKind(n.kind)) continue;
@@ -245,6 +248,14 @@ struct Compiler {
 				case CRH_BSDF_EMISSION: d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, VALUE); break;
 				case CRH_BSDF_BACKGROUND: d.a = operand(n.a, g, COLOR); d.b = operand(n.b, g, VALUE); d.c = operand(n.c, g, VALUE); break;
 				default: break;
+			}
+			{   /* does anything below this bsdf read rec.uv? (images and programs do; constants and gradients do not) */
+				const bool kids = n.kind == CRH_BSDF_MIX || n.kind == CRH_BSDF_ADD;
+				bool u = false;
+				if (kids) u = needUv[n.a] || needUv[n.b] || (n.kind == CRH_BSDF_MIX && oprUv(d.c));
+				else if (n.kind == CRH_BSDF_PLASTIC) u = oprUv(d.a) || oprUv(d.b) || needUv[n.c];
+				else u = oprUv(d.a) || oprUv(d.b) || oprUv(d.c);
+				needUv[g] = u ? 1 : 0;
 			}
 			CHECK(addDepth[g] <= CRH_ADD_DEPTH, CRH_ERR_UNSUPPORTED, "bsdf node %u nests add nodes %u deep (device limit %d)", g, addDepth[g], CRH_ADD_DEPTH);
 			out.max_add_depth = std::max(out.max_add_depth, addDepth[g]);
@@ -305,9 +316,12 @@ struct Compiler {
 		compileGraph();
 		CHECK(s->background < s->gnode_count && s->gnodes[s->background].kind == CRH_BSDF_BACKGROUND, CRH_ERR_INVALID, "scene.background is not a background node");
 		out.background = s->background;
+		out.materials.assign(s->materials, s->materials + s->material_count);
+		if (out.materials.empty()) { crh_material z; memset(&z, 0, sizeof(z)); out.materials.push_back(z); }
 		for (uint64_t m = 0; m < s->material_count; ++m) {
 			const uint32_t b = s->materials[m].bsdf;
 			CHECK(b < s->gnode_count && isBsdfKind(s->gnodes[b].kind) && s->gnodes[b].kind != CRH_BSDF_BACKGROUND, CRH_ERR_INVALID, "material %llu has no surface bsdf", (unsigned long long)m);
+			out.materials[m].pad[0] = needUv[b];
 		}
 
 		/* BLAS per mesh, prepared triangles */

@@ -33,6 +33,7 @@ struct CompiledScene {
 	std::vector<DShadeTri> shade;
 	std::vector<DInstance> instances;
 	std::vector<DBsdf> bsdfs;
+	std::vector<crh_material> materials;   /* scene materials + pad[0] = 1 when the material's bsdf graph reads the hit's uv */
 	std::vector<f4> consts;
 	std::vector<DImage> images;
 	std::vector<DOp> prog;

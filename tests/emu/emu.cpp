@@ -33,7 +33,7 @@ DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
 	DScene d;
 	memset(&d, 0, sizeof(d));
 	d.nodes = c.nodes.data(); d.tris = c.tris.data(); d.prims = s->prim_indices; d.shade = c.shade.data();
-	d.instances = c.instances.data(); d.materials = s->materials;
+	d.instances = c.instances.data(); d.materials = c.materials.data();
 	d.bsdfs = c.bsdfs.data(); d.consts = c.consts.data(); d.images = c.images.data(); d.prog = c.prog.data();
 	d.textures = c.textures.data(); d.texels = c.texels.data();
 	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base;
@@ -131,7 +131,7 @@ int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, c
 		memset(oh, 0, sizeof(*oh));
 		oh->inst = h.inst < 0 ? -1 : (int32_t)d.instances[h.inst].orig; oh->distance = h.t; oh->node_tests = cnt.node_tests; oh->tri_tests = cnt.tri_tests;
 		if (h.inst < 0) { oh->poly = -1; oh->material = CRH_NODE_NONE; continue; }
-		const HitInfo hi = finishHit(d, o, dd, h);
+		const HitInfo hi = finishHit<false>(d, o, dd, h);
 		oh->poly = hitPoly(d, h); oh->uv[0] = hi.uv.x; oh->uv[1] = hi.uv.y;
 		oh->point[0] = hi.point.x; oh->point[1] = hi.point.y; oh->point[2] = hi.point.z;
 		oh->normal[0] = hi.normal.x; oh->normal[1] = hi.normal.y; oh->normal[2] = hi.normal.z;

@@ -219,6 +219,12 @@ class Context:
                                               prims.ctypes.data, C.byref(n), C.byref(st)), "crh_bvh_build_triangles")
         return nodes[:n.value], prims[:poly_count], {k: getattr(st, k) for k, _ in abi.BvhBuildStats._fields_ if k != "pad"}
 
+    def frames_reduce(self, fb, width, height):
+        """crh_frames_reduce over this one context (n = 1: a no-op unless CRH_FORCE_RCCL is set)."""
+        ctxs = (C.c_void_p * 1)(self.h)
+        fbs = (C.c_void_p * 1)(fb)
+        _check(self.L.crh_frames_reduce(ctxs, fbs, 1, width, height), "crh_frames_reduce")
+
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         hits = np.zeros(len(rays), dtype=abi.HIT_DTYPE)

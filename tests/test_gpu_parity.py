@@ -297,6 +297,65 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     assert st["rmse"] <= 5e-3 and st["frac_gt_1e-3"] <= 5e-3, st
 
 
+def test_c_host_reduce_goes_through_rccl(pkg, manifest, golden_blob, tmp_path):
+    """crh_frames_reduce (the C host's frame assembly) on the one GPU that is here: with CRH_FORCE_RCCL the single-rank case
+    takes the real path (dlopen librccl, ncclCommInitAll, grouped in-place ncclReduce on the context's stream) and must
+    leave the frame unchanged. Runs in its own process (the RCCL communicator is process-wide state)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = manifest["fence"]
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r})
+from __graft_entry__ import load_package
+pkg = load_package(); api = pkg.api
+ctx = api.Context(0); ctx.upload(api.Scene({golden_blob("fence")!r}))
+w, h, s, b = {m["width"]}, {m["height"]}, {m["samples"]}, {m["bounces"]}
+fb = ctx.framebuffer(w, h); ctx.render_region(fb, w, h, s, b)
+before = ctx.download(fb, w, h)
+ctx.frames_reduce(fb, w, h); ctx.frames_reduce(fb, w, h)
+after = ctx.download(fb, w, h)
+assert before.any() and np.array_equal(before, after)
+print("reduce ok")
+"""
+    proc = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRH_FORCE_RCCL="1"), stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0 and b"reduce ok" in proc.stdout, proc.stdout.decode(errors="replace")[-2000:]
+
+
+def test_bench_reduce_path_with_a_one_rank_rccl_group(pkg, manifest, golden_blob):
+    """bench.py's N > 1 step (FrameRenderer.render + torch.distributed.reduce over backend nccl = RCCL) with the one rank
+    that can exist here: process group on 127.0.0.1, the framebuffer tensor reduced in place on the renderer's stream."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = manifest["fence"]
+    code = f"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from __graft_entry__ import load_package
+pkg = load_package()
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+w, h, s, b = {m["width"]}, {m["height"]}, {m["samples"]}, {m["bounces"]}
+fr = pkg.render.FrameRenderer(pkg.api, pkg.api.Scene({golden_blob("fence")!r}), w, h, device=0, rank=0, world=1, tile=(32, 32))
+fr.render(s, b); torch.cuda.synchronize(); before = fr.fb.cpu().numpy().copy()
+for _ in range(2):
+    fr.render(s, b)
+    with torch.cuda.stream(fr.stream):
+        dist.reduce(fr.fb, dst=0, op=dist.ReduceOp.SUM)
+dist.barrier(); torch.cuda.synchronize()
+assert before.any() and np.array_equal(fr.fb.cpu().numpy(), before)
+dist.destroy_process_group()
+print("nccl reduce ok")
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0 and b"nccl reduce ok" in proc.stdout, proc.stdout.decode(errors="replace")[-2000:]
+
+
 def test_frame_renderer_on_torch_stream(pkg, ctx, manifest, golden_blob):
     """The torch.distributed host (render.py): kernels on a torch stream, framebuffer = torch tensor. Same frame as the
     plain C-ABI path, for the full tile list and for an interleaved 1-of-2 share (the other half stays exactly zero)."""

@@ -2,16 +2,19 @@
  * cray_hip.hip — libcray_hip.so: the C-ABI of include/cray_hip.h and the gfx950 kernels behind it.
  *
  * Kernels (all hand-written for CDNA4, wave = 64):
- *   k_pathtrace<LEVEL>   persistent-thread path tracer: one ray per lane. A wave pulls one pixel block
- *                        (8x8 / 4x4) at a time from a global queue (one atomic per wave, readfirstlane
- *                        broadcast) and strides its 64 lanes over the block's (pixel, pass) items: a lane
- *                        whose path ended starts its next item in the same loop iteration, so lanes are
- *                        refilled instead of idling, and all lanes of a wave stay on the same few pixels
- *                        (coherent BVH walks). Samples are staged per wave and folded into the running mean
- *                        in pass order (renderer.c:288-291). Traversal stack in LDS (entry-major,
- *                        conflict-free); deeper entries in a private array.
+ *   k_pathtrace<LEVEL, WPS, PROG, SAMP>   the hot kernel: persistent grid, every wave a small wavefront machine. A wave
+ *                        pulls pixel blocks from a global queue (one atomic per wave, readfirstlane broadcast); the
+ *                        block's (pixel, pass) paths live in a per-wave table of 128-byte records (global memory),
+ *                        their ids on LDS byte stacks (rays / hits / misses / free); lanes are workers, and each
+ *                        iteration the wave ballots its lanes' needs and runs ONE kind of step for all of them: BVH node
+ *                        pair, two triangles, instance entry, retire + refill, generate 64 camera rays, shade 64 hits,
+ *                        64 background misses (see the comment inside the kernel and DESIGN.md section 3). Samples are
+ *                        staged per wave and folded into the running mean in pass order (renderer.c:288-291).
+ *                        Traversal stack in LDS (entry-major, conflict-free); deeper entries in a private array.
+ *   k_fold_black         bounces <= 0: every sample is black, only the running mean moves.
  *   k_trace_rays         getClosestIsect for caller rays (diagnostic / parity entry).
  *   k_to_srgb8           colorToSRGB + setPixel truncation.
+ * bvh_build.hip (same library): the reference's binned-SAH BVH builder on the GPU (crh_bvh_build_triangles).
  * No CPU fallback: every entry point fails with CRH_ERR_NO_DEVICE when there is no GPU.
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see c-ray_amd/build.py).
  */

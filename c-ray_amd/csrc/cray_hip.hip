@@ -965,7 +965,7 @@ int crh_kernel_time_ms(crh_ctx *c, float *last_ms, double *total_ms, uint64_t *l
 }
 
 /* debug: wall-clock ticks (100 MHz), summed over waves, spent in {item setup, BVH walk, shading} by the counting kernel */
-int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* 11 values: ticks {setup, walk, shade}, wave steps {node, tri, ctrl, all, shade, setup}, lanes served {node, shade} */) {
+int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* CRH_NCOUNTERS - 8 = 24 values: clocks {tri, node, shade}, wave steps {node, tri, ctrl, rounds, shade}, ctrl clock, lanes served {node, shade}, swap / gen clocks and counts, lanes {swap, tri, ctrl} */) {
 	if (!c || !out3) return fail(CRH_ERR_INVALID, "crh_debug_phase_ticks: NULL argument");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;

@@ -269,7 +269,7 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);
-int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out3);
+int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out24);   /* debug: 24 values — per-step-kind clocks (10 ns ticks), step counts and lanes served of the counter-level-2 kernel */
 
 /* SURVEY.md 8(f) row 1 — replaces buildBottomLevelBvh() (src/accelerators/bvh.c:299-301 -> buildBvhGeneric, bvh.c:245-287,
  * with getPolyBBoxAndCenter, bvh.c:289-297): the reference's binned-SAH builder on the GPU. The result is THE reference's

@@ -85,6 +85,10 @@ struct BlockQueue {
 	uint32_t ntiles, total;
 	uint32_t *counter;
 	int bw, bh;
+	/* the last tiles of the list (from firstSmall on) are cut into smaller blocks (sbw x sbh): the units handed out last
+	 * are short, so the waves finish close together instead of up to one full unit apart */
+	uint32_t firstSmall;
+	int sbw, sbh;
 };
 
 /* Pointers that arrive inside a by-value kernel-argument struct are generic ("flat") to the compiler; a round
@@ -183,13 +187,14 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
 		const crh_tile t = asGlobal(Q.tiles)[lo];
 		const uint32_t local = unit - asGlobal(Q.start)[lo];
-		const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + Q.bw - 1) / (uint32_t)Q.bw;
+		const int ubw = lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstSmall ? Q.sbh : Q.bh;
+		const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + ubw - 1) / (uint32_t)ubw;
 		BlockJob J;
-		J.bw = Q.bw; J.bh = Q.bh;
-		J.x0 = t.x0 + (int)(local % nbx) * Q.bw;
-		J.y0 = t.y0 + (int)(local / nbx) * Q.bh;
-		J.w = min(Q.bw, t.x1 - J.x0);
-		J.h = min(Q.bh, t.y1 - J.y0);
+		J.bw = ubw; J.bh = ubh;
+		J.x0 = t.x0 + (int)(local % nbx) * ubw;
+		J.y0 = t.y0 + (int)(local / nbx) * ubh;
+		J.w = min(ubw, t.x1 - J.x0);
+		J.h = min(ubh, t.y1 - J.y0);
 		for (int c0 = P.first_pass; c0 < passEnd; c0 += chunk) {
 			J.passBegin = c0;
 			J.passCount = min(chunk, passEnd - c0);
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 			}
 			(void)validItems;
 			__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
-			for (uint32_t pix = lane; pix < (uint32_t)(Q.bw * Q.bh); pix += 64u) foldBlockPixel(P, J, pix, myStage, fb);
+			for (uint32_t pix = lane; pix < (uint32_t)(J.bw * J.bh); pix += 64u) foldBlockPixel(P, J, pix, myStage, fb);
 			__threadfence_block();                 /* ... and read before the next chunk overwrites them */
 		}
 	}
@@ -502,6 +507,7 @@ struct crh_ctx {
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
 	int sampler = CRH_SAMPLER_RANDOM;
+	int tailPercent = 16;       /* share of a dispatch's pixels that is cut into quarter-size blocks at the end of the work queue */
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;
 	float *dStage = nullptr;
@@ -643,6 +649,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			c->sched = k;
 			return CRH_OK;
 		}
+		case CRH_OPT_TAIL_PERCENT:
+			if (value < 0 || value > 50) return fail(CRH_ERR_INVALID, "tail percent must be 0..50");
+			c->tailPercent = (int)value; return CRH_OK;
 		case CRH_OPT_SAMPLER:
 			if (value != CRH_SAMPLER_RANDOM && value != CRH_SAMPLER_HALTON) return fail(CRH_ERR_INVALID, "sampler must be CRH_SAMPLER_RANDOM or CRH_SAMPLER_HALTON");
 			c->sampler = (int)value; return CRH_OK;
@@ -768,17 +777,50 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	while (area > 1 && pixels / area < (uint64_t)c->unitsPerWave * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
 	int bw = 1, bh = 1;
 	while (bw * bh < area) { if (bw <= bh) bw *= 2; else bh *= 2; }
-	std::vector<uint32_t> start(tile_count + 1, 0);
-	uint64_t total = 0;
 	for (uint32_t t = 0; t < tile_count; ++t) {
 		const crh_tile &r = tiles[t];
 		if (r.x0 < 0 || r.y0 < 0 || r.x1 > P->image_width || r.y1 > P->image_height || r.x0 > r.x1 || r.y0 > r.y1)
 			return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
+	}
+	/* Tapered units: the work queue is consumed in list order, so the tail of the list decides how far apart the waves
+	 * finish. The last tailPercent of the pixels (whole tiles from the end of the list, the boundary tile split by rows)
+	 * are cut into blocks of a quarter of the area. */
+	std::vector<crh_tile> work(tiles, tiles + tile_count);
+	uint32_t firstSmall = tile_count;
+	int sbw = bw, sbh = bh;
+	if (area >= 4 && c->tailPercent > 0) {
+		sbw = 1; sbh = 1;
+		while (sbw * sbh < area / 4) { if (sbw <= sbh) sbw *= 2; else sbh *= 2; }
+		const uint64_t want = pixels * (uint64_t)c->tailPercent / 100;
+		uint64_t got = 0;
+		uint32_t t = tile_count;
+		while (t > 0 && got < want) {
+			const crh_tile r = work[t - 1];
+			const uint64_t a = (uint64_t)(r.x1 - r.x0) * (uint64_t)(r.y1 - r.y0);
+			if (got + a <= want + want / 4 || r.y1 - r.y0 < 2) { got += a; --t; continue; }
+			/* split this tile by rows: the upper part (in list order: first) keeps the big blocks */
+			const int w = r.x1 - r.x0;
+			int rowsSmall = (int)((want - got + (uint64_t)w - 1) / (uint64_t)(w ? w : 1));
+			rowsSmall = std::min(std::max(rowsSmall, 1), r.y1 - r.y0 - 1);
+			const int ySplit = r.y1 - rowsSmall;                 /* rows are independent: which part goes first is free */
+			work[t - 1] = crh_tile{r.x0, r.y0, r.x1, ySplit};
+			work.insert(work.begin() + t, crh_tile{r.x0, ySplit, r.x1, r.y1});
+			got = want;
+			break;
+		}
+		firstSmall = t;
+	}
+	const uint32_t work_count = (uint32_t)work.size();
+	std::vector<uint32_t> start(work_count + 1, 0);
+	uint64_t total = 0;
+	for (uint32_t t = 0; t < work_count; ++t) {
+		const crh_tile &r = work[t];
+		const int ubw = t >= firstSmall ? sbw : bw, ubh = t >= firstSmall ? sbh : bh;
 		start[t] = (uint32_t)total;
-		total += (uint64_t)((r.x1 - r.x0 + bw - 1) / bw) * ((r.y1 - r.y0 + bh - 1) / bh);
+		total += (uint64_t)((r.x1 - r.x0 + ubw - 1) / ubw) * ((r.y1 - r.y0 + ubh - 1) / ubh);
 		if (total > 0xFFFFFFF0ull) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: more than 2^32 pixel blocks in one dispatch");
 	}
-	start[tile_count] = (uint32_t)total;
+	start[work_count] = (uint32_t)total;
 	if (total == 0 || P->pass_count == 0) return CRH_OK;
 
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (total + 3) / 4);
@@ -811,23 +853,24 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 
 	/* per-launch tile list in HBM (freed once the stream has drained) */
 	void *dTiles = nullptr;
-	const size_t tileBytes = tile_count * sizeof(crh_tile), startBytes = (tile_count + 1) * sizeof(uint32_t);
+	const size_t tileBytes = work_count * sizeof(crh_tile), startBytes = (work_count + 1) * sizeof(uint32_t);
 	HIP_TRY(hipMalloc(&dTiles, tileBytes + startBytes));
 	c->deferredFrees.push_back(dTiles);
-	HIP_TRY(hipMemcpy(dTiles, tiles, tileBytes, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(dTiles, work.data(), tileBytes, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy((char *)dTiles + tileBytes, start.data(), startBytes, hipMemcpyHostToDevice));
 
 	BlockQueue Q;
 	Q.tiles = (const crh_tile *)dTiles;
 	Q.start = (const uint32_t *)((char *)dTiles + tileBytes);
-	Q.ntiles = tile_count;
+	Q.ntiles = work_count;
 	Q.total = (uint32_t)total;
 	Q.counter = c->dWork + (c->workSlot++ % CRH_WORK_SLOTS);
 	Q.bw = bw; Q.bh = bh;
+	Q.firstSmall = firstSmall; Q.sbw = sbw; Q.sbh = sbh;
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
 
 	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */
-		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(tile_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, tile_count, dev_fb);
+		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(work_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, work_count, dev_fb);
 		hipError_t e0 = hipGetLastError();
 		if (e0 != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_fold_black launch: ") + hipGetErrorString(e0));
 		return CRH_OK;

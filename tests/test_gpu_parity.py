@@ -98,6 +98,15 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
         ctx.render_region(fb, w, h, s, b)
         assert np.array_equal(ctx.download(fb, w, h), full), sched
     ctx.set_sched(70, 160, 120, 32)
+    # tapered units: how much of the dispatch ends the work queue as quarter-size blocks (incl. a row-split of the single tile)
+    for tail in (0, 50, 7):
+        ctx.set_option(pkg.abi.OPT_TAIL_PERCENT, tail)
+        ctx.clear(fb, w, h)
+        ctx.reset_counters()
+        ctx.render_region(fb, w, h, s, b)
+        assert np.array_equal(ctx.download(fb, w, h), full), tail
+        assert ctx.counters() == cnt_full
+    ctx.set_option(pkg.abi.OPT_TAIL_PERCENT, 16)
     # both register-budget variants and both counter levels compute the same frame
     for wps, level in ((1, 2), (1, 1), (4, 1)):
         ctx.set_option(pkg.abi.OPT_WAVES_PER_SIMD, wps)

@@ -1223,7 +1223,15 @@ CRH_DEV void foldBlockPixel(const crh_render_params &P, const BlockJob &J, uint3
 	float *out = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;
 	float r = out[0], g = out[1], b = out[2];
 	const float *sp = stage + (size_t)pix * (size_t)J.passCount * 3;
-	for (int k = 0; k < J.passCount; ++k) foldSample(r, g, b, sp[3 * k], sp[3 * k + 1], sp[3 * k + 2], J.passBegin + k + 1);
+	/* the mean is a serial chain, the loads are not: fetch eight samples at a time, then fold them in pass order (one
+	 * load latency per eight passes instead of one per pass — a block's fold is on the critical path of its wave) */
+	int k = 0;
+	for (; k + 8 <= J.passCount; k += 8) {
+		float s[24];
+		for (int i = 0; i < 24; ++i) s[i] = sp[3 * k + i];
+		for (int j = 0; j < 8; ++j) foldSample(r, g, b, s[3 * j], s[3 * j + 1], s[3 * j + 2], J.passBegin + k + j + 1);
+	}
+	for (; k < J.passCount; ++k) foldSample(r, g, b, sp[3 * k], sp[3 * k + 1], sp[3 * k + 2], J.passBegin + k + 1);
 	out[0] = r; out[1] = g; out[2] = b;
 }
 

@@ -12,7 +12,7 @@ scene = api.Scene(os.path.join(BUILT, "cfg2_hdr.blob")); ctx.upload(scene)
 w, h, b = 1280, 720, 8
 fb = ctx.framebuffer(w, h)
 for spp in (32, 256):
-    for items, upw, tail in ((2048, 8, 0), (2048, 8, 12), (2048, 8, 16), (2048, 8, 24), (2048, 8, 32)):
+    for items, upw, tail in ((2048, 8, 0), (2048, 8, 16), (1024, 16, 16), (1024, 16, 24), (512, 32, 16)):
         ctx.set_option(abi.OPT_UNIT_ITEMS, items); ctx.set_option(abi.OPT_UNITS_PER_WAVE, upw); ctx.set_option(abi.OPT_TAIL_PERCENT, tail)
         best = None
         for rep in range(2):

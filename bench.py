@@ -5,10 +5,10 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one full frame: every rank renders ITS tiles of the reference's ordered tile list (tile.c order,
-64x64 tiles from the scene JSON, rank r takes tiles r, r+N, ...) for all 256 passes in one dispatch of the
-persistent kernel, then the float framebuffers are summed onto rank 0 with one RCCL reduce (non-owned
-pixels are exactly 0, so the sum is a gather). The frame is a fixed job, so N > 1 is STRONG scaling.
+One step = one full frame: every rank renders ITS share of the frame (N = 1: the reference's ordered 64x64 tile list;
+N > 1: every N-th 4-row strip, which balances the ranks where dealing out tiles does not — c-ray_amd/render.py) for
+all 256 passes in one dispatch of the persistent kernel, then the float framebuffers are summed onto rank 0 with one
+RCCL reduce (non-owned pixels are exactly 0, so the sum is a gather). The frame is a fixed job, so N > 1 is STRONG scaling.
 value = rays (getClosestIsect calls, primary + secondary, counted by the kernel) of all ranks / wall time.
 
 Extra objects on the JSON line (N = 1 only for cpu_baseline):
@@ -181,7 +181,8 @@ def main():
             "config": {"workload": f"input/hdr.json {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[1]); venusscaled.obj = "
                                    "generated 524288-triangle stand-in (tools/gen_assets.py), HDR env map + 2048^2 grid texture from the reference tree",
                        "rays_per_step": int(total_rays / a.steps), "paths_per_step": int(total_paths / a.steps),
-                       "parallelism": f"tiles 64x64 interleaved over {world} rank(s) + RCCL reduce of the float framebuffer"},
+                       "parallelism": ("1 rank: the reference's 64x64 tile list in one dispatch" if world == 1 else
+                                       f"4-row strips interleaved over {world} ranks + one RCCL reduce of the float framebuffer")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_pathtrace", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg),

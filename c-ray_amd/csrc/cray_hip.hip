@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #define CRH_NCOUNTERS 32
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, swapMin; };
+struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo; };
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 				if (hitsQ >= 64) pick = ST_SHADE;
 				else if (missQn >= 64) pick = ST_MISS;
 				else if (nF + nE >= K.swapMin && (nF > 0 || (nE > 0 && raysQ > 0))) pick = ST_SWAP;
-				else if (canGen && raysQ < 64 && nE + nF > 0 && raysQ < nE + nF) pick = ST_GEN;
+				/* generate when lanes are out of rays — and whenever fewer than fillTo paths are in flight: a full table means full
+				 * shading batches from the start of a job on */
+				else if (canGen && raysQ < 64 && (((int)CRH_PATHS - freeQ) < K.fillTo || (nE + nF > 0 && raysQ < nE + nF))) pick = ST_GEN;
 				else if (walkers > 0) {
 					int best = nN * K.wNode;
 					pick = ST_NODE;
@@ -502,7 +504,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 32};
+	Sched sched = {70, 160, 120, 32, 192};
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
@@ -644,7 +646,8 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			if (value != 1 && value != 4) return fail(CRH_ERR_INVALID, "waves per SIMD must be 1 (unconstrained) or 4");
 			c->wavesPerSimd = (int)value; return CRH_OK;
 		case CRH_OPT_SCHED_WEIGHTS: {  /* four 12-bit fields, low to high: node, tri, ctrl weights; finished + idle lanes that trigger a swap step */
-			const Sched k = {(int)(value & 0xFFF), (int)((value >> 12) & 0xFFF), (int)((value >> 24) & 0xFFF), (int)((value >> 36) & 0xFFF)};
+			Sched k = {(int)(value & 0xFFF), (int)((value >> 12) & 0xFFF), (int)((value >> 24) & 0xFFF), (int)((value >> 36) & 0xFFF), c->sched.fillTo};
+			if ((value >> 48) & 0x1FF) k.fillTo = (int)((value >> 48) & 0x1FF) - 1;      /* optional fifth field: paths to keep in flight, stored + 1 */
 			if (k.wNode < 1 || k.wTri < 1 || k.wCtrl < 1 || k.swapMin < 1 || k.swapMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
 			c->sched = k;
 			return CRH_OK;

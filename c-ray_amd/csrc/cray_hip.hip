@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #define CRH_NCOUNTERS 32
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo; };
+struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum; };
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 				uint32_t tk = 0;
 				if constexpr (LEVEL >= 2) tk = CRH_TICK();
 				switch (pick) {
-					case ST_NODE: {          /* keep stepping while at least 3/4 of the lanes that started this run still want node steps */
+					case ST_NODE: {          /* keep stepping while at least runNum/8 (half) of the lanes that started this run still want node steps */
 						int now = nN;
 						do {
 							if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
 							now = __popcll(__ballot(w.phase == PH_NODE));
-						} while (now * 4 >= nN * 3);
+						} while (now * 8 >= nN * K.runNum);
 						break;
 					}
 					case ST_TRI: {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_tri += 1; cnt.u_tri += (uint32_t)now; } }
 							now = __popcll(__ballot(w.phase == PH_TRI));
-						} while (now * 4 >= nT * 3);
+						} while (now * 8 >= nT * K.runNum);
 						break;
 					}
 					case ST_CTRL:
@@ -504,7 +504,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 32, 192};
+	Sched sched = {70, 160, 120, 32, 192, 4};
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
@@ -646,7 +646,8 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			if (value != 1 && value != 4) return fail(CRH_ERR_INVALID, "waves per SIMD must be 1 (unconstrained) or 4");
 			c->wavesPerSimd = (int)value; return CRH_OK;
 		case CRH_OPT_SCHED_WEIGHTS: {  /* four 12-bit fields, low to high: node, tri, ctrl weights; finished + idle lanes that trigger a swap step */
-			Sched k = {(int)(value & 0xFFF), (int)((value >> 12) & 0xFFF), (int)((value >> 24) & 0xFFF), (int)((value >> 36) & 0xFFF), c->sched.fillTo};
+			Sched k = {(int)(value & 0xFFF), (int)((value >> 12) & 0xFFF), (int)((value >> 24) & 0xFFF), (int)((value >> 36) & 0xFFF), c->sched.fillTo, c->sched.runNum};
+			if ((value >> 58) & 0xF) k.runNum = (int)((value >> 58) & 0xF);
 			if ((value >> 48) & 0x1FF) k.fillTo = (int)((value >> 48) & 0x1FF) - 1;      /* optional fifth field: paths to keep in flight, stored + 1 */
 			if (k.wNode < 1 || k.wTri < 1 || k.wCtrl < 1 || k.swapMin < 1 || k.swapMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
 			c->sched = k;

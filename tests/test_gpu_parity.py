@@ -92,12 +92,12 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
     ctx.set_option(pkg.abi.OPT_UNIT_ITEMS, 1024)
     ctx.set_option(pkg.abi.OPT_PASS_CHUNK, 64)
     # wave scheduler: which step kind runs when changes nothing a path computes
-    for sched in ((1, 1, 1, 1, 0), (400, 10, 10, 64, 64), (10, 10, 400, 8, 192)):
+    for sched in ((1, 1, 1, 1, 0, 8, 65), (400, 10, 10, 64, 64, 1, 1), (10, 10, 400, 8, 192, 4, 20)):
         ctx.set_sched(*sched)
         ctx.clear(fb, w, h)
         ctx.render_region(fb, w, h, s, b)
         assert np.array_equal(ctx.download(fb, w, h), full), sched
-    ctx.set_sched(70, 160, 120, 32, 192)
+    ctx.set_sched(70, 160, 120, 32)
     # tapered units: how much of the dispatch ends the work queue as quarter-size blocks (incl. a row-split of the single tile)
     for tail in (0, 50, 7):
         ctx.set_option(pkg.abi.OPT_TAIL_PERCENT, tail)

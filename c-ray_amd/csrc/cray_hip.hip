@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #define CRH_NCOUNTERS 32
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun; };
+struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun; };
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -260,9 +260,13 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						do {
 							if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
-							/* lanes that reached a leaf: test their triangles inside the run once enough of them wait */
+							/* lanes that reached a leaf or an instance: serve them inside the run once enough of them wait (no scheduling
+							 * round in between, and the node lanes they become again rejoin this run) */
 							if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) {
 								if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+							}
+							if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
+								if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt);
 							}
 							now = __popcll(__ballot(w.phase == PH_NODE));
 						} while (now * 8 >= nN * K.runNum);
@@ -508,7 +512,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 32, 192, 4, 12};
+	Sched sched = {70, 160, 120, 32, 192, 4, 12, 12};
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
@@ -656,10 +660,10 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			c->sched = k;
 			return CRH_OK;
 		}
-		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 */
+		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 | ctrlInRun << 24 */
 			Sched k = c->sched;
-			k.fillTo = (int)(value & 0xFFF); k.runNum = (int)((value >> 12) & 0xF); k.triInRun = (int)((value >> 16) & 0xFF);
-			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
+			k.fillTo = (int)(value & 0xFFF); k.runNum = (int)((value >> 12) & 0xF); k.triInRun = (int)((value >> 16) & 0xFF); k.ctrlInRun = (int)((value >> 24) & 0xFF);
+			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65 || k.ctrlInRun < 1 || k.ctrlInRun > 65) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
 			c->sched = k;
 			return CRH_OK;
 		}

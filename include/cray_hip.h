@@ -263,7 +263,8 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_SCHED_WEIGHTS 7   /* wave scheduler, four 12-bit fields: node | tri<<12 | ctrl<<24 step weights, finished+idle lanes that trigger a swap step <<36 (default 70,160,120,32) */
 #define CRH_OPT_SCHED_RUNS   11   /* wave scheduler: paths a wave keeps in flight before it waits for idle lanes to generate more (0..192, default 192)
                                    * | n<<12: a node / triangle run continues while n/8 of its lanes still want that step (default 4)
-                                   * | m<<16: inside a node run, triangles are tested as soon as m lanes wait for them (default 12; 65 = never) */
+                                   * | m<<16: inside a node run, triangles are tested as soon as m lanes wait for them (default 12; 65 = never)
+                                   * | k<<24: likewise instance entries / sphere tests (control steps), as soon as k lanes wait (default 12; 65 = never) */
 #define CRH_OPT_UNITS_PER_WAVE 8  /* shrink the pixel blocks until every wave gets at least this many work units (default 8) */
 #define CRH_OPT_SAMPLER       9   /* which sampler seeds a (pixel, pass): CRH_SAMPLER_RANDOM = renderThread (sampler.c:41-44, default),
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */

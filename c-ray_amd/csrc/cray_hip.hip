@@ -512,7 +512,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 32, 192, 4, 12, 12};
+	Sched sched = {70, 160, 120, 16, 192, 4, 12, 12};
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;

@@ -260,7 +260,7 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_PASS_CHUNK    3   /* passes a wave traces per pixel block before folding them (default 64)         */
 #define CRH_OPT_WAVES_PER_SIMD 4  /* register budget variant of the path-tracing kernel: 4 (<=128 VGPRs, default) or 1 */
 #define CRH_OPT_UNIT_ITEMS    6   /* paths per work unit (pixel block x passes) the block shape aims for (default 2048) */
-#define CRH_OPT_SCHED_WEIGHTS 7   /* wave scheduler, four 12-bit fields: node | tri<<12 | ctrl<<24 step weights, finished+idle lanes that trigger a swap step <<36 (default 70,160,120,32) */
+#define CRH_OPT_SCHED_WEIGHTS 7   /* wave scheduler, four 12-bit fields: node | tri<<12 | ctrl<<24 step weights, finished+idle lanes that trigger a swap step <<36 (default 70,160,120,16) */
 #define CRH_OPT_SCHED_RUNS   11   /* wave scheduler: paths a wave keeps in flight before it waits for idle lanes to generate more (0..192, default 192)
                                    * | n<<12: a node / triangle run continues while n/8 of its lanes still want that step (default 4)
                                    * | m<<16: inside a node run, triangles are tested as soon as m lanes wait for them (default 12; 65 = never)

@@ -97,7 +97,7 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
         ctx.clear(fb, w, h)
         ctx.render_region(fb, w, h, s, b)
         assert np.array_equal(ctx.download(fb, w, h), full), sched
-    ctx.set_sched(70, 160, 120, 32)
+    ctx.set_sched(70, 160, 120, 16)
     # tapered units: how much of the dispatch ends the work queue as quarter-size blocks (incl. a row-split of the single tile)
     for tail in (0, 50, 7):
         ctx.set_option(pkg.abi.OPT_TAIL_PERCENT, tail)

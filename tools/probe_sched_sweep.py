@@ -7,7 +7,7 @@ from __graft_entry__ import load_package, BUILT
 pkg = load_package(); api = pkg.api; abi = pkg.abi
 ctx = api.Context(0)
 ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
-SWEEP = [tuple(int(v) for v in s.split(",")) for s in sys.argv[1:]] or [(70, 160, 120, 32)]
+SWEEP = [tuple(int(v) for v in s.split(",")) for s in sys.argv[1:]] or [(70, 160, 120, 16)]
 for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("soup_1m", 2560, 1440, 16, 8), ("cfg4_statues", 3840, 2160, 4, 30)):
     scene = api.Scene(os.path.join(BUILT, name + ".blob"))
     ctx.upload(scene)

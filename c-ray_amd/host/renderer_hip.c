@@ -17,8 +17,8 @@
  * output with the reference's own colorToSRGB()/setPixel() on the host.
  *
  * --iterative (renderThreadInteractive, renderer.c:184-250): passes 1 .. sampleCount-1 with the Halton sampler, the frame
- * shown while it converges. Here the main thread drives every GPU pass-chunk by pass-chunk (tile i belongs to GPU i mod G for
- * the whole frame, so each pixel's running mean stays on one GPU), gathers the tiles on the host after each chunk and redraws.
+ * shown while it converges. Here the main thread drives every GPU pass-chunk by pass-chunk (every G-th 4-row strip belongs to
+ * one GPU for the whole frame, so each pixel's running mean stays on one GPU), gathers the strips on the host after each chunk and redraws.
  * The result is the reference's single-thread result: with several threads the reference itself races on
  * state.finishedPasses and is not reproducible.
  *
@@ -144,12 +144,18 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
 			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK)
 			logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
-		tiles[g] = calloc((size_t)tileCount / gpus + 1, sizeof(crh_tile));
+		tiles[g] = calloc((size_t)(gpus == 1 ? tileCount : H / 4 / gpus + 2), sizeof(crh_tile));
 		ntiles[g] = 0;
 	}
-	for (int i = 0; i < tileCount; ++i) {
-		const struct renderTile *t = &r->state.renderTiles[i];
-		tiles[i % gpus][ntiles[i % gpus]++] = (crh_tile){t->begin.x, t->begin.y, t->end.x, t->end.y};
+	if (gpus == 1) {
+		for (int i = 0; i < tileCount; ++i) {
+			const struct renderTile *t = &r->state.renderTiles[i];
+			tiles[0][ntiles[0]++] = (crh_tile){t->begin.x, t->begin.y, t->end.x, t->end.y};
+		}
+	} else {
+		/* static shares must be balanced: 4-row strips dealt round-robin (dealing out the tile list is not) */
+		for (int y = 0, i = 0; y < H; y += 4, ++i)
+			tiles[i % gpus][ntiles[i % gpus]++] = (crh_tile){0, y, W, y + 4 < H ? y + 4 : H};
 	}
 	const int passes = r->prefs.sampleCount - 1;             /* finishedPasses runs from 1 while < sampleCount (renderer.c:199, tile.c:52) */
 	crh_render_params p;

@@ -900,12 +900,16 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 #define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
+#ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/kernel_regs.py): one instantiation compiles in seconds */
+	CRH_LAUNCH(1, 4, false, 0);
+#else
 	if (c->sampler == CRH_SAMPLER_HALTON) {          /* interactive mode: the 128-register variants only */
 		if (c->counterLevel >= 2) { if (c->hasPrograms) CRH_LAUNCH(2, 4, true, 1); else CRH_LAUNCH(2, 4, false, 1); }
 		else { if (c->hasPrograms) CRH_LAUNCH(1, 4, true, 1); else CRH_LAUNCH(1, 4, false, 1); }
 	}
 	else if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
 	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
+#endif
 #undef CRH_LAUNCH2
 #undef CRH_LAUNCH
 	hipError_t e = hipGetLastError();

@@ -97,3 +97,24 @@ def camera_rays(desc, n, seed):
     rays[:, 0:3] = A[:, 3]
     rays[:, 3:6] = (local @ A[:, :3].T).astype(np.float32)
     return rays
+
+
+BIG_CASES = ["cfg2_hdr_small", "cfg3_venus_small", "cfg4_statues_small", "soup_1m_small"]
+
+
+def built_blob(name):
+    """Path of scenes/_built/<name>.blob (made by __graft_entry__.build() where /root/reference exists; travels to the GPU box)."""
+    from __graft_entry__ import BUILT
+    path = os.path.join(BUILT, name + ".blob")
+    if not os.path.exists(path):
+        pytest.skip(f"scenes/_built/{name}.blob not built")
+    return path
+
+
+def resize_camera(scene, width, height):
+    """The blobs of BASELINE.json configs[1..4] are flattened at full frame size; a frame of the same aspect ratio differs only in
+    camera.width / height (camera.c:27-32: the sensor is a function of FOV and aspect ratio)."""
+    cam = scene.desc.camera
+    assert cam.width * height == cam.height * width, "resize_camera keeps the aspect ratio"
+    cam.width, cam.height = width, height
+    return scene

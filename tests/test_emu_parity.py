@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import camera_rays
+from conftest import BIG_CASES, built_blob, camera_rays, resize_camera
 
 CASES = ["cfg1_scene", "alphanode", "fence", "glowmetal", "refraction", "uvsphere"]
 
@@ -36,6 +36,17 @@ def test_emulated_kernel_bit_exact_vs_reference(name, emu, oracle, manifest, gol
     mx = C.c_uint32()
     assert emu.emu_compile_check(scene.ptr, C.byref(mx), None, None) == 0
     assert high <= mx.value, "traversal stack bound computed by the scene compiler was exceeded"
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_emulated_kernel_bit_exact_on_baseline_configs_reduced_frame(name, emu, oracle, manifest, golden_ref):
+    """BASELINE.json configs[1..4] at 320x180 through the device lane code built for the host: the reference's frame bit for bit."""
+    m = manifest[name]
+    scene = resize_camera(oracle.OracleScene(built_blob(m["built_blob"])), m["width"], m["height"])
+    fb, cnt, _ = emu_render(emu, oracle, scene, m["width"], m["height"], m["samples"], m["bounces"])
+    ref = golden_ref(name)
+    assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32)), f"{name}: {(fb != ref).sum()} floats differ"
+    assert cnt["rays"] == m["rays"] and cnt["node_tests"] <= m["node_tests"] and cnt["node_tests"] >= 0.98 * m["node_tests"]
 
 
 def test_emulated_kernel_interactive_mode_bit_exact(emu, oracle, manifest, golden_blob, golden_ref):

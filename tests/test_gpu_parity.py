@@ -13,7 +13,7 @@ Tolerances (stated once, used everywhere below):
 import numpy as np
 import pytest
 
-from conftest import camera_rays, image_stats
+from conftest import BIG_CASES, built_blob, camera_rays, image_stats, resize_camera
 
 pytestmark = pytest.mark.gpu
 CASES = ["cfg1_scene", "alphanode", "fence", "glowmetal", "refraction", "uvsphere"]
@@ -61,6 +61,70 @@ def test_image_parity_vs_reference(name, pkg, ctx, oracle, manifest, golden_blob
     assert abs(cnt["rays"] - m["rays"]) <= 0.002 * m["rays"], (cnt["rays"], m["rays"])
     assert abs(cnt["node_tests"] - m["node_tests"]) <= 0.02 * m["node_tests"]
     assert np.isfinite(img).all()
+
+
+@pytest.mark.parametrize("name", ["cfg3_venus", "cfg4_statues", "soup_1m"])
+def test_trace_rays_bit_exact_on_baseline_configs(name, pkg, ctx, oracle):
+    """BASELINE.json configs[2..4] at full scene size (deep BLAS; 55-instance TLAS; 1 M-triangle soup without normals):
+    getClosestIsect records and per-ray node / triangle test counts equal the oracle's bit for bit."""
+    blob = built_blob(name)
+    ctx.upload(pkg.api.Scene(blob))
+    oscene = oracle.OracleScene(blob)
+    rays = camera_rays(oscene.desc, 50000, 7)
+    hg, ho = ctx.trace_rays(rays), oracle.trace_rays(oscene, rays)
+    for f in ("inst", "poly", "distance", "point", "normal", "node_tests", "tri_tests", "material"):
+        assert np.array_equal(hg[f], ho[f]), f"{name}: {f} differs in {(hg[f] != ho[f]).sum()} records"
+    assert np.abs(hg["uv"] - ho["uv"]).max() <= 1e-6
+    assert (ho["inst"] >= 0).sum() > 500
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_image_parity_on_baseline_configs_reduced_frame(name, pkg, ctx, manifest, golden_ref):
+    """BASELINE.json configs[1..4] at 320x180, 4 spp, the configs' own bounce limits, against the real reference's frame
+    (c-ray-ref-strict). Gates: the usual ones (RMSE <= 5e-3, <= 0.5 % of pixels with per-pixel L2 > 1e-3) or, for a scene whose
+    own chaos is larger than that, the chaos floor recorded next to the fixture — how far the SAME reference C sources land from
+    themselves when only FMA contraction changes (statues.json: a transparent plane re-hit at t ~ 0, material.c:58-65, turns one
+    ulp into another path for 42 % of the pixels). Ray and node-test counts within 0.2 % / 2 %."""
+    m = manifest[name]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    scene = resize_camera(pkg.api.Scene(built_blob(m["built_blob"])), w, h)
+    ctx.upload(scene)
+    fb = ctx.framebuffer(w, h)
+    ctx.reset_counters()
+    ctx.render_region(fb, w, h, s, b)
+    img, cnt = ctx.download(fb, w, h), ctx.counters()
+    st = image_stats(img, golden_ref(name))
+    floor = m["floor"]
+    assert st["rmse"] <= max(5e-3, floor["rmse"]) and st["frac_gt_1e-3"] <= max(5e-3, floor["frac_gt_1e-3"]), (name, st, floor)
+    if floor["frac_gt_1e-3"] > 5e-3:       # chaotic scene: the GPU must sit well inside the reference's own spread, not merely at it
+        assert st["frac_gt_1e-3"] <= 0.5 * floor["frac_gt_1e-3"] and st["rmse"] <= floor["rmse"], (name, st, floor)
+    assert cnt["paths"] == w * h * s
+    assert abs(cnt["rays"] - m["rays"]) <= 0.002 * m["rays"], (cnt["rays"], m["rays"])
+    assert abs(cnt["node_tests"] - m["node_tests"]) <= 0.02 * m["node_tests"]
+    assert np.isfinite(img).all()
+
+
+def test_sampler_key_wraps_at_4k_2048spp(pkg, ctx, oracle):
+    """configs[3] is 3840x2160 at 2048 spp: pixelIndex * maxPasses + pass exceeds 2^32 for every row above y = 546 and the
+    reference's 32-bit key wraps (sampler.c:42). Two passes of a strip up there, seeded with maxPasses = 2048, against the oracle."""
+    blob = built_blob("cfg4_statues")
+    w, h, b = 3840, 2160, 30
+    region = (1800, 1200, 1928, 1216)
+    ctx.upload(pkg.api.Scene(blob))
+    fb = ctx.framebuffer(w, h)
+    ctx.reset_counters()
+    ctx.render_region(fb, w, h, 2048, b, first_pass=0, pass_count=2, region=region)
+    img, cnt = ctx.download(fb, w, h), ctx.counters()
+    oscene = oracle.OracleScene(blob)
+    ref = np.zeros((h, w, 3), np.float32)
+    _, ocnt = oracle.render(oscene, w, h, 2048, b, region=region, first_pass=0, pass_count=2, fb=ref)
+    x0, y0, x1, y1 = region
+    a, r = img[h - y1:h - y0, x0:x1], ref[h - y1:h - y0, x0:x1]
+    assert (region[1] * w + region[0]) * 2048 > 2 ** 32
+    assert np.median(np.abs(a - r).max(axis=2)) == 0.0            # the typical pixel is identical: the seeds are the reference's
+    assert abs(cnt["rays"] - ocnt["rays"]) <= 0.01 * ocnt["rays"]
+    mask = np.ones((h, w), bool); mask[h - y1:h - y0, x0:x1] = False
+    assert not img[mask].any()
 
 
 def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_blob):

@@ -4,6 +4,8 @@ ray / node-test / triangle-test counters must equal the instrumented reference's
 import numpy as np
 import pytest
 
+from conftest import BIG_CASES, built_blob, resize_camera
+
 CASES = ["cfg1_scene", "alphanode", "fence", "glowmetal", "refraction", "uvsphere"]
 
 
@@ -59,3 +61,15 @@ def test_srgb8_truncates(oracle):
     fb = np.array([[[0.0, 0.0031308, 1.0], [0.5, 2.0, 0.2]]], np.float32)
     out = oracle.to_srgb8(fb)
     assert out.tolist() == [[[0, 10, 254], [187, 255, 123]]]   # 1.055 * 1 - 0.055 = 0.99999994 -> 254: truncation, texture.c:18-22
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_oracle_bit_exact_on_baseline_configs_reduced_frame(name, oracle, manifest, golden_ref):
+    """BASELINE.json configs[1..4] (HDR environment + DOF, deep BLAS at 32 bounces, instanced TLAS, triangle soup) at 320x180:
+    the restatement equals c-ray-ref-strict bit for bit, counters equal c-ray-ref-count."""
+    m = manifest[name]
+    scene = resize_camera(oracle.OracleScene(built_blob(m["built_blob"])), m["width"], m["height"])
+    img, cnt = oracle.render(scene, m["width"], m["height"], m["samples"], m["bounces"])
+    ref = golden_ref(name)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{name}: {(img != ref).sum()} floats differ"
+    assert cnt["rays"] == m["rays"] and cnt["node_tests"] == m["node_tests"] and cnt["tri_tests"] == m["tri_tests"]

@@ -31,6 +31,24 @@ CASES = {
 }
 
 
+# BASELINE.json configs[1..4] at a reduced 16:9 frame (the sensor depends only on FOV and aspect ratio, camera.c:30-32, so the
+# committed fixture is only the reference's float buffer: the scene comes from scenes/_built/<blob>.blob with camera.width /
+# height patched). Next to the strict buffer, the "chaos floor": how far the SAME reference sources built with the upstream
+# default flags (FMA contraction on: c-ray-ref) land from the strict build — what any other correct fp32 implementation is allowed.
+BIG_CASES = {
+    "cfg2_hdr_small": ("hdr.json", "cfg2_hdr", 320, 180, 4, 8),
+    "cfg3_venus_small": ("venus.json", "cfg3_venus", 320, 180, 4, 32),
+    "cfg4_statues_small": ("statues.json", "cfg4_statues", 320, 180, 4, 30),
+    "soup_1m_small": ("soup_1000000.json", "soup_1m", 320, 180, 4, 8),
+}
+
+
+def per_pixel_stats(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    l2 = np.sqrt((d ** 2).sum(axis=2))
+    return {"rmse": float(np.sqrt((d ** 2).mean())), "frac_gt_1e-3": float((l2 > 1e-3).mean()), "mean_l2": float(l2.mean())}
+
+
 def gz_write(path, data):
     with gzip.GzipFile(path, "wb", compresslevel=9, mtime=0) as f:
         f.write(data)
@@ -71,6 +89,18 @@ def main():
                                              "bounces": bounces, "ref_flavour": "c-ray-ref-strict --iterative -j 1",
                                              "ref_md5": hashlib.md5(ibuf.tobytes()).hexdigest(), "mean": float(ibuf.mean())}
             print(name + "_iterative", manifest[name + "_iterative"])
+    for name, (scene, blob, w, h, spp, bounces) in BIG_CASES.items():
+        if only and name not in only:
+            continue
+        buf, _ = refrun.render_reference(scene, w, h, spp, bounces, "strict")
+        fma, _ = refrun.render_reference(scene, w, h, spp, bounces, "default")
+        _, cst = refrun.render_reference(scene, w, h, spp, bounces, "count")
+        gz_write(os.path.join(GOLDEN, name + ".ref.f32.gz"), buf.tobytes())
+        manifest[name] = {"scene": scene, "built_blob": blob, "width": w, "height": h, "samples": spp, "bounces": bounces,
+                          "ref_flavour": "c-ray-ref-strict", "ref_md5": hashlib.md5(buf.tobytes()).hexdigest(),
+                          "rays": cst["rays"], "node_tests": cst["node_tests"], "tri_tests": cst["tri_tests"], "mean": float(buf.mean()),
+                          "floor": dict(per_pixel_stats(fma, buf), flavour="c-ray-ref (same sources, FMA contraction on) vs c-ray-ref-strict")}
+        print(name, manifest[name])
     with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

@@ -5,6 +5,8 @@
  * src/main.c:14-42) and adds what the reference cannot do on its own:
  *   CRH_DUMP_F32=<path>    after the render, write state.renderBuffer (linear float RGB, the
  *                          reference's y-flipped layout, src/datatypes/image/texture.c:24-28) as raw f32
+ *   CRH_NODE_PATCH=<name>  after the scene is loaded, rebuild some materials / instances from the reference's own C node
+ *                          constructors (oracle/ref_node_patch.c): the nodes no JSON path reaches
  *   CRH_DUMP_STATS=<path>  write one JSON line: render wall ms, threads, W, H, spp, bounces, and —
  *                          in the -count flavour — rays / node tests / triangle tests
  * Every other translation unit of these binaries is the UNMODIFIED reference source compiled where
@@ -21,6 +23,7 @@
 #include "utils/timer.h"
 
 extern struct renderer *g_renderer;
+void crh_apply_node_patch(struct renderer *r);      /* oracle/ref_node_patch.c */
 
 /* Defined by the -count flavour's wrapper TUs (ref_count_*.c); absent (NULL) otherwise. */
 extern uint64_t crh_count_rays __attribute__((weak));
@@ -63,6 +66,7 @@ int main(int argc, char *argv[]) {
 	}
 	if (crLoadSceneFromBuf(input) != 0) return -1;
 	free(input);
+	crh_apply_node_patch(g_renderer);
 
 	crStartRenderer();
 	long renderMs = (long)getMs(*g_renderer->state.timer);

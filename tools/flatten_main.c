@@ -16,6 +16,7 @@
 #include "flatten.h"
 
 extern struct renderer *g_renderer;
+void crh_apply_node_patch(struct renderer *r);      /* oracle/ref_node_patch.c: CRH_NODE_PATCH=<name> (fixtures for API-only nodes) */
 
 int main(int argc, char *argv[]) {
 	const char *outPath = getenv("CRH_DUMP_SCENE");
@@ -37,6 +38,7 @@ int main(int argc, char *argv[]) {
 		return 1;
 	}
 	free(input);
+	crh_apply_node_patch(g_renderer);
 
 	crh_scene_desc desc;
 	int rc = crh_flatten_world(g_renderer, &desc);

@@ -43,6 +43,66 @@ BIG_CASES = {
 }
 
 
+# Fixtures for the nodes no JSON path reaches: the scene is written here,
+# the exotic graphs are built INSIDE the reference by oracle/ref_node_patch.c (CRH_NODE_PATCH). name: (scene, patch, W, H, spp, bounces)
+PATCHED_CASES = {
+    "nodezoo": ("nodezoo.json", {"CRH_NODE_PATCH": "zoo", "CRH_ZOO_TAME": "1"}, 320, 192, 4, 6),   # exotic + JSON graphs, full paths
+    "nodezoo_display": ("nodezoo.json", {"CRH_NODE_PATCH": "zoo"}, 320, 192, 1, 2),    # known answers: first hit x white background
+}
+ZOO_COLS, ZOO_ROWS, ZOO_PITCH, ZOO_RADIUS = 10, 6, 0.1, 0.042
+
+
+def zoo_sphere_center(i):
+    """World position of nodezoo sphere i (row-major from the top left as the camera sees it)."""
+    col, row = i % ZOO_COLS, i // ZOO_COLS
+    return ((col - (ZOO_COLS - 1) / 2) * ZOO_PITCH, ((ZOO_ROWS - 1) / 2 - row) * ZOO_PITCH, 0.0)
+
+
+def write_nodezoo_scene():
+    """60 spheres in a 10 x 6 grid facing the camera + an untextured cube and a textured plane. Spheres 0..49 are re-materialised
+    by ref_node_patch.c; 50..59 and the meshes carry the node graphs the JSON loader itself can build (sceneloader.c:766-870)."""
+    grid = "shapes/grid.png"
+    json_materials = [
+        {"type": "add", "A": {"type": "diffuse", "color": [0.5, 0.1, 0.1]}, "B": {"type": "metal", "color": [0.1, 0.1, 0.5], "roughness": 0.1}},
+        {"type": "diffuse", "color": {"type": "checkerboard", "size": 30}},
+        {"type": "diffuse", "color": {"type": "blackbody", "degrees": 3500}},
+        {"type": "metal", "color": [0.9, 0.9, 0.9], "roughness": {"path": grid, "lerp": False, "transform": False}},
+        {"type": "diffuse", "color": {"path": grid, "lerp": True, "transform": True}},
+        {"type": "diffuse", "color": {"path": grid}},
+        {"type": "glass", "color": [1.0, 1.0, 1.0], "roughness": 0.05, "IOR": 1.5},
+        {"type": "plastic", "color": [0.2, 0.3, 0.8]},
+        {"type": "mix", "A": {"type": "diffuse", "color": [0.8, 0.2, 0.2]}, "B": {"type": "transparent", "color": [1.0, 1.0, 1.0]},
+         "factor": {"path": grid, "lerp": True}},
+        {"type": "emissive", "color": [1.0, 0.8, 0.6], "strength": 3.0},
+    ]
+    prims = []
+    for i in range(ZOO_COLS * ZOO_ROWS):
+        x, y, z = zoo_sphere_center(i)
+        p = {"type": "sphere", "bsdf": "lambertian", "color": {"r": 0.8, "g": 0.8, "b": 0.8}, "radius": ZOO_RADIUS, "IOR": 1.45,
+             "instances": [{"transforms": [{"type": "rotateY", "degrees": 20 + 3 * i}, {"type": "translate", "x": x, "y": y, "z": z}]}]}
+        if i >= 50:
+            p["material"] = json_materials[i - 50]
+        prims.append(p)
+    meshes = [
+        {"fileName": "shapes/cube.obj", "bsdf": "lambertian",       # no texture coordinates: checker.c takes the hit-point branch
+         "material": {"type": "diffuse", "color": {"type": "checkerboard", "size": 40}},
+         "instances": [{"transforms": [{"type": "scaleUniform", "scale": 0.04}, {"type": "rotateY", "degrees": 30},
+                                       {"type": "translate", "x": -0.62, "y": 0.0, "z": 0.0}]}]},
+        {"fileName": "shapes/gridplane.obj", "bsdf": "lambertian",  # textured, far behind the grid
+         "instances": [{"transforms": [{"type": "scaleUniform", "scale": 0.3}, {"type": "rotateX", "degrees": -90},
+                                       {"type": "translate", "x": 0.62, "y": 0.0, "z": 0.3}]}]},
+    ]
+    scene = {"version": 1.0,
+             "renderer": {"threads": 0, "samples": 4, "bounces": 6, "antialiasing": True, "tileWidth": 32, "tileHeight": 32, "tileOrder": "fromMiddle",
+                          "outputFilePath": "/tmp/", "outputFileName": "nodezoo", "fileType": "bmp", "count": 0, "width": 320, "height": 192},
+             "display": {"isFullscreen": False, "isBorderless": False, "windowScale": 1.0},
+             "camera": {"FOV": 28.0, "focalDistance": 3.0, "fstops": 0, "transforms": [{"type": "translate", "x": 0, "y": 0, "z": -3.0}]},
+             "scene": {"ambientColor": {"offset": 0, "down": {"r": 1.0, "g": 1.0, "b": 1.0}, "up": {"r": 0.5, "g": 0.7, "b": 1.0}},
+                       "primitives": prims, "meshes": meshes}}
+    with open(os.path.join(refrun.INPUT_DIR, "nodezoo.json"), "w") as f:
+        json.dump(scene, f, indent=1)
+
+
 def per_pixel_stats(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     l2 = np.sqrt((d ** 2).sum(axis=2))
@@ -89,6 +149,29 @@ def main():
                                              "bounces": bounces, "ref_flavour": "c-ray-ref-strict --iterative -j 1",
                                              "ref_md5": hashlib.md5(ibuf.tobytes()).hexdigest(), "mean": float(ibuf.mean())}
             print(name + "_iterative", manifest[name + "_iterative"])
+    blobs_done = {}
+    for name, (scene, env, w, h, spp, bounces) in PATCHED_CASES.items():
+        if only and name not in only:
+            continue
+        if scene == "nodezoo.json":
+            write_nodezoo_scene()
+        entry = {"scene": scene, "patch": env, "width": w, "height": h, "samples": spp, "bounces": bounces,
+                 "ref_flavour": "c-ray-ref-strict + oracle/ref_node_patch.c"}
+        if (scene, str(env)) not in blobs_done:
+            tmp_blob = os.path.join("/tmp", f"golden_{name}.blob")
+            refrun.flatten_scene(scene, tmp_blob, w, h, spp, bounces, env=env)
+            blob = open(tmp_blob, "rb").read()
+            gz_write(os.path.join(GOLDEN, name + ".blob.gz"), blob)
+            blobs_done[(scene, str(env))] = name
+            entry["blob_md5"] = hashlib.md5(blob).hexdigest()
+        entry["blob"] = blobs_done[(scene, str(env))]
+        buf, st = refrun.render_reference(scene, w, h, spp, bounces, "strict", env=env)
+        _, cst = refrun.render_reference(scene, w, h, spp, bounces, "count", env=env)
+        gz_write(os.path.join(GOLDEN, name + ".ref.f32.gz"), buf.tobytes())
+        entry.update({"ref_md5": hashlib.md5(buf.tobytes()).hexdigest(), "rays": cst["rays"], "node_tests": cst["node_tests"],
+                      "tri_tests": cst["tri_tests"], "mean": float(buf.mean())})
+        manifest[name] = entry
+        print(name, entry)
     for name, (scene, blob, w, h, spp, bounces) in BIG_CASES.items():
         if only and name not in only:
             continue

@@ -58,7 +58,7 @@ def _run(binary, scene_json, threads, env_extra, timeout, extra_args=()):
 
 
 def render_reference(scene_name, width, height, samples, bounces, flavour="strict", threads=None, timeout=3600,
-                     tile=None, iterative=False):
+                     tile=None, iterative=False, env=None):
     """Run the real reference; returns (float32 array [H, W, 3] in the reference's stored row order, stats dict).
     iterative=True: `--iterative` (renderThreadInteractive, Halton sampler) on ONE thread — with more threads the
     reference races on state.finishedPasses and its output changes from run to run."""
@@ -68,7 +68,7 @@ def render_reference(scene_name, width, height, samples, bounces, flavour="stric
         f32 = os.path.join(tmp, "buffer.f32")
         stats = os.path.join(tmp, "stats.json")
         log = _run(binary, scene, 1 if iterative else (threads or os.cpu_count()),
-                   {"CRH_DUMP_F32": f32, "CRH_DUMP_STATS": stats, "CRH_NO_IMAGE": "1"}, timeout,
+                   dict(env or {}, CRH_DUMP_F32=f32, CRH_DUMP_STATS=stats, CRH_NO_IMAGE="1"), timeout,
                    extra_args=("--iterative",) if iterative else ())
         buf = np.fromfile(f32, dtype=np.float32).reshape(height, width, 3)
         with open(stats) as f:
@@ -77,11 +77,11 @@ def render_reference(scene_name, width, height, samples, bounces, flavour="stric
     return buf, st
 
 
-def flatten_scene(scene_name, out_blob, width, height, samples, bounces, tile=None, timeout=3600):
+def flatten_scene(scene_name, out_blob, width, height, samples, bounces, tile=None, timeout=3600, env=None):
     """Run crh-flatten (reference loader + product flattener) to write a scene blob."""
     scene = rewrite_scene(scene_name, width, height, samples, bounces, tile=tile)
     os.makedirs(os.path.dirname(os.path.abspath(out_blob)), exist_ok=True)
-    return _run("crh-flatten", scene, None, {"CRH_DUMP_SCENE": os.path.abspath(out_blob)}, timeout)
+    return _run("crh-flatten", scene, None, dict(env or {}, CRH_DUMP_SCENE=os.path.abspath(out_blob)), timeout)
 
 
 if __name__ == "__main__":

@@ -546,8 +546,12 @@ struct UpperNode {
 };
 template <class T> struct DevBuf {
 	T *p = nullptr;
-	~DevBuf() { if (p) (void)hipFree(p); }
-	hipError_t alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;                 /* owning: a copy-assignment would drop the live allocation without freeing it */
+	DevBuf &operator=(const DevBuf &) = delete;
+	~DevBuf() { release(); }
+	void release() { if (p) (void)hipFree(p); p = nullptr; }
+	hipError_t alloc(size_t n) { release(); return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
 };
 #define BVH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return crh_internal_fail(CRH_ERR_HIP, (std::string("crh_bvh_build_triangles: ") + #expr + ": " + hipGetErrorString(e_)).c_str()); } while (0)
 }  // namespace
@@ -635,13 +639,11 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 		const uint32_t nChunks = (uint32_t)hChunks.size();
 		if (nNodes > capNodes) {
 			capNodes = (size_t)nNodes * 2;
-			dLevel = DevBuf<LargeNode>(); dBins = DevBuf<BinKeys>(); dCounts = DevBuf<uint32_t>(); dDec = DevBuf<Decision>(); dNodeChunk0 = DevBuf<uint32_t>(); dNodeSwaps = DevBuf<uint32_t>();
 			BVH_TRY(dLevel.alloc(capNodes)); BVH_TRY(dBins.alloc(capNodes * 3 * CRH_BVH_BINS)); BVH_TRY(dCounts.alloc(capNodes * 3 * CRH_BVH_BINS));
 			BVH_TRY(dDec.alloc(capNodes)); BVH_TRY(dNodeChunk0.alloc(capNodes + 1)); BVH_TRY(dNodeSwaps.alloc(capNodes));
 		}
 		if (nChunks > capChunks) {
 			capChunks = (size_t)nChunks * 2;
-			dChunks = DevBuf<Chunk>(); dChunkML = DevBuf<uint32_t>(); dChunkMR = DevBuf<uint32_t>();
 			BVH_TRY(dChunks.alloc(capChunks)); BVH_TRY(dChunkML.alloc(capChunks)); BVH_TRY(dChunkMR.alloc(capChunks));
 		}
 		BVH_TRY(hipMemcpyAsync(dLevel.p, hNodes.data(), nNodes * sizeof(LargeNode), hipMemcpyHostToDevice, st));

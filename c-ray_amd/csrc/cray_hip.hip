@@ -479,10 +479,11 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 }
 
 /* bounces <= 0: pathTrace() returns black (pathtrace.c:36); only the running mean moves (renderer.c:288-291) */
-__global__ void k_fold_black(const crh_render_params P, const crh_tile *tiles, uint32_t ntiles, float *fb) {
+__global__ void k_fold_black(const crh_render_params P, const crh_tile *tiles, uint32_t ntiles, float *fb, unsigned long long *counters) {
 	for (uint32_t t = blockIdx.y; t < ntiles; t += gridDim.y) {
 		const crh_tile r = tiles[t];
 		const int w = r.x1 - r.x0, n = w * (r.y1 - r.y0);
+		if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n * (unsigned long long)P.pass_count);   /* paths are still counted (renderer.c:283) */
 		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 			const int x = r.x0 + i % w, y = r.y0 + i / w;
 			float *out = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;
@@ -888,7 +889,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
 
 	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */
-		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(work_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, work_count, dev_fb);
+		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(work_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, work_count, dev_fb, c->dCounters);
 		hipError_t e0 = hipGetLastError();
 		if (e0 != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_fold_black launch: ") + hipGetErrorString(e0));
 		return CRH_OK;

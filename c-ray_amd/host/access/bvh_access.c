@@ -34,13 +34,28 @@ struct bvh *buildBottomLevelBvh(struct poly *polys, unsigned count) {
 	if (count < 1) return bvh;                                  /* bvh.c:250-256 */
 	bvh->nodes = malloc(sizeof(struct bvhNode) * (2 * (size_t)count - 1));
 	bvh->primIndices = malloc(sizeof(int) * count);
+	/* Upload only the vertex range this mesh references (the loader gives every mesh a contiguous range of g_vertices,
+	 * wavefront.c:110-126), not the whole global buffer once per mesh: polygons are handed over with indices rebased to it. */
+	int vmin = polys[0].vertexIndex[0], vmax = vmin;
+	for (unsigned i = 0; i < count; ++i)
+		for (int k = 0; k < 3; ++k) {
+			const int v = polys[i].vertexIndex[k];
+			if (v < vmin) vmin = v;
+			if (v > vmax) vmax = v;
+		}
+	if (vmin < 0 || vmax >= vertexCount) logr(error, "c-ray-hip: mesh references vertex %i outside g_vertices[0..%i)\n", vmin < 0 ? vmin : vmax, vertexCount);
+	crh_poly *local = malloc(sizeof(*local) * count);
+	memcpy(local, polys, sizeof(*local) * count);
+	for (unsigned i = 0; i < count; ++i)
+		for (int k = 0; k < 3; ++k) local[i].v[k] -= vmin;
 	pthread_mutex_lock(&g_bvh_lock);
 	int rc = CRH_OK;
 	if (!g_bvh_ctx) rc = crh_context_create(0, NULL, &g_bvh_ctx);
 	if (rc == CRH_OK)
-		rc = crh_bvh_build_triangles(g_bvh_ctx, (const crh_poly *)polys, count, (const float *)g_vertices, (uint64_t)vertexCount,
+		rc = crh_bvh_build_triangles(g_bvh_ctx, local, count, (const float *)(g_vertices + vmin), (uint64_t)(vmax - vmin + 1),
 		                             (crh_bvh_node *)bvh->nodes, bvh->primIndices, &bvh->nodeCount, NULL);
 	pthread_mutex_unlock(&g_bvh_lock);
+	free(local);
 	if (rc != CRH_OK) logr(error, "c-ray-hip: GPU BVH build failed (%i): %s\n", rc, crh_last_error());   /* exits: no CPU path here */
 	bvh->nodes = realloc(bvh->nodes, sizeof(struct bvhNode) * bvh->nodeCount);   /* bvh.c:283 */
 	return bvh;

@@ -58,6 +58,7 @@ struct gpuWorker {
 	float *fb;
 	int device;
 	int failed;
+	char error[256];      /* crh_last_error() is per thread: the failing dispatch thread keeps its message here */
 	uint64_t rays;
 };
 
@@ -81,7 +82,8 @@ static void *gpuThread(void *arg) {
 
 	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_scene_upload(w->ctx, w->scene) != CRH_OK ||
 		crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK) {
-		logr(warning, "GPU %d: %s\n", w->device, crh_last_error());
+		snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
+		logr(warning, "GPU %d: %s\n", w->device, w->error);
 		w->failed = 1;
 		w->state->threadComplete = true;
 		return NULL;
@@ -101,7 +103,8 @@ static void *gpuThread(void *arg) {
 		w->state->currentTileNum = tileNums[0];
 		w->state->completedSamples = 1;
 		if (crh_render_tiles(w->ctx, &p, batch, (uint32_t)n, w->fb) != CRH_OK || crh_synchronize(w->ctx) != CRH_OK) {
-			logr(warning, "GPU %d: %s\n", w->device, crh_last_error());
+			snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
+			logr(warning, "GPU %d: %s\n", w->device, w->error);
 			w->failed = 1;
 			break;
 		}
@@ -266,8 +269,9 @@ struct texture *renderFrame(struct renderer *r) {
 
 	int failed = 0;
 	uint64_t rays = 0;
-	for (int g = 0; g < gpus; ++g) { failed += workers[g].failed; rays += workers[g].rays; }
-	if (failed) logr(error, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), crh_last_error());
+	const char *firstError = "";
+	for (int g = gpus - 1; g >= 0; --g) { failed += workers[g].failed; rays += workers[g].rays; if (workers[g].failed) firstError = workers[g].error; }
+	if (failed) logr(error, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), firstError);
 
 	/* assemble the frame on GPU 0 (RCCL reduce over xGMI; tiles are disjoint so the sum is a gather) */
 	if (gpus > 1) {

@@ -111,7 +111,7 @@ int crh_blob_load(const char *path, crh_scene_desc **scene_out, crh_blob_prefs *
 	if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return CRH_ERR_IO; }
 	long size = ftell(f);
 	rewind(f);
-	if (size < (long)(sizeof(struct blob_header) + SEC_COUNT * sizeof(struct blob_section))) { fclose(f); return CRH_ERR_IO; }
+	if (size < 0 || size < (long)(sizeof(struct blob_header) + SEC_COUNT * sizeof(struct blob_section))) { fclose(f); return CRH_ERR_IO; }
 	char *buf = malloc((size_t)size);
 	if (!buf) { fclose(f); return CRH_ERR_NOMEM; }
 	if (fread(buf, 1, (size_t)size, f) != (size_t)size) { fclose(f); free(buf); return CRH_ERR_IO; }
@@ -128,8 +128,10 @@ int crh_blob_load(const char *path, crh_scene_desc **scene_out, crh_blob_prefs *
 		sizeof(crh_sphere), sizeof(crh_material), sizeof(crh_gnode), sizeof(crh_texture), 1
 	};
 	for (int i = 0; i < SEC_COUNT; ++i) {
-		if (sec[i].id != (uint32_t)i || sec[i].elem_size != elem[i] ||
-			sec[i].offset + sec[i].count * sec[i].elem_size > (uint64_t)size) {
+		/* no wrap-around: offset inside the file and past the tables, 16-byte aligned (typed reads), count bounded by what is left */
+		const uint64_t tables = sizeof(struct blob_header) + SEC_COUNT * sizeof(struct blob_section);
+		if (sec[i].id != (uint32_t)i || sec[i].elem_size != elem[i] || sec[i].offset > (uint64_t)size || sec[i].offset < tables ||
+			(sec[i].offset & 15u) || sec[i].count > ((uint64_t)size - sec[i].offset) / elem[i]) {
 			free(buf);
 			return CRH_ERR_INVALID;
 		}

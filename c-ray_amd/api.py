@@ -159,6 +159,10 @@ class Context:
         self.set_option(abi.OPT_SCHED_WEIGHTS, node | (tri << 12) | (ctrl << 24) | (swap_min << 36))
         self.set_option(abi.OPT_SCHED_RUNS, fill_to | (run_num << 12) | (tri_in_run << 16) | (ctrl_in_run << 24))
 
+    def set_sched_wg(self, linger=8, drain_at=192, max_drainers=1, partial_min=16, walk_min=32, fill_to=768):
+        """Scheduler of the workgroup kernel (CRH_OPT_KERNEL = KERNEL_WG), see cray_hip.hip: k_pathtrace_wg."""
+        self.set_option(abi.OPT_SCHED_WG, linger | (drain_at << 8) | (max_drainers << 20) | (partial_min << 24) | (walk_min << 32) | (fill_to << 40))
+
     def upload(self, scene):
         desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)
         _check(self.L.crh_scene_upload(self.h, desc), "crh_scene_upload")

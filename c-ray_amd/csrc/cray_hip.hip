@@ -449,6 +449,373 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	}
 }
 
+/* ================================================================================================================================
+ * k_pathtrace_wg — the WORKGROUP-cooperative form of the machine above (CRH_OPT_KERNEL = CRH_KERNEL_WG).
+ *
+ * Why: in k_pathtrace one wave alternates between walking and shading, so the ~30 VGPRs of walk state stay live across the
+ * shading code (which alone wants ~140): at the 128-register budget of 4 waves / SIMD that is ~90 spilled VGPRs and ~120 B of
+ * scratch traffic per ray. Here the four waves of a workgroup share ONE path table (1024 records) and ONE set of id stacks, and
+ * a wave only ever shades / generates / evaluates misses when it holds NO walk: walk state and shading state are never live
+ * at the same program point, so neither is spilled. Roles are dynamic:
+ *   - a wave without live walks (top of the loop) takes the job with the most pending work: SHADE (>= 64 hits queued), MISS,
+ *     GEN (table below its fill level), or WALK (pop up to 64 ray ids and walk them);
+ *   - a walking wave retires finished walks and refills idle lanes from the shared ray stack for as long as rays are there; it
+ *     returns to the top only when it has drained — because the ray stack is empty, or because it took the workgroup's DRAIN
+ *     token (backlog of hits + misses >= drainAt and fewer than maxDrainers waves already draining): that is how walkers
+ *     become servers when shading falls behind;
+ *   - a wave that just served lingers (sleeps, up to `linger` polls) for the next full batch before it walks again: that is how
+ *     a server stays a server while the workload keeps it busy, without oscillating.
+ * Stacks are LIFO, mutated only under the workgroup's LDS spin lock (critical sections touch LDS only; path records are
+ * written before the lock is taken and published by the release fence). Every path's own sequence of operations is the same
+ * as in k_pathtrace, hence the same frame bit for bit. A watchdog (wall clock) aborts the dispatch instead of hanging.
+ * ================================================================================================================================ */
+#define CRH_WG_PATHS 1024u
+#define CRH_WG_STACK_LDS 22          /* (22 + 13 park) x 1 KB + 2 x 2 KB id arrays + control words <= 40 KB: 4 workgroups per CU */
+struct SchedWg { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, linger, drainAt, maxDrainers, partialMin, walkMin; };
+
+/* traversal stack of the workgroup kernel: LDS first, deeper entries in a per-lane column of a global array (never scratch) */
+struct WgStack {
+	lds_u32 *lds, *parkp;
+	uint32_t *ovf;       /* wave-uniform: &ovfAll[wave * OVF * 64]; entry i of lane l at ovf[i * 64 + l] */
+	uint32_t lane;
+	__device__ __forceinline__ void park(int i, uint32_t v) { parkp[i * CRH_BLOCK] = v; }
+	__device__ __forceinline__ uint32_t unpark(int i) { return parkp[i * CRH_BLOCK]; }
+	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
+		if (__builtin_expect(i < CRH_WG_STACK_LDS, 1)) lds[i * CRH_BLOCK] = v;
+		else ovf[(i - CRH_WG_STACK_LDS) * 64u + lane] = v;
+	}
+	__device__ __forceinline__ uint32_t pop(uint32_t i) {
+		if (__builtin_expect(i < CRH_WG_STACK_LDS, 1)) return lds[i * CRH_BLOCK];
+		return ovf[(i - CRH_WG_STACK_LDS) * 64u + lane];
+	}
+};
+#define CRH_WG_OVF (134 - CRH_WG_STACK_LDS)
+
+enum { CT_LOCK, CT_RAYS, CT_HITS, CT_MISSES, CT_FREE, CT_NEXT, CT_DRAINERS, CT_ABORT, CT_UNIT, CT_WORDS };
+typedef volatile __attribute__((address_space(3))) int wg_int;
+typedef volatile __attribute__((address_space(3))) uint16_t wg_u16;
+
+/* spin lock of the workgroup's queues; false = the dispatch is being aborted (watchdog) */
+__device__ __forceinline__ bool wgLock(int *lockWord, wg_int *ctl, uint32_t lane, unsigned int *errFlag) {
+	if (lane == 0) {
+		uint32_t spins = 0;
+		while (atomicCAS(lockWord, 0, 1) != 0) {
+			__builtin_amdgcn_s_sleep(2);
+			if (++spins > (1u << 24) || ctl[CT_ABORT]) { ctl[CT_ABORT] = 1; atomicOr(errFlag, 1u); break; }
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	return ctl[CT_ABORT] == 0;
+}
+__device__ __forceinline__ void wgUnlock(int *lockWord, uint32_t lane) {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          /* this wave's id / counter writes are in LDS before the lock opens */
+	if (lane == 0) __hip_atomic_store(lockWord, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int LEVEL, bool PROG, int SAMP>
+__global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
+																unsigned long long *counters, float *stage, int chunk, const SchedWg K, float *queues,
+																uint32_t *ovfAll, unsigned int *errFlag) {
+	__shared__ uint32_t s_stack[CRH_WG_STACK_LDS * CRH_BLOCK];
+	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
+	__shared__ uint16_t s_idsA[CRH_WG_PATHS];      /* rays grow up from 0, hits grow down from the end */
+	__shared__ uint16_t s_idsB[CRH_WG_PATHS];      /* misses grow up from 0, free slots grow down from the end */
+	__shared__ int s_ctl[CT_WORDS];
+	static_assert((CRH_WG_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + 2 * CRH_WG_PATHS * 2 + CT_WORDS * 4 <= 40960, "4 workgroups per CU share 160 KB of LDS");
+	const DScene S = globalize(Sarg);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
+	WgStack stk;
+	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
+	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
+	stk.ovf = (uint32_t *)(__attribute__((address_space(1))) uint32_t *)(ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_WG_OVF * 64u);
+	stk.lane = lane;
+	CountersT<LEVEL, PROG> cnt;
+	memset(&cnt, 0, sizeof(cnt));
+	float *const myStage = stage + (size_t)blockIdx.x * ((size_t)Q.bw * Q.bh * chunk * 3);
+	const int passEnd = P.first_pass + P.pass_count;
+	f4 *const ptab = (f4 *)(queues + (size_t)blockIdx.x * (CRH_WG_PATHS * CRH_PATH_F4 * 4u));
+	wg_int *const ctl = (wg_int *)s_ctl;
+	wg_u16 *const idsA = (wg_u16 *)s_idsA;
+	wg_u16 *const idsB = (wg_u16 *)s_idsB;
+	int *const lockWord = &s_ctl[CT_LOCK];
+	const int NP = (int)CRH_WG_PATHS;
+	if (threadIdx.x == 0) s_ctl[CT_ABORT] = 0;
+	for (;;) {
+		if (threadIdx.x == 0) {
+			s_ctl[CT_UNIT] = (int)atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
+			s_ctl[CT_LOCK] = 0; s_ctl[CT_DRAINERS] = 0;
+		}
+		__syncthreads();
+		const uint32_t unit = (uint32_t)ctl[CT_UNIT];
+		if (unit >= Q.total || ctl[CT_ABORT]) break;
+		uint32_t lo = 0, hi = Q.ntiles;           /* largest t with start[t] <= unit */
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
+		const crh_tile t = asGlobal(Q.tiles)[lo];
+		const uint32_t local = unit - asGlobal(Q.start)[lo];
+		const int ubw = lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstSmall ? Q.sbh : Q.bh;
+		const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + ubw - 1) / (uint32_t)ubw;
+		BlockJob J;
+		J.bw = ubw; J.bh = ubh;
+		J.x0 = t.x0 + (int)(local % nbx) * ubw;
+		J.y0 = t.y0 + (int)(local / nbx) * ubh;
+		J.w = min(ubw, t.x1 - J.x0);
+		J.h = min(ubh, t.y1 - J.y0);
+		for (int c0 = P.first_pass; c0 < passEnd; c0 += chunk) {
+			J.passBegin = c0;
+			J.passCount = min(chunk, passEnd - c0);
+			const uint32_t nItems = (uint32_t)(J.bw * J.bh * J.passCount);       /* incl. the padding of ragged tile edges */
+			if (threadIdx.x == 0) { s_ctl[CT_RAYS] = 0; s_ctl[CT_HITS] = 0; s_ctl[CT_MISSES] = 0; s_ctl[CT_FREE] = NP; s_ctl[CT_NEXT] = 0; }
+			for (uint32_t i = threadIdx.x; i < CRH_WG_PATHS; i += CRH_BLOCK) s_idsB[i] = (uint16_t)i;   /* all slots free */
+			__syncthreads();
+			int idlePolls = K.linger;                     /* a wave that has not served yet does not linger */
+			uint32_t waitStart = 0;
+			bool waiting = false;
+			for (;;) {   /* ---- top of the machine: this wave holds no walk ---- */
+				if (ctl[CT_ABORT]) break;
+				const int nH = ctl[CT_HITS], nM = ctl[CT_MISSES], nR = ctl[CT_RAYS];
+				const uint32_t nextItem = (uint32_t)ctl[CT_NEXT];
+				const int nFree = ctl[CT_FREE];
+				const bool canGen = nextItem < nItems && nFree >= 64;
+				enum { JB_SHADE, JB_MISS, JB_GEN, JB_WALK, JB_WAIT };
+				int job = JB_WAIT;
+				if (nH >= 64) job = JB_SHADE;
+				else if (nM >= 64) job = JB_MISS;
+				else if (canGen && nR < 64 && (NP - nFree) < K.fillTo) job = JB_GEN;
+				else if (nR == 0 && nH >= K.partialMin) job = JB_SHADE;        /* walkers are out of rays: a partial batch now beats a full one later */
+				else if (idlePolls >= K.linger) {          /* not (or no longer) waiting for a full batch: take what is there */
+					if (nR >= K.walkMin) job = JB_WALK;
+					else if (nH >= K.partialMin) job = JB_SHADE;
+					else if (nR > 0) job = JB_WALK;
+					else if (nH > 0) job = JB_SHADE;
+					else if (nM > 0) job = JB_MISS;
+					else if (canGen) job = JB_GEN;
+				}
+				if (job == JB_WAIT) {
+					/* nothing queued at all: finished, or the other waves still hold the remaining paths. The unlocked test is sound
+					 * (GEN lowers CT_FREE before it raises CT_NEXT, and CT_NEXT was read first); the locked one is belt and braces. */
+					if (nFree == NP && nextItem >= nItems) {
+						if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+						const bool finished = ctl[CT_FREE] == NP && (uint32_t)ctl[CT_NEXT] >= nItems;
+						wgUnlock(lockWord, lane);
+						if (finished) break;
+					}
+					++idlePolls;
+					const uint32_t now = CRH_TICK();
+					if (!waiting) { waiting = true; waitStart = now; }
+					else if (now - waitStart > 400000000u) { if (lane == 0) { ctl[CT_ABORT] = 1; atomicOr(errFlag, 2u); } }    /* 4 s without work: watchdog */
+					__builtin_amdgcn_s_sleep(16);
+					continue;
+				}
+				waiting = false;
+				if (job == JB_SHADE) {           /* pathtrace.c:44-57 for up to 64 surface hits */
+					if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+					const int hq = ctl[CT_HITS];
+					const int n = min(hq, 64);
+					uint32_t id = 0;
+					if ((int)lane < n) id = idsA[NP - hq + (int)lane];
+					if (lane == 0) ctl[CT_HITS] = hq - n;
+					wgUnlock(lockWord, lane);
+					if (n == 0) continue;
+					bool cont = false, done = false;
+					if ((int)lane < n) {
+						f4 *q = ptab + id * CRH_PATH_F4;
+						const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+						v3 o{q0.x, q0.y, q0.z}, d{q1.x, q1.y, q1.z};
+						PathRecT<RngT<SAMP>> r;
+						r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
+						r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
+						r.rng.state = (uint64_t)asU32(q2.w) | ((uint64_t)asU32(q3.w) << 32);
+						r.depth = (int)asU32(q0.w);
+						const uint32_t item = asU32(q1.w);
+						TravHit h;
+						h.t = q4.x; h.u = q4.y; h.v = q4.z;
+						h.slot = (int32_t)asU32(q4.w); h.inst = (int32_t)asU32(q[5].x);
+						__builtin_assume(h.inst >= 0);
+						cont = shadeCore(S, P, o, d, h, r, cnt);
+						done = !cont;
+						if (cont) putPathRay(q, o, d, r, item);
+						else { float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb; }
+					}
+					const unsigned long long cm = __ballot(cont), dm = __ballot(done);
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* records and samples are written before their ids are published */
+					if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+					const int rq = ctl[CT_RAYS], fq = ctl[CT_FREE];
+					if (cont) idsA[rq + (int)laneRank(cm)] = (uint16_t)id;
+					if (done) idsB[NP - 1 - fq - (int)laneRank(dm)] = (uint16_t)id;
+					if (lane == 0) { ctl[CT_RAYS] = rq + (int)__popcll(cm); ctl[CT_FREE] = fq + (int)__popcll(dm); }
+					wgUnlock(lockWord, lane);
+					idlePolls = 0;
+					continue;
+				}
+				if (job == JB_MISS) {            /* pathtrace.c:39-42: background for up to 64 rays that left the scene; the sample is complete */
+					if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+					const int mq = ctl[CT_MISSES];
+					const int n = min(mq, 64);
+					uint32_t id = 0;
+					if ((int)lane < n) id = idsB[mq - n + (int)lane];
+					if (lane == 0) ctl[CT_MISSES] = mq - n;
+					wgUnlock(lockWord, lane);
+					if (n == 0) continue;
+					if ((int)lane < n) {
+						const f4 *q = ptab + id * CRH_PATH_F4;
+						const f4 q1 = q[1], q2 = q[2], q3 = q[3];
+						v3 o{0.0f, 0.0f, 0.0f}, d{q1.x, q1.y, q1.z};
+						PathRecT<RngT<SAMP>> r;
+						r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
+						r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
+						r.rng.state = 0; r.depth = 0;
+						const uint32_t item = asU32(q1.w);
+						TravHit h;
+						h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
+						(void)shadeCore(S, P, o, d, h, r, cnt);
+						float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+					const int fq = ctl[CT_FREE];
+					if ((int)lane < n) idsB[NP - 1 - fq - (int)lane] = (uint16_t)id;
+					if (lane == 0) ctl[CT_FREE] = fq + n;
+					wgUnlock(lockWord, lane);
+					idlePolls = 0;
+					continue;
+				}
+				if (job == JB_GEN) {             /* renderer.c:280-284 for the next 64 items */
+					if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+					const uint32_t it0 = (uint32_t)ctl[CT_NEXT];
+					const int fq = ctl[CT_FREE];
+					const bool ok = it0 < nItems && fq >= 64;
+					const uint32_t item = it0 + lane;
+					int x = 0, y = 0, pass = 0;
+					const bool valid = ok && item < nItems && decodeItem(J, item, x, y, pass);
+					const unsigned long long vm = __ballot(valid);
+					const int n = (int)__popcll(vm);
+					uint32_t id = 0;
+					if (valid) id = idsB[NP - fq + (int)laneRank(vm)];
+					if (lane == 0 && ok) { ctl[CT_FREE] = fq - n; ctl[CT_NEXT] = (int)(it0 + 64u); }
+					wgUnlock(lockWord, lane);
+					if (!ok) continue;
+					if (valid) {
+						v3 o, d;
+						PathRecT<RngT<SAMP>> r;
+						beginPath(S, P, x, y, pass, o, d, r, cnt);
+						putPathRay(ptab + id * CRH_PATH_F4, o, d, r, item);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (n > 0) {
+						if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+						const int rq = ctl[CT_RAYS];
+						if (valid) idsA[rq + (int)laneRank(vm)] = (uint16_t)id;
+						if (lane == 0) ctl[CT_RAYS] = rq + n;
+						wgUnlock(lockWord, lane);
+					}
+					continue;
+				}
+				/* ---- JB_WALK: this wave walks rays until it has drained ---- */
+				{
+					Walk w;
+					memset(&w, 0, sizeof(w));
+					w.phase = PH_IDLE;
+					uint32_t myPath = 0;
+					bool draining = false;
+					for (;;) {
+						const uint32_t ph = w.phase;
+						const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
+						const int nF = __popcll(__ballot(ph == PH_SHADE));
+						const int nE = 64 - nN - nT - nC - nF;
+						const int walkers = nN + nT + nC;
+						const int raysQ = ctl[CT_RAYS];
+						if (walkers == 0 || (nF + nE >= K.swapMin && (nF > 0 || (raysQ > 0 && !draining)))) {
+							/* SWAP: finished walks leave their result in the path's record ... */
+							const bool fin = (ph == PH_SHADE);
+							const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
+							const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
+							if (fin) {
+								f4 *q = ptab + myPath * CRH_PATH_F4;
+								q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
+								if (finHit) q[5].x = asF32((uint32_t)w.hit.inst);
+								w.phase = PH_IDLE;
+							}
+							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+							if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+							const int rq = ctl[CT_RAYS], hq = ctl[CT_HITS], mq = ctl[CT_MISSES];
+							/* ... their ids go on the hit / miss stacks ... */
+							if (finHit) idsA[NP - 1 - hq - (int)laneRank(hm)] = (uint16_t)myPath;
+							if (finMiss) idsB[mq + (int)laneRank(mm)] = (uint16_t)myPath;
+							const int hq2 = hq + (int)__popcll(hm), mq2 = mq + (int)__popcll(mm);
+							/* ... the drain token: shading has fallen behind -> this wave stops taking rays and becomes a server once its walks end */
+							int drainers = ctl[CT_DRAINERS];
+							if (!draining && drainers < K.maxDrainers && hq2 + mq2 >= K.drainAt) { draining = true; ++drainers; }
+							else if (draining && hq2 + mq2 < 64) { draining = false; --drainers; }
+							/* ... and idle lanes pop ray ids */
+							const bool idle = (w.phase == PH_IDLE);
+							const unsigned long long em = __ballot(idle);
+							const uint32_t er = laneRank(em);
+							const int take = draining ? 0 : min(rq, (int)__popcll(em));
+							const bool got = idle && (int)er < take;
+							if (got) myPath = idsA[rq - take + (int)er];
+							if (lane == 0) { ctl[CT_HITS] = hq2; ctl[CT_MISSES] = mq2; ctl[CT_RAYS] = rq - take; ctl[CT_DRAINERS] = drainers; }
+							wgUnlock(lockWord, lane);
+							if (got) {
+								const f4 *q = ptab + myPath * CRH_PATH_F4;
+								const f4 q0 = q[0], q1 = q[1];
+								walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt);
+							}
+							if (__ballot(w.phase != PH_IDLE) == 0ull) break;        /* drained: back to the top */
+							continue;
+						}
+						int pick = 0, best = nN * K.wNode;
+						if (nT * K.wTri > best) { best = nT * K.wTri; pick = 1; }
+						if (nC * K.wCtrl > best) { best = nC * K.wCtrl; pick = 2; }
+						if (pick == 0) {          /* node run, with leaf / instance steps served in place (see k_pathtrace) */
+							int now = nN;
+							do {
+								if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
+								if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) { if (w.phase == PH_TRI) stepTri(S, w, stk, cnt); }
+								if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) { if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt); }
+								now = __popcll(__ballot(w.phase == PH_NODE));
+							} while (now * 8 >= nN * K.runNum);
+						} else if (pick == 1) {
+							int now = nT;
+							do {
+								if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+								now = __popcll(__ballot(w.phase == PH_TRI));
+							} while (now * 8 >= nT * K.runNum);
+						} else {
+							if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt);
+							if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt); }   /* degenerate rays: rare */
+						}
+					}
+					if (draining) {
+						if (!wgLock(lockWord, ctl, lane, errFlag)) break;
+						if (lane == 0) ctl[CT_DRAINERS] = ctl[CT_DRAINERS] - 1;
+						wgUnlock(lockWord, lane);
+					}
+					idlePolls = K.linger;          /* a drained walker takes whatever is there */
+				}
+			}
+			__syncthreads();                       /* every sample of the chunk is staged (the barrier is a workgroup-scope fence) */
+			if (!ctl[CT_ABORT])
+				for (uint32_t pix = threadIdx.x; pix < (uint32_t)(J.bw * J.bh); pix += CRH_BLOCK) foldBlockPixel(P, J, pix, myStage, fb);
+			__syncthreads();                       /* ... and folded before the next chunk overwrites the slab */
+		}
+		if (ctl[CT_ABORT]) break;
+		__syncthreads();                           /* everyone has read CT_UNIT before thread 0 replaces it */
+	}
+	const bool lead = (lane == 0);
+	uint32_t v;
+	v = waveSum(cnt.paths); if (lead && v) atomicAdd(&counters[0], (unsigned long long)v);
+	v = waveSum(cnt.rays); if (lead && v) atomicAdd(&counters[1], (unsigned long long)v);
+	if constexpr (LEVEL >= 2) {
+		v = waveSum(cnt.node_tests); if (lead && v) atomicAdd(&counters[2], (unsigned long long)v);
+		v = waveSum(cnt.tri_tests); if (lead && v) atomicAdd(&counters[3], (unsigned long long)v);
+		v = waveSum(cnt.inst_visits); if (lead && v) atomicAdd(&counters[4], (unsigned long long)v);
+		v = waveSum(cnt.inst_hits); if (lead && v) atomicAdd(&counters[5], (unsigned long long)v);
+		v = waveSum(cnt.sphere_tests); if (lead && v) atomicAdd(&counters[6], (unsigned long long)v);
+		v = waveSum(cnt.tex_fetches); if (lead && v) atomicAdd(&counters[7], (unsigned long long)v);
+	}
+}
+
 __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
@@ -514,6 +881,11 @@ struct crh_ctx {
 	int unitItems = 2048;
 	int unitsPerWave = 8;
 	Sched sched = {70, 160, 120, 16, 192, 4, 12, 12};
+	int kernel = CRH_KERNEL_WAVE;            /* CRH_OPT_KERNEL */
+	SchedWg schedWg = {70, 160, 120, 16, 768, 4, 12, 12, 8, 192, 1, 16, 32};
+	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
+	size_t ovfWords = 0;
+	unsigned int *dErr = nullptr;            /* workgroup kernel: watchdog flag */
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
@@ -567,6 +939,17 @@ static int resolveTimes(crh_ctx *c, bool wait) {
 	return CRH_OK;
 }
 
+/* the workgroup kernel aborts instead of hanging: report it (call with the stream drained) */
+static int checkWatchdog(crh_ctx *c) {
+	unsigned int err = 0;
+	HIP_TRY(hipMemcpy(&err, c->dErr, sizeof(err), hipMemcpyDeviceToHost));
+	if (err) {
+		HIP_TRY(hipMemset(c->dErr, 0, sizeof(err)));
+		return fail(CRH_ERR_HIP, "k_pathtrace_wg: watchdog abort (flag " + std::to_string(err) + "): the frame is incomplete");
+	}
+	return CRH_OK;
+}
+
 template <class T>
 static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
 	void *p = nullptr;
@@ -610,6 +993,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, CRH_NCOUNTERS * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, CRH_NCOUNTERS * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dErr, sizeof(unsigned int));
+	if (e == hipSuccess) e = hipMemset(c->dErr, 0, sizeof(unsigned int));
 	if (e != hipSuccess) {
 		const std::string msg = std::string("crh_context_create: ") + hipGetErrorString(e);
 		crh_context_destroy(c);
@@ -633,6 +1018,8 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dWork) (void)hipFree(c->dWork);
 	if (c->dStage) (void)hipFree(c->dStage);
 	if (c->dQueues) (void)hipFree(c->dQueues);
+	if (c->dOvf) (void)hipFree(c->dOvf);
+	if (c->dErr) (void)hipFree(c->dErr);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return CRH_OK;
@@ -659,6 +1046,7 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			k.wNode = (int)(value & 0xFFF); k.wTri = (int)((value >> 12) & 0xFFF); k.wCtrl = (int)((value >> 24) & 0xFFF); k.swapMin = (int)((value >> 36) & 0xFFF);
 			if (value < 0 || k.wNode < 1 || k.wTri < 1 || k.wCtrl < 1 || k.swapMin < 1 || k.swapMin > 64) return fail(CRH_ERR_INVALID, "bad scheduler parameters");
 			c->sched = k;
+			c->schedWg.wNode = k.wNode; c->schedWg.wTri = k.wTri; c->schedWg.wCtrl = k.wCtrl; c->schedWg.swapMin = k.swapMin;
 			return CRH_OK;
 		}
 		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 | ctrlInRun << 24 */
@@ -666,6 +1054,7 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			k.fillTo = (int)(value & 0xFFF); k.runNum = (int)((value >> 12) & 0xF); k.triInRun = (int)((value >> 16) & 0xFF); k.ctrlInRun = (int)((value >> 24) & 0xFF);
 			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65 || k.ctrlInRun < 1 || k.ctrlInRun > 65) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
 			c->sched = k;
+			c->schedWg.runNum = k.runNum; c->schedWg.triInRun = k.triInRun; c->schedWg.ctrlInRun = k.ctrlInRun;
 			return CRH_OK;
 		}
 		case CRH_OPT_TAIL_PERCENT:
@@ -683,6 +1072,18 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_PASS_CHUNK:
 			if (value < 1 || value > 4096) return fail(CRH_ERR_INVALID, "pass chunk must be 1..4096");
 			c->passChunk = (int)value; return CRH_OK;
+		case CRH_OPT_KERNEL:
+			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_WAVE or CRH_KERNEL_WG");
+			c->kernel = (int)value; return CRH_OK;
+		case CRH_OPT_SCHED_WG: {       /* linger | drainAt << 8 | maxDrainers << 20 | partialMin << 24 | walkMin << 32 | fillTo << 40 */
+			SchedWg k = c->schedWg;
+			k.linger = (int)(value & 0xFF); k.drainAt = (int)((value >> 8) & 0xFFF); k.maxDrainers = (int)((value >> 20) & 0xF);
+			k.partialMin = (int)((value >> 24) & 0xFF); k.walkMin = (int)((value >> 32) & 0xFF); k.fillTo = (int)((value >> 40) & 0xFFF);
+			if (value < 0 || k.drainAt < 1 || k.maxDrainers > 4 || k.partialMin < 1 || k.walkMin < 1 || k.walkMin > 64 || k.fillTo > 960)
+				return fail(CRH_ERR_INVALID, "bad workgroup scheduler parameters");
+			c->schedWg = k;
+			return CRH_OK;
+		}
 		default: return fail(CRH_ERR_INVALID, "unknown option");
 	}
 }
@@ -756,7 +1157,7 @@ int crh_framebuffer_download(crh_ctx *c, const float *dev_fb, int width, int hei
 	if (rc) return rc;
 	HIP_TRY(hipMemcpyAsync(host_rgb, dev_fb, (size_t)width * height * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	return CRH_OK;
+	return checkWatchdog(c);
 }
 
 int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int height, uint8_t *host_rgb8) {
@@ -790,9 +1191,12 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	 * 256 spp, 1x1 beyond. Smaller blocks also keep the 64 lanes of a wave on fewer pixels (coherent walks). */
 	uint64_t pixels = 0;
 	for (uint32_t t = 0; t < tile_count; ++t) pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * std::max(0, tiles[t].y1 - tiles[t].y0);
-	const uint64_t wavesMax = (uint64_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
+	/* the workgroup kernel's unit is worked on by four waves: four times the paths, a quarter of the consumers */
+	const bool wg = c->kernel == CRH_KERNEL_WG;
+	const int unitItems = wg ? c->unitItems * 4 : c->unitItems;
+	const uint64_t wavesMax = (uint64_t)c->cuCount * c->blocksPerCU * (wg ? 1 : CRH_BLOCK / 64);
 	int area = 1;
-	while (area < 256 && (int64_t)area * P->pass_count < c->unitItems) area *= 2;
+	while (area < 256 && (int64_t)area * P->pass_count < unitItems) area *= 2;
 	while (area > 1 && pixels / area < (uint64_t)c->unitsPerWave * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
 	int bw = 1, bh = 1;
 	while (bw * bh < area) { if (bw <= bh) bw *= 2; else bh *= 2; }
@@ -842,14 +1246,14 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	start[work_count] = (uint32_t)total;
 	if (total == 0 || P->pass_count == 0) return CRH_OK;
 
-	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, (total + 3) / 4);
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, wg ? total : (total + 3) / 4);
 	/* passes per chunk: a chunk (block x passes) should also hold about unitItems paths, so that each lane runs >= 16
 	 * paths between two wave-wide folds */
-	const int chunk = std::min(P->pass_count, std::max(c->passChunk, (c->unitItems + area - 1) / area));
+	const int chunk = std::min(P->pass_count, std::max(c->passChunk, (unitItems + area - 1) / area));
 	c->lastGrid = grid;
 	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > 8192) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
 	{
-		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
+		const size_t need = (size_t)grid * (wg ? 1 : CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
 		if (need > c->stageFloats) {
 			HIP_TRY(hipStreamSynchronize(c->stream));
 			if (c->dStage) HIP_TRY(hipFree(c->dStage));
@@ -860,13 +1264,25 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	}
 
 	{
-		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_WAVE_QUEUE_FLOATS;
+		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_WAVE_QUEUE_FLOATS;      /* = grid x CRH_WG_PATHS records for the workgroup kernel */
+		static_assert(CRH_WG_PATHS * CRH_PATH_F4 * 4u == (CRH_BLOCK / 64) * CRH_WAVE_QUEUE_FLOATS, "both kernels use the same path-table footprint per workgroup");
 		if (need > c->queueFloats) {
 			HIP_TRY(hipStreamSynchronize(c->stream));
 			if (c->dQueues) HIP_TRY(hipFree(c->dQueues));
 			c->dQueues = nullptr; c->queueFloats = 0;
 			HIP_TRY(hipMalloc((void **)&c->dQueues, need * sizeof(float)));
 			c->queueFloats = need;
+		}
+	}
+
+	if (wg) {
+		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_WG_OVF * 64u;
+		if (need > c->ovfWords) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (c->dOvf) HIP_TRY(hipFree(c->dOvf));
+			c->dOvf = nullptr; c->ovfWords = 0;
+			HIP_TRY(hipMalloc((void **)&c->dOvf, need * sizeof(uint32_t)));
+			c->ovfWords = need;
 		}
 	}
 
@@ -901,9 +1317,21 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 #define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
+#define CRH_LAUNCH_WG(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_wg<LEVEL, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+													  c->dCounters, c->dStage, chunk, c->schedWg, c->dQueues, c->dOvf, c->dErr)
 #ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/kernel_regs.py): one instantiation compiles in seconds */
-	CRH_LAUNCH(1, 4, false, 0);
+	if (wg) CRH_LAUNCH_WG(1, false, 0); else CRH_LAUNCH(1, 4, false, 0);
 #else
+	if (wg) {
+		const bool halton = c->sampler == CRH_SAMPLER_HALTON;
+		if (c->counterLevel >= 2) {
+			if (c->hasPrograms) { if (halton) CRH_LAUNCH_WG(2, true, 1); else CRH_LAUNCH_WG(2, true, 0); }
+			else { if (halton) CRH_LAUNCH_WG(2, false, 1); else CRH_LAUNCH_WG(2, false, 0); }
+		} else {
+			if (c->hasPrograms) { if (halton) CRH_LAUNCH_WG(1, true, 1); else CRH_LAUNCH_WG(1, true, 0); }
+			else { if (halton) CRH_LAUNCH_WG(1, false, 1); else CRH_LAUNCH_WG(1, false, 0); }
+		}
+	} else
 	if (c->sampler == CRH_SAMPLER_HALTON) {          /* interactive mode: the 128-register variants only */
 		if (c->counterLevel >= 2) { if (c->hasPrograms) CRH_LAUNCH(2, 4, true, 1); else CRH_LAUNCH(2, 4, false, 1); }
 		else { if (c->hasPrograms) CRH_LAUNCH(1, 4, true, 1); else CRH_LAUNCH(1, 4, false, 1); }
@@ -913,6 +1341,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 #endif
 #undef CRH_LAUNCH2
 #undef CRH_LAUNCH
+#undef CRH_LAUNCH_WG
 	hipError_t e = hipGetLastError();
 	HIP_TRY(hipEventRecord(ev.b, c->stream));
 	c->pendingTimes.push_back(ev);
@@ -995,6 +1424,7 @@ int crh_synchronize(crh_ctx *c) {
 	rc = resolveTimes(c, true);
 	for (void *p : c->deferredFrees) (void)hipFree(p);
 	c->deferredFrees.clear();
+	if (rc == CRH_OK) rc = checkWatchdog(c);
 	return rc;
 }
 

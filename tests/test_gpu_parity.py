@@ -184,6 +184,65 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
     ctx.set_option(pkg.abi.OPT_COUNTER_LEVEL, 2)
 
 
+def test_workgroup_kernel_is_bit_identical_to_the_wave_kernel(pkg, ctx, manifest, golden_blob):
+    """CRH_OPT_KERNEL: the workgroup-cooperative form (walker / shader roles, shared path table, LDS lock) runs the same per-path
+    operations as the per-wave machine — same frame, same counters, for every scheduler setting incl. the degenerate ones (never
+    linger / always linger, drain at once / never, no drainers, partial batches of 1, tables of 64 paths), both samplers, a scene with
+    node programs, multi-chunk passes and ragged tiles."""
+    abi = pkg.abi
+    scheds = [(8, 192, 1, 16, 32, 768), (0, 1, 4, 1, 1, 64), (255, 4095, 0, 64, 64, 960), (3, 64, 2, 8, 16, 256)]
+    try:
+        for name in ("refraction", "glowmetal", "cfg1_scene"):
+            m = manifest[name]
+            w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+            full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob(name), w, h, s, b)
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WG)
+            for sc in scheds:
+                ctx.set_sched_wg(*sc)
+                for level in (2, 1):
+                    ctx.set_option(abi.OPT_COUNTER_LEVEL, level)
+                    ctx.clear(fb, w, h)
+                    ctx.reset_counters()
+                    ctx.render_region(fb, w, h, s, b)
+                    assert np.array_equal(ctx.download(fb, w, h), full), (name, sc, level)
+                    got = ctx.counters()
+                    assert got["rays"] == cnt_full["rays"] and got["paths"] == cnt_full["paths"]
+                    if level == 2:
+                        assert got == cnt_full, (name, sc)
+            ctx.set_sched_wg()
+            ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+            # ragged tiles, pass splits and small units through the workgroup kernel
+            ctx.set_option(abi.OPT_UNIT_ITEMS, 64)
+            ctx.set_option(abi.OPT_PASS_CHUNK, 1)
+            ctx.clear(fb, w, h)
+            ctx.render_tiles(fb, w, h, s, b, [(0, 0, w - 1, h // 3), (0, h // 3, w - 1, h), (w - 1, 0, w, h)], first_pass=0, pass_count=1)
+            ctx.render_tiles(fb, w, h, s, b, [(0, 0, w, h)], first_pass=1)
+            assert np.array_equal(ctx.download(fb, w, h), full), name
+            ctx.set_option(abi.OPT_UNIT_ITEMS, 1024)
+            ctx.set_option(abi.OPT_PASS_CHUNK, 64)
+        # Halton sampler (interactive mode)
+        m = manifest["cfg1_scene_iterative"]
+        w, h, n, b = m["width"], m["height"], m["samples"], m["bounces"]
+        ctx.upload(pkg.api.Scene(golden_blob(m["blob"])))
+        fb = ctx.framebuffer(w, h)
+        ctx.set_option(abi.OPT_SAMPLER, abi.SAMPLER_HALTON)
+        imgs = []
+        for kern in (abi.KERNEL_WAVE, abi.KERNEL_WG):
+            ctx.set_option(abi.OPT_KERNEL, kern)
+            ctx.clear(fb, w, h)
+            ctx.render_region(fb, w, h, n, b, pass_count=m["passes"])
+            imgs.append(ctx.download(fb, w, h))
+        assert np.array_equal(imgs[0], imgs[1])
+    finally:
+        ctx.set_option(abi.OPT_SAMPLER, abi.SAMPLER_RANDOM)
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+        ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+        ctx.set_option(abi.OPT_UNIT_ITEMS, 2048)
+        ctx.set_option(abi.OPT_PASS_CHUNK, 64)
+        ctx.set_sched_wg()
+
+
 def test_zero_component_rays(pkg, ctx, oracle, golden_blob):
     blob = golden_blob("cfg1_scene")
     ctx.upload(pkg.api.Scene(blob))

@@ -26,8 +26,18 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-WORKLOAD = {"scene": "hdr.json", "blob": "cfg2_hdr", "width": 1280, "height": 720, "samples": 256, "bounces": 8,
-            "tile": (64, 64), "tile_order": 1}
+WORKLOADS = {   # BASELINE.json configs[1..4]; the default (and the headline) is cfg2
+    "cfg2": {"scene": "hdr.json", "blob": "cfg2_hdr", "width": 1280, "height": 720, "samples": 256, "bounces": 8, "tile": (64, 64), "tile_order": 1,
+             "what": "input/hdr.json {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[1]); venusscaled.obj = generated 524288-triangle stand-in "
+                     "(tools/gen_assets.py), HDR env map + 2048^2 grid texture from the reference tree"},
+    "cfg3": {"scene": "venus.json", "blob": "cfg3_venus", "width": 1920, "height": 1080, "samples": 1024, "bounces": 32, "tile": (64, 64), "tile_order": 1,
+             "what": "input/venus.json {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[2]); venusscaled.obj = generated stand-in"},
+    "cfg4": {"scene": "statues.json", "blob": "cfg4_statues", "width": 3840, "height": 2160, "samples": 2048, "bounces": 30, "tile": (64, 64), "tile_order": 1,
+             "what": "input/statues.json {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[3]: the 1/2/4/8-GPU scaling scene); 55 instances of the stand-in statue"},
+    "soup": {"scene": "soup_1000000.json", "blob": "soup_1m", "width": 2560, "height": 1440, "samples": 512, "bounces": 8, "tile": (64, 64), "tile_order": 1,
+             "what": "synthetic 1 M-triangle soup {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[4] at 1 M triangles; the 10 M blob is built on the box by tools/make_soup.sh)"},
+}
+WORKLOAD = WORKLOADS["cfg2"]
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -52,6 +62,57 @@ def algorithmic_bytes(cnt, path_state=True):
     return b
 
 
+def kernel_source_md5():
+    """Fingerprint of the kernel sources: PMC figures in profiles/ are quoted only while they describe THIS kernel."""
+    import hashlib
+    m = hashlib.md5()
+    for f in ("cray_hip.hip", "pt_device.h"):
+        m.update(open(os.path.join(REPO, "c-ray_amd", "csrc", f), "rb").read())
+    return m.hexdigest()
+
+
+def measured_profile(workload_key):
+    """(traffic bytes per launch, VALU roofline dict) from the committed rocprofv3 PMC summary — or (None, None) when that summary
+    was taken from different kernel sources or another workload (stale numbers are not quoted)."""
+    path = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None, None
+    if t.get("source_md5") != kernel_source_md5() or t.get("workload", "cfg2") != workload_key:
+        return None, None
+    return t.get("hbm_bytes_per_launch"), t.get("valu")
+
+
+def dropin_timing(workload):
+    """The binary a c-ray user runs: c-ray-hip (reference main + loader + encoders, renderer.c replaced) on the same frame. Render phase =
+    the timer of src/c-ray.c:279-281 around renderFrame(); CRH_DUMP_STATS splits it (flatten, context + upload, dispatch, download, sRGB)."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    exe = os.path.join(REPO, "c-ray_amd", "_lib", "c-ray-hip")
+    overlay = os.path.join(REPO, "oracle", "_ref", "input")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(overlay, workload["scene"]))):
+        return {"skipped": "c-ray-hip or the asset overlay is not built"}
+    import refrun
+    with tempfile.TemporaryDirectory() as tmp:
+        scene = refrun.rewrite_scene(workload["scene"], workload["width"], workload["height"], workload["samples"], workload["bounces"],
+                                     tile=workload["tile"], out_dir=tmp)
+        stats = os.path.join(tmp, "stats.json")
+        env = dict(os.environ, CRH_DUMP_STATS=stats, CRAY_HIP_DEVICES="1", CRH_NO_IMAGE="1")
+        t0 = time.perf_counter()
+        proc = subprocess.run([exe], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        wall = time.perf_counter() - t0
+        if proc.returncode != 0 or not os.path.exists(stats):
+            return {"failed": proc.stdout.decode(errors="replace")[-300:]}
+        st = json.load(open(stats))
+    return {"program": "c-ray_amd/_lib/c-ray-hip < hdr.json (1 GPU)", "mrays": round(st["rays"] / st["render_ms"] / 1e3, 1), "render_ms": st["render_ms"],
+            "context_upload_ms": st["context_upload_ms"], "flatten_ms": st["flatten_ms"], "reduce_download_ms": st["reduce_download_ms"],
+            "resolve_srgb_ms": st["resolve_srgb_ms"], "process_wall_s": round(wall, 2), "rays": st["rays"],
+            "note": "render_ms = first dispatch to last synchronize inside renderFrame(); context_upload_ms = HIP context creation + layout compile + copies "
+                    "(one-off per process); process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
+
+
 def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
     """Reference pthread renderer on the host cores, bounded sample of the same frame (reduced spp)."""
     import numpy as np
@@ -74,7 +135,7 @@ def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
             _, st = refrun.render_reference(WORKLOAD["scene"], w, h, spp, bounces, flavour="default", threads=cores)
             secs = st["render_ms"] / 1e3
             return {"value": round(cnt["rays"] / secs / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "reference",
-                    "sample": f"oracle/_ref/c-ray-ref -j {cores}: {WORKLOAD['scene']} {w}x{h}, {spp} spp (of 256), {bounces} bounces, "
+                    "sample": f"oracle/_ref/c-ray-ref -j {cores}: {WORKLOAD['scene']} {w}x{h}, {spp} spp (of {WORKLOAD['samples']}), {bounces} bounces, "
                               f"render phase {secs:.2f} s, {cnt['rays']} rays (counted by the bit-exact restatement)",
                     "port_value": round(cnt["rays"] / port_s / 1e6, 3)}
         except Exception as e:  # fall back to the restatement, say so
@@ -82,7 +143,7 @@ def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
     else:
         note = " (oracle/_ref binary or asset overlay absent)"
     return {"value": round(cnt["rays"] / port_s / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libcray_oracle.so (OpenMP, {cores} threads): {w}x{h}, {spp} spp (of 256), {bounces} bounces, {port_s:.2f} s" + note}
+            "sample": f"oracle/libcray_oracle.so (OpenMP, {cores} threads): {w}x{h}, {spp} spp (of {WORKLOAD['samples']}), {bounces} bounces, {port_s:.2f} s" + note}
 
 
 def main():
@@ -90,9 +151,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=WORKLOAD["samples"], help=argparse.SUPPRESS)   # dev only
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 (default, the headline: BASELINE.json configs[1]); cfg4 = configs[3], the scene the 1/2/4/8-GPU curve is quoted on")
+    ap.add_argument("--samples", type=int, default=0, help=argparse.SUPPRESS)   # dev only: fewer passes than the config names
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-dropin", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    global WORKLOAD
+    WORKLOAD = WORKLOADS[a.workload]
+    if not a.samples:
+        a.samples = WORKLOAD["samples"]
 
     import torch
     from __graft_entry__ import load_package, BUILT
@@ -167,35 +235,43 @@ def main():
         alg = algorithmic_bytes(full)
         alg_no_state = algorithmic_bytes(full, path_state=False)
         achieved = alg / (avg_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1 and SPP == WORKLOAD["samples"]:
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, valu = (None, None)
+        if world == 1 and SPP == WORKLOAD["samples"]:
+            traffic, valu = measured_profile(a.workload)
+        frac_state = achieved / HBM_PEAK_GBS
+        achieved_scene = alg_no_state / (avg_kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mray/s (primary+secondary)", "value": round(value, 2), "unit": "Mray/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"input/hdr.json {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[1]); venusscaled.obj = "
-                                   "generated 524288-triangle stand-in (tools/gen_assets.py), HDR env map + 2048^2 grid texture from the reference tree",
+            "config": {"workload": WORKLOAD["what"].format(W=W, H=H, SPP=SPP, B=B),
                        "rays_per_step": int(total_rays / a.steps), "paths_per_step": int(total_paths / a.steps),
                        "parallelism": ("1 rank: the reference's 64x64 tile list in one dispatch" if world == 1 else
                                        f"4-row strips interleaved over {world} ranks + one RCCL reduce of the float framebuffer")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_pathtrace", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg),
-                         "bytes_per_ray": round(alg / max(full["rays"], 1), 1),
-                         "frac_without_path_state": round(alg_no_state / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "note": "rank 0's launch. algorithmic bytes = scene records touched (node/triangle/instance/shading/texel) + SURVEY 8(d) "
-                                 "B_state (152 B/ray: paths live in a per-wave table in memory). traffic = L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE); the "
-                                 "scene (~165 MB) and the path tables sit in the 256 MB Infinity Cache, so most of it never reaches HBM"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_scene / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_pathtrace", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
+                         "bytes_per_ray": round(alg_no_state / max(full["rays"], 1), 1),
+                         "frac_with_path_state": round(frac_state, 5),
+                         "what_it_is": "ALGORITHMIC rate, not an HBM measurement: scene records touched (node / triangle / instance / shading / texel), "
+                                       "B_state = 0 (SURVEY 8(d): persistent megakernel), divided by the launch time. Most of those bytes are served by L2 and the "
+                                       "256 MB Infinity Cache; `traffic` is the measured L2<->fabric volume (FETCH_SIZE x2 + WRITE_SIZE, MALL hits included) and is "
+                                       "null whenever profiles/hbm_traffic.json was not measured on these kernel sources / this workload. frac_with_path_state adds "
+                                       "152 B/ray for the per-wave path table",
+                         "valu": valu},
         }
         if world == 1 and not a.no_cpu:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import oracle_py
             out["cpu_baseline"] = cpu_baseline(oracle_py, blob, W, H, B)
+        if world == 1 and not a.no_dropin and SPP == WORKLOAD["samples"] and a.workload == "cfg2":
+            try:
+                fr.close()                 # the drop-in is its own process with its own context
+            except Exception:
+                pass
+            out["dropin"] = dropin_timing(WORKLOAD)
+            if isinstance(out["dropin"].get("render_ms"), (int, float)):
+                out["dropin"]["vs_bench_ms_per_step"] = round(out["dropin"]["render_ms"] / ms_per_step, 3)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -571,8 +571,10 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 			int idlePolls = K.linger;                     /* a wave that has not served yet does not linger */
 			uint32_t waitStart = 0;
 			bool waiting = false;
+			const uint32_t chunkStart = CRH_TICK();
 			for (;;) {   /* ---- top of the machine: this wave holds no walk ---- */
 				if (ctl[CT_ABORT]) break;
+				if (CRH_TICK() - chunkStart > 3000000000u) { if (lane == 0) { ctl[CT_ABORT] = 1; atomicOr(errFlag, 4u); } break; }   /* 30 s in one chunk: watchdog */
 				const int nH = ctl[CT_HITS], nM = ctl[CT_MISSES], nR = ctl[CT_RAYS];
 				const uint32_t nextItem = (uint32_t)ctl[CT_NEXT];
 				const int nFree = ctl[CT_FREE];
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 							const int hq2 = hq + (int)__popcll(hm), mq2 = mq + (int)__popcll(mm);
 							/* ... the drain token: shading has fallen behind -> this wave stops taking rays and becomes a server once its walks end */
 							int drainers = ctl[CT_DRAINERS];
-							if (!draining && drainers < K.maxDrainers && hq2 + mq2 >= K.drainAt) { draining = true; ++drainers; }
+							if (!draining && walkers + nF > 0 && drainers < K.maxDrainers && hq2 + mq2 >= K.drainAt) { draining = true; ++drainers; }    /* (a wave with nothing in flight has nothing to drain: it takes rays, so every WALK job makes progress) */
 							else if (draining && hq2 + mq2 < 64) { draining = false; --drainers; }
 							/* ... and idle lanes pop ray ids */
 							const bool idle = (w.phase == PH_IDLE);
@@ -902,7 +904,10 @@ struct crh_ctx {
 	unsigned long long *dCounters = nullptr;
 	uint32_t *dWork = nullptr;             /* ring of work counters, one per in-flight launch */
 	uint32_t workSlot = 0;
-	std::vector<void *> deferredFrees;     /* per-launch tile lists: freed once the stream has drained */
+	/* per-launch tile lists: a ring of persistent device buffers, each with a pinned host twin (no hipMalloc and no blocking copy per
+	 * launch: one hipMemcpyAsync on the launch stream); a slot is reused only after the launch that read it has finished */
+	struct TileSlot { void *dev = nullptr; void *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool inFlight = false; };
+	TileSlot tileSlots[64];
 	struct Timed { hipEvent_t a, b; };
 	std::vector<Timed> pendingTimes;
 	std::vector<Timed> eventPool;
@@ -911,6 +916,7 @@ struct crh_ctx {
 	uint64_t launches = 0;
 };
 #define CRH_WORK_SLOTS 64
+static_assert(sizeof(((crh_ctx *)nullptr)->tileSlots) / sizeof(crh_ctx::TileSlot) == CRH_WORK_SLOTS, "one tile slot per work counter");
 
 static int setDevice(crh_ctx *c) {
 	HIP_TRY(hipSetDevice(c->device));
@@ -1011,7 +1017,11 @@ int crh_context_destroy(crh_ctx *c) {
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	freeScene(c);
-	for (void *p : c->deferredFrees) (void)hipFree(p);
+	for (auto &ts : c->tileSlots) {
+		if (ts.dev) (void)hipFree(ts.dev);
+		if (ts.host) (void)hipHostFree(ts.host);
+		if (ts.done) (void)hipEventDestroy(ts.done);
+	}
 	for (auto &t : c->pendingTimes) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (auto &t : c->eventPool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	if (c->dCounters) (void)hipFree(c->dCounters);
@@ -1185,7 +1195,6 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	int rc = setDevice(c);
 	if (rc) return rc;
 	(void)resolveTimes(c, false);
-	if (c->pendingTimes.empty()) { for (void *p : c->deferredFrees) (void)hipFree(p); c->deferredFrees.clear(); }
 	/* Block shape: one work unit (a block for all passes of the dispatch) should hold about unitItems paths, so
 	 * that every wave gets many units (load balance) whatever the sample count: 16x16 pixels at 4 spp ... 2x2 at
 	 * 256 spp, 1x1 beyond. Smaller blocks also keep the 64 lanes of a wave on fewer pixels (coherent walks). */
@@ -1286,20 +1295,32 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		}
 	}
 
-	/* per-launch tile list in HBM (freed once the stream has drained) */
-	void *dTiles = nullptr;
+	/* per-launch tile list: pinned host slot -> device slot, asynchronously on the launch stream */
+	const uint32_t slot = c->workSlot++ % CRH_WORK_SLOTS;
+	crh_ctx::TileSlot &ts = c->tileSlots[slot];
 	const size_t tileBytes = work_count * sizeof(crh_tile), startBytes = (work_count + 1) * sizeof(uint32_t);
-	HIP_TRY(hipMalloc(&dTiles, tileBytes + startBytes));
-	c->deferredFrees.push_back(dTiles);
-	HIP_TRY(hipMemcpy(dTiles, work.data(), tileBytes, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy((char *)dTiles + tileBytes, start.data(), startBytes, hipMemcpyHostToDevice));
+	if (ts.inFlight) { HIP_TRY(hipEventSynchronize(ts.done)); ts.inFlight = false; }
+	if (tileBytes + startBytes > ts.cap) {
+		if (ts.dev) HIP_TRY(hipFree(ts.dev));
+		if (ts.host) HIP_TRY(hipHostFree(ts.host));
+		ts.dev = ts.host = nullptr; ts.cap = 0;
+		const size_t cap = std::max<size_t>(4096, 2 * (tileBytes + startBytes));
+		HIP_TRY(hipMalloc(&ts.dev, cap));
+		HIP_TRY(hipHostMalloc(&ts.host, cap, hipHostMallocDefault));
+		ts.cap = cap;
+	}
+	if (!ts.done) HIP_TRY(hipEventCreateWithFlags(&ts.done, hipEventDisableTiming));
+	memcpy(ts.host, work.data(), tileBytes);
+	memcpy((char *)ts.host + tileBytes, start.data(), startBytes);
+	HIP_TRY(hipMemcpyAsync(ts.dev, ts.host, tileBytes + startBytes, hipMemcpyHostToDevice, c->stream));
+	void *dTiles = ts.dev;
 
 	BlockQueue Q;
 	Q.tiles = (const crh_tile *)dTiles;
 	Q.start = (const uint32_t *)((char *)dTiles + tileBytes);
 	Q.ntiles = work_count;
 	Q.total = (uint32_t)total;
-	Q.counter = c->dWork + (c->workSlot++ % CRH_WORK_SLOTS);
+	Q.counter = c->dWork + slot;
 	Q.bw = bw; Q.bh = bh;
 	Q.firstSmall = firstSmall; Q.sbw = sbw; Q.sbh = sbh;
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
@@ -1308,6 +1329,8 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(work_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, work_count, dev_fb, c->dCounters);
 		hipError_t e0 = hipGetLastError();
 		if (e0 != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_fold_black launch: ") + hipGetErrorString(e0));
+		HIP_TRY(hipEventRecord(ts.done, c->stream));
+		ts.inFlight = true;
 		return CRH_OK;
 	}
 	crh_ctx::Timed ev;
@@ -1344,6 +1367,8 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 #undef CRH_LAUNCH_WG
 	hipError_t e = hipGetLastError();
 	HIP_TRY(hipEventRecord(ev.b, c->stream));
+	HIP_TRY(hipEventRecord(ts.done, c->stream));
+	ts.inFlight = true;
 	c->pendingTimes.push_back(ev);
 	c->launches++;
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_pathtrace launch: ") + hipGetErrorString(e));
@@ -1422,8 +1447,7 @@ int crh_synchronize(crh_ctx *c) {
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	rc = resolveTimes(c, true);
-	for (void *p : c->deferredFrees) (void)hipFree(p);
-	c->deferredFrees.clear();
+	for (auto &ts : c->tileSlots) ts.inFlight = false;
 	if (rc == CRH_OK) rc = checkWatchdog(c);
 	return rc;
 }

@@ -10,9 +10,10 @@
  *
  * What changes is who consumes the tile queue: instead of N pthread workers running the pixel x pass loop
  * (renderer.c:258-327) there is ONE host thread per GPU. Each flattens nothing itself — the scene is
- * flattened once (flatten.c) — owns a crh_ctx (libcray_hip.so), pulls batches of tiles from the reference's
- * own nextTile() queue (tile.c:22-45) and renders a batch with one crh_render_tiles() dispatch. When the
- * queue is empty the per-GPU float framebuffers (disjoint tiles, zero elsewhere) are summed onto GPU 0 with
+ * flattened once (flatten.c) — owns a crh_ctx (libcray_hip.so) and renders ITS share of the frame — one GPU: the reference's tile
+ * list (tile.c:66-241) in its order; several: every G-th 4-row strip — with ONE crh_render_tiles() dispatch per 512 passes (the
+ * persistent kernel balances the work units inside a dispatch itself; a drain per tile batch would idle the GPU). Then
+ * the per-GPU float framebuffers (disjoint pixels, zero elsewhere) are summed onto GPU 0 with
  * RCCL over xGMI (crh_frames_reduce), downloaded into state.renderBuffer, and converted to the 8-bit sRGB
  * output with the reference's own colorToSRGB()/setPixel() on the host.
  *
@@ -47,6 +48,7 @@
 
 #include "cray_hip.h"
 #include "flatten.h"
+#include "share.h"
 
 #define MAX_GPUS 16
 
@@ -60,25 +62,43 @@ struct gpuWorker {
 	int failed;
 	char error[256];      /* crh_last_error() is per thread: the failing dispatch thread keeps its message here */
 	uint64_t rays;
+	long setupUs, renderUs;   /* context + upload + framebuffer; dispatch loop (first launch to last sync) */
 };
 
-static int tilesPerBatch(const struct renderer *r, int gpus) {
-	/* enough tiles per dispatch to fill a GPU, few enough that the queue still balances the GPUs */
-	int per = r->state.tileCount / (gpus * 4);
-	if (per < 1) per = 1;
-	if (per > 64) per = 64;
-	return per;
+/* passes per dispatch: one dispatch keeps the whole GPU busy from its first work unit to its last (no drain in between), so a
+ * frame is cut only along the pass axis, and only when it is long enough that the preview window / abort key should get a turn */
+#define PASSES_PER_DISPATCH 512
+
+/* The share of GPU g of G: G == 1 -> the reference's own tile list in its order (tile.c:66-241); G > 1 -> every G-th 4-row strip
+ * (static shares must be balanced, and dealing out the tile list is not: DESIGN.md section 6). Returns the tile count. */
+static uint32_t gpuShare(const struct renderer *r, int g, int G, crh_tile **out) {
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	if (G == 1) {
+		crh_tile *t = calloc((size_t)(r->state.tileCount > 0 ? r->state.tileCount : 1), sizeof(*t));
+		for (int i = 0; i < r->state.tileCount; ++i) {
+			const struct renderTile *rt = &r->state.renderTiles[i];
+			t[i] = (crh_tile){rt->begin.x, rt->begin.y, rt->end.x, rt->end.y};
+		}
+		*out = t;
+		return (uint32_t)r->state.tileCount;
+	}
+	crh_tile *t = calloc((size_t)crh_strip_share_max(H, G), sizeof(*t));
+	*out = t;
+	return crh_strip_share(W, H, g, G, t);
 }
 
 static void *gpuThread(void *arg) {
 	struct gpuWorker *w = threadUserData(arg);
 	struct renderer *r = w->r;
 	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	const int G = r->prefs.threadCount;
 	crh_render_params p;
 	memset(&p, 0, sizeof(p));
 	p.image_width = W; p.image_height = H;
-	p.first_pass = 0; p.pass_count = r->prefs.sampleCount; p.max_passes = r->prefs.sampleCount;
+	p.max_passes = r->prefs.sampleCount;
 	p.bounces = r->prefs.bounces;
+	struct timeval phase;
+	startTimer(&phase);
 
 	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_scene_upload(w->ctx, w->scene) != CRH_OK ||
 		crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK) {
@@ -88,39 +108,34 @@ static void *gpuThread(void *arg) {
 		w->state->threadComplete = true;
 		return NULL;
 	}
-	const int batchMax = tilesPerBatch(r, r->prefs.threadCount);
-	crh_tile *batch = calloc((size_t)batchMax, sizeof(*batch));
-	int *tileNums = calloc((size_t)batchMax, sizeof(*tileNums));
-	while (r->state.isRendering && !r->state.renderAborted) {
-		int n = 0;
-		while (n < batchMax) {
-			struct renderTile t = nextTile(r);
-			if (t.tileNum == -1) break;
-			batch[n] = (crh_tile){t.begin.x, t.begin.y, t.end.x, t.end.y};
-			tileNums[n++] = t.tileNum;
-		}
-		if (n == 0) break;
-		w->state->currentTileNum = tileNums[0];
-		w->state->completedSamples = 1;
-		if (crh_render_tiles(w->ctx, &p, batch, (uint32_t)n, w->fb) != CRH_OK || crh_synchronize(w->ctx) != CRH_OK) {
+	crh_tile *share = NULL;
+	const uint32_t n = gpuShare(r, w->device, G, &share);
+	uint64_t pixels = 0;
+	for (uint32_t i = 0; i < n; ++i) pixels += (uint64_t)(share[i].x1 - share[i].x0) * (uint64_t)(share[i].y1 - share[i].y0);
+	if (G == 1) for (int i = 0; i < r->state.tileCount; ++i) r->state.renderTiles[i].isRendering = true;
+	w->state->currentTileNum = 0;
+	w->setupUs = getUs(phase);
+	startTimer(&phase);
+	for (int done = 0; done < r->prefs.sampleCount && r->state.isRendering && !r->state.renderAborted; ) {
+		p.first_pass = done;
+		p.pass_count = r->prefs.sampleCount - done < PASSES_PER_DISPATCH ? r->prefs.sampleCount - done : PASSES_PER_DISPATCH;
+		if (n && (crh_render_tiles(w->ctx, &p, share, n, w->fb) != CRH_OK || crh_synchronize(w->ctx) != CRH_OK)) {
 			snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 			logr(warning, "GPU %d: %s\n", w->device, w->error);
 			w->failed = 1;
 			break;
 		}
-		w->state->completedSamples = r->prefs.sampleCount;
-		for (int i = 0; i < n; ++i) {
-			struct renderTile *t = &r->state.renderTiles[tileNums[i]];
-			w->state->totalSamples += (uint64_t)t->width * t->height * (uint64_t)r->prefs.sampleCount;
-			t->isRendering = false;
-			t->renderComplete = true;
-		}
+		done += p.pass_count;
+		w->state->completedSamples = done;
+		w->state->totalSamples = pixels * (uint64_t)done;
 		while (w->state->paused && !r->state.renderAborted) sleepMSec(100);
 	}
+	w->renderUs = getUs(phase);
+	if (G == 1 && !w->failed && !r->state.renderAborted)
+		for (int i = 0; i < r->state.tileCount; ++i) { r->state.renderTiles[i].isRendering = false; r->state.renderTiles[i].renderComplete = true; }
 	crh_counters c;
 	if (!w->failed && crh_counters_get(w->ctx, &c) == CRH_OK) w->rays = c.rays;
-	free(batch);
-	free(tileNums);
+	free(share);
 	w->state->currentTileNum = -1;
 	w->state->threadComplete = true;
 	return NULL;
@@ -137,7 +152,6 @@ static void resolveOutput(struct renderer *r, struct texture *output) {
 /* --iterative: returns the rays traced, fills state.renderBuffer and output */
 static uint64_t renderInteractive(struct renderer *r, struct texture *output, const crh_scene_desc *scene, int gpus) {
 	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
-	const int tileCount = r->state.tileCount;
 	crh_ctx *ctx[MAX_GPUS];
 	float *fb[MAX_GPUS];
 	crh_tile *tiles[MAX_GPUS];
@@ -147,18 +161,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
 			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK)
 			logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
-		tiles[g] = calloc((size_t)(gpus == 1 ? tileCount : H / 4 / gpus + 2), sizeof(crh_tile));
-		ntiles[g] = 0;
-	}
-	if (gpus == 1) {
-		for (int i = 0; i < tileCount; ++i) {
-			const struct renderTile *t = &r->state.renderTiles[i];
-			tiles[0][ntiles[0]++] = (crh_tile){t->begin.x, t->begin.y, t->end.x, t->end.y};
-		}
-	} else {
-		/* static shares must be balanced: 4-row strips dealt round-robin (dealing out the tile list is not) */
-		for (int y = 0, i = 0; y < H; y += 4, ++i)
-			tiles[i % gpus][ntiles[i % gpus]++] = (crh_tile){0, y, W, y + 4 < H ? y + 4 : H};
+		ntiles[g] = gpuShare(r, g, gpus, &tiles[g]);
 	}
 	const int passes = r->prefs.sampleCount - 1;             /* finishedPasses runs from 1 while < sampleCount (renderer.c:199, tile.c:52) */
 	crh_render_params p;
@@ -220,7 +223,10 @@ struct texture *renderFrame(struct renderer *r) {
 	logr(info, "Rendering at %i x %i, %i samples, %i bounces on %i GPU%s.\n", W, H, r->prefs.sampleCount, r->prefs.bounces, gpus, PLURAL(gpus));
 
 	crh_scene_desc scene;
+	struct timeval phase;
+	startTimer(&phase);
 	const int frc = crh_flatten_world(r, &scene);
+	const long flattenUs = getUs(phase);
 	if (frc != CRH_OK) logr(error, "c-ray-hip: the scene cannot be flattened for the GPU (%i)\n", frc);
 
 	r->state.isRendering = true;
@@ -273,6 +279,7 @@ struct texture *renderFrame(struct renderer *r) {
 	for (int g = gpus - 1; g >= 0; --g) { failed += workers[g].failed; rays += workers[g].rays; if (workers[g].failed) firstError = workers[g].error; }
 	if (failed) logr(error, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), firstError);
 
+	startTimer(&phase);
 	/* assemble the frame on GPU 0 (RCCL reduce over xGMI; tiles are disjoint so the sum is a gather) */
 	if (gpus > 1) {
 		crh_ctx *ctxs[MAX_GPUS];
@@ -284,7 +291,24 @@ struct texture *renderFrame(struct renderer *r) {
 	if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
 		logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
 
+	const long gatherUs = getUs(phase);
+	startTimer(&phase);
 	resolveOutput(r, output);      /* 8-bit output exactly like renderer.c:294-300 */
+	const long resolveUs = getUs(phase);
+	/* CRH_DUMP_STATS=<path>: where the render phase (src/c-ray.c:279-281) went, for bench.py's `dropin` object */
+	const char *statsPath = getenv("CRH_DUMP_STATS");
+	if (statsPath) {
+		long setupUs = 0, renderUs = 0;
+		for (int g = 0; g < gpus; ++g) { if (workers[g].setupUs > setupUs) setupUs = workers[g].setupUs; if (workers[g].renderUs > renderUs) renderUs = workers[g].renderUs; }
+		FILE *f = fopen(statsPath, "w");
+		if (f) {
+			fprintf(f, "{\"gpus\": %d, \"width\": %d, \"height\": %d, \"samples\": %d, \"bounces\": %d, \"rays\": %llu, \"flatten_ms\": %.3f, "
+					"\"context_upload_ms\": %.3f, \"render_ms\": %.3f, \"reduce_download_ms\": %.3f, \"resolve_srgb_ms\": %.3f}\n",
+					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, setupUs / 1e3, renderUs / 1e3,
+					gatherUs / 1e3, resolveUs / 1e3);
+			fclose(f);
+		}
+	}
 
 	const char *dump = getenv("CRH_DUMP_F32");
 	if (dump) {

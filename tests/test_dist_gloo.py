@@ -52,3 +52,37 @@ def test_two_rank_tile_sharding_reproduces_the_frame(manifest, golden_blob, gold
              nprocs=2, join=True)
     frame = np.load(out)
     assert np.array_equal(frame, golden_ref("fence")), "2-rank frame differs from the reference's single-process frame"
+
+
+def test_eight_rank_strip_sharding_reproduces_the_frame(manifest, golden_blob, golden_ref, tmp_path):
+    """World size 8 with a frame height (100) that is not a multiple of 4 x 8: ragged last strip, ranks with unequal strip counts."""
+    import torch.multiprocessing as mp
+    m = manifest["fence"]
+    assert m["height"] % (4 * 8) != 0
+    out = str(tmp_path / "frame8.npy")
+    mp.spawn(_worker, args=(8, _free_port(), golden_blob("fence"), m["width"], m["height"], m["samples"], m["bounces"], out),
+             nprocs=8, join=True)
+    assert np.array_equal(np.load(out), golden_ref("fence")), "8-rank frame differs from the reference's single-process frame"
+
+
+@pytest.mark.parametrize("width,height,gpus", [(160, 100, 8), (1280, 720, 8), (3840, 2160, 8), (33, 7, 3), (64, 3, 2), (5, 9, 16)])
+def test_c_host_partition_equals_the_python_hosts_and_covers_the_frame_once(width, height, gpus, pkg, tmp_path):
+    """c-ray-hip (host/share.h: crh_strip_share) and render.py (owned_tiles) must own the same pixels on every rank; together the
+    shares cover every pixel exactly once (ragged heights, more GPUs than strips)."""
+    import subprocess
+    src = tmp_path / "share.c"
+    src.write_text('#include <stdio.h>\n#include <stdlib.h>\n#include "share.h"\n'
+                   'int main(int c, char **v) { int W = atoi(v[1]), H = atoi(v[2]), G = atoi(v[3]);\n'
+                   ' crh_tile *t = calloc(crh_strip_share_max(H, G), sizeof(*t));\n'
+                   ' for (int g = 0; g < G; ++g) { uint32_t n = crh_strip_share(W, H, g, G, t); if (n > crh_strip_share_max(H, G)) return 1;\n'
+                   '  for (uint32_t i = 0; i < n; ++i) printf("%d %d %d %d %d\\n", g, t[i].x0, t[i].y0, t[i].x1, t[i].y1); }\n return 0; }\n')
+    exe = tmp_path / "share"
+    subprocess.check_call(["gcc", "-std=gnu99", "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(REPO, "c-ray_amd", "host"), str(src), "-o", str(exe)])
+    rows = [tuple(int(x) for x in line.split()) for line in subprocess.check_output([str(exe), str(width), str(height), str(gpus)]).decode().splitlines()]
+    cover = np.zeros((height, width), np.int32)
+    for g in range(gpus):
+        mine = [r[1:] for r in rows if r[0] == g]
+        assert mine == [tuple(t) for t in pkg.render.owned_tiles(width, height, 64, 64, pkg.tiles.ORDER_FROM_MIDDLE, g, gpus)], g
+        for x0, y0, x1, y1 in mine:
+            cover[y0:y1, x0:x1] += 1
+    assert (cover == 1).all()

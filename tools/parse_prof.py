@@ -15,7 +15,7 @@ import sqlite3
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(REPO, "gpurun_out", "prof")
+PROF = os.path.join(REPO, "gpurun_out", "prof" + os.environ.get("PROF_SUFFIX", ""))
 OUT = os.path.join(REPO, "profiles")
 
 
@@ -31,9 +31,13 @@ def kernel_stats(db):
 
 
 def counters(db, kernel_like="k_pathtrace"):
+    """Per-dispatch averages over the TIMED launches (counter level 1: bench.py's counting pass runs the level-2 instantiation)."""
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select counter_name, count(*), sum(value), avg(value) from counters_collection "
-                       "where kernel_name like ? group by counter_name", (f"%{kernel_like}%",)).fetchall()
+    q = ("select counter_name, count(*), sum(value), avg(value) from counters_collection "
+         "where (kernel_name like ? or kernel_name like ?) group by counter_name")
+    rows = cur.execute(q, (f"%{kernel_like}<1,%", f"%{kernel_like}ILi1E%")).fetchall()
+    if not rows:
+        rows = cur.execute(q, (f"%{kernel_like}%", f"%{kernel_like}%")).fetchall()
     return {r[0]: {"dispatches": r[1], "sum": r[2], "per_dispatch": r[3]} for r in rows}
 
 
@@ -66,8 +70,20 @@ def main():
         if "FETCH_SIZE" in pmc or "WRITE_SIZE" in pmc:
             rd = pmc.get("FETCH_SIZE", {}).get("per_dispatch", 0.0) * 1024
             wr = pmc.get("WRITE_SIZE", {}).get("per_dispatch", 0.0) * 1024
+            sys.path.insert(0, REPO)
+            from bench import kernel_source_md5
+            valu = None
+            need = ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU")
+            if all(k in pmc for k in need):
+                g = lambda k: pmc[k]["per_dispatch"]
+                valu = {"bound": "valu-issue", "pipe_busy": round(g("SQ_ACTIVE_INST_VALU") / (g("SQ_WAVE_CYCLES") / 4.0), 4),
+                        "lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INSTS_VALU")), 4),
+                        "valu_wave_instructions_per_launch": g("SQ_INSTS_VALU"),
+                        "formulas": "pipe_busy = SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU)",
+                        "source": f"profiles/{tag}_rocprof_summary.json"}
             hbm = {"fetch_bytes_raw": rd, "fetch_bytes_gfx950_corrected": 2 * rd, "write_bytes": wr,
-                   "hbm_bytes_per_launch": 2 * rd + wr,
+                   "hbm_bytes_per_launch": 2 * rd + wr, "tag": tag, "workload": os.environ.get("PROFILE_WORKLOAD", "cfg2"),
+                   "source_md5": kernel_source_md5(), "valu": valu,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; bytes = counter * 1024; read side doubled per MI355X_MICROARCH.md §HBM (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)"}
             summary["hbm"] = hbm
             lines.append("")

@@ -3,13 +3,15 @@
 #   one --kernel-trace --stats pass of bench.py, then one --pmc pass per counter group (PMC is never combined with tracing).
 # Afterwards, here:  python tools/parse_prof.py TAG
 TAG=${1:-r01}
+WORKLOAD=${2:-cfg2}          # bench.py --workload; SAMPLES (env) = dev override for the long configs
+EXTRA="--workload $WORKLOAD --no-cpu --no-dropin ${SAMPLES:+--samples $SAMPLES}"
 cd "$(dirname "$0")/.." || exit 1
 REPO=$(pwd)
 export TMPDIR=/tmp
-OUT=$REPO/gpurun_out/prof
+OUT=$REPO/gpurun_out/prof${PROF_SUFFIX:-}
 mkdir -p "$OUT"
 cd /tmp || exit 1
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o "$TAG" -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu > "$OUT/trace_$TAG.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o "$TAG" -- python "$REPO/bench.py" --steps 3 --warmup 1 $EXTRA > "$OUT/trace_$TAG.log" 2>&1
 echo "trace rc $?"; tail -1 "$OUT/trace_$TAG.log"
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE" \
@@ -19,6 +21,6 @@ for group in "FETCH_SIZE" "WRITE_SIZE" \
              "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
 	i=$((i + 1))
 	# shellcheck disable=SC2086
-	rocprofv3 --pmc $group -d "$OUT/pmc$i" -o "$TAG" -- python "$REPO/bench.py" --steps 2 --warmup 0 --no-cpu > "$OUT/pmc${i}_$TAG.log" 2>&1
+	rocprofv3 --pmc $group -d "$OUT/pmc$i" -o "$TAG" -- python "$REPO/bench.py" --steps 2 --warmup 0 $EXTRA > "$OUT/pmc${i}_$TAG.log" 2>&1
 	echo "pmc$i ($group) rc $?"
 done

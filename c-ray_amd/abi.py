@@ -24,7 +24,7 @@ class Poly(C.Structure):
 
 class Instance(C.Structure):
     _fields_ = [("Ainv", C.c_float * 12), ("A", C.c_float * 12), ("kind", C.c_uint32), ("object", C.c_uint32),
-                ("pad", C.c_uint32 * 6)]
+                ("density", C.c_float), ("pad", C.c_uint32 * 5)]
 
 
 class Mesh(C.Structure):

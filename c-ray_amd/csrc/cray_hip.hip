@@ -137,6 +137,20 @@ __device__ __forceinline__ void putPathRay(f4 *q, const v3 &o, const v3 &d, cons
 	q[3] = f4{r.fr, r.fg, r.fb, asF32((uint32_t)(r.rng.state >> 32))};
 }
 
+/* What a walk may ask of its path (pt_device.h: volumes): the sampler lives in words 2.w / 3.w of the path's record, words 6..7 are free */
+template <int SAMP> struct TablePort {
+	f4 *q;
+	__device__ __forceinline__ float draw() {
+		RngT<SAMP> r;
+		r.state = (uint64_t)asU32(q[2].w) | ((uint64_t)asU32(q[3].w) << 32);
+		const float v = getDimension(r);
+		q[2].w = asF32((uint32_t)r.state); q[3].w = asF32((uint32_t)(r.state >> 32));
+		return v;
+	}
+	__device__ __forceinline__ void save(int i, uint32_t v) { ((uint32_t *)(q + 6))[i] = v; }
+	__device__ __forceinline__ uint32_t load(int i) { return ((const uint32_t *)(q + 6))[i]; }
+};
+
 /* rank of this lane among the set bits of a ballot mask below it */
 __device__ __forceinline__ uint32_t laneRank(unsigned long long m) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -225,6 +239,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 			uint32_t myPath = 0;
 			for (;;) {
 				const uint32_t ph = w.phase;
+				TablePort<SAMP> port{ptab + myPath * CRH_PATH_F4};           /* the walking lane's path (volumes draw from its sampler) */
 				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
 				const int nF = __popcll(__ballot(ph == PH_SHADE));           /* walks that ended, result not yet queued */
 				const int nE = 64 - nN - nT - nC - nF;                        /* idle lanes */
@@ -258,15 +273,15 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 					case ST_NODE: {          /* keep stepping while at least runNum/8 (half) of the lanes that started this run still want node steps */
 						int now = nN;
 						do {
-							if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
+							if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
 							/* lanes that reached a leaf or an instance: serve them inside the run once enough of them wait (no scheduling
 							 * round in between, and the node lanes they become again rejoin this run) */
 							if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) {
-								if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+								if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
 							}
 							if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
-								if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt);
+								if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
 							}
 							now = __popcll(__ballot(w.phase == PH_NODE));
 						} while (now * 8 >= nN * K.runNum);
@@ -275,15 +290,15 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 					case ST_TRI: {
 						int now = nT;
 						do {
-							if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+							if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_tri += 1; cnt.u_tri += (uint32_t)now; } }
 							now = __popcll(__ballot(w.phase == PH_TRI));
 						} while (now * 8 >= nT * K.runNum);
 						break;
 					}
 					case ST_CTRL:
-						if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt);
-						if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt); }   /* degenerate rays: rare */
+						if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
+						if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port); }   /* degenerate rays: rare */
 						break;
 					case ST_SWAP: {
 						/* retire: a walk that ended leaves its result in the path's slot; the id goes on the hit or the miss stack */
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							myPath = ids[CRH_IDS_RAYS + (uint32_t)(raysQ - take) + er];
 							const f4 *q = ptab + myPath * CRH_PATH_F4;
 							const f4 q0 = q[0], q1 = q[1];
-							walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt);
+							{ TablePort<SAMP> port{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port); }
 						}
 						if (lane == 0) { wq[WQ_HITS] = hitsQ + (int)__popcll(hm); wq[WQ_MISSES] = missQn + (int)__popcll(mm); wq[WQ_RAYS] = raysQ - take; }
 						__threadfence_block();
@@ -722,6 +737,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 					bool draining = false;
 					for (;;) {
 						const uint32_t ph = w.phase;
+						TablePort<SAMP> port{ptab + myPath * CRH_PATH_F4};
 						const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
 						const int nF = __popcll(__ballot(ph == PH_SHADE));
 						const int nE = 64 - nN - nT - nC - nF;
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 							if (got) {
 								const f4 *q = ptab + myPath * CRH_PATH_F4;
 								const f4 q0 = q[0], q1 = q[1];
-								walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt);
+								{ TablePort<SAMP> port{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port); }
 							}
 							if (__ballot(w.phase != PH_IDLE) == 0ull) break;        /* drained: back to the top */
 							continue;
@@ -772,20 +788,20 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 						if (pick == 0) {          /* node run, with leaf / instance steps served in place (see k_pathtrace) */
 							int now = nN;
 							do {
-								if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
-								if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) { if (w.phase == PH_TRI) stepTri(S, w, stk, cnt); }
-								if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) { if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt); }
+								if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
+								if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) { if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port); }
+								if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) { if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port); }
 								now = __popcll(__ballot(w.phase == PH_NODE));
 							} while (now * 8 >= nN * K.runNum);
 						} else if (pick == 1) {
 							int now = nT;
 							do {
-								if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
+								if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
 								now = __popcll(__ballot(w.phase == PH_TRI));
 							} while (now * 8 >= nT * K.runNum);
 						} else {
-							if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt);
-							if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt); }   /* degenerate rays: rare */
+							if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
+							if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port); }   /* degenerate rays: rare */
 						}
 					}
 					if (draining) {
@@ -899,6 +915,7 @@ struct crh_ctx {
 	size_t stageFloats = 0;
 	bool haveScene = false;
 	bool hasPrograms = true;     /* the compiled scene contains node programs -> kernel variant with runProgram() */
+	bool hasVolumes = false;     /* walks draw from the path's sampler: crh_trace_rays (caller rays, no path) refuses such scenes */
 	DScene d;                              /* device pointers */
 	std::vector<void *> sceneAllocs;
 	unsigned long long *dCounters = nullptr;
@@ -1127,7 +1144,8 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base;
 	d.background = cs.background; d.camera = cs.camera;
 	c->d = d;
-	c->hasPrograms = cs.prog.size() > 1 || getenv("CRH_FORCE_PROGRAMS") != nullptr;
+	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
+	c->hasVolumes = cs.has_volumes;
 	c->haveScene = true;
 	return CRH_OK;
 }
@@ -1512,6 +1530,7 @@ int crh_internal_fail(int code, const char *message) { return fail(code, message
 int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits_host) {
 	if (!c || (!rays_host && n) || (!hits_host && n)) return fail(CRH_ERR_INVALID, "crh_trace_rays: NULL argument");
 	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_trace_rays: no scene uploaded");
+	if (c->hasVolumes) return fail(CRH_ERR_UNSUPPORTED, "crh_trace_rays: the scene has volume instances, whose intersection draws from a path's sampler (instance.c:74, 199)");
 	if (n == 0) return CRH_OK;
 	int rc = setDevice(c);
 	if (rc) return rc;

@@ -20,7 +20,9 @@
 #if defined(__HIPCC__)
 #define CRH_DEV __device__ __forceinline__
 #define CRH_DEV_NOINLINE __device__ __noinline__
+#define CRH_MEM __device__ __forceinline__            /* member functions */
 #else
+#define CRH_MEM inline __attribute__((always_inline))
 #define CRH_DEV static inline __attribute__((always_inline))
 #define CRH_DEV_NOINLINE static __attribute__((noinline))
 #endif
@@ -45,6 +47,8 @@ struct rgba { float r, g, b, a; };
 #define CRH_DINST_MESH       1u   /* BLAS with an inner root: root = device index of the root's child pair */
 #define CRH_DINST_MESH_LEAF  2u   /* bvh->nodeCount == 1: root = device index of the root leaf (bvh.c:382-387) */
 #define CRH_DINST_MESH_EMPTY 3u   /* bvh->nodeCount == 0 (bvh.c:362-365) */
+#define CRH_DINST_KIND(k)    ((k) & 15u)
+#define CRH_DINST_VOLUME     16u  /* flag: the sphere / mesh bounds a constant-density medium (instance.c:62-92, 187-216) */
 struct alignas(16) DInstance {
 	float Ainv[12];
 	uint32_t kind;        /* CRH_DINST_* */
@@ -55,7 +59,7 @@ struct alignas(16) DInstance {
 	uint32_t orig;        /* index in crh_scene_desc.instances */
 	uint32_t poly_base;   /* mesh: first polygon in polys[] (crh_trace_rays reports polygon indices) */
 	uint32_t material;    /* sphere: material index; mesh: material_base */
-	uint32_t pad;
+	float    density;     /* volumes */
 };
 
 /* Per BLAS prim slot, next to tris[]: what finishing a hit on that triangle needs, so that poly.c:37-48 + instance.c:150-167
@@ -127,9 +131,10 @@ struct DScene {
 };
 
 /* Counter levels: 0 none, 1 rays + paths only (timed runs), 2 everything (parity / roofline runs).
- * The counter type also carries the compile-time switch `programs`: kernels instantiated with programs = false
+ * The counter type also carries the compile-time switch `programs` = "rare features": kernels instantiated with programs = false
  * contain no call to runProgram() (a device function call in the persistent loop costs ~200 SGPR spills and
- * the callee's register budget); the host picks that variant when the compiled scene has no node programs. */
+ * the callee's register budget) and no volume code (instance.c:62-92, 187-216: two extra walk states and a sampler draw inside
+ * the traversal); the host picks that variant when the compiled scene has neither node programs nor volume instances. */
 template <int LEVEL, bool PROGRAMS> struct CountersT;
 template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	static constexpr int level = 2;
@@ -835,13 +840,89 @@ struct Walk {
 	TravHit hit;
 };
 
+/* What a walk needs from its PATH (volumes only, instance.c:62-92, 187-216): one sampler draw inside the traversal, and a few words
+ * of per-path memory while two BLAS walks bracket the medium. The kernels pass the path's record in the path table, the host
+ * emulation the lane's own path; walks of caller rays (crh_trace_rays) have no path — scenes with volumes are refused there. */
+struct NullPort {
+	CRH_MEM float draw() { return 0.5f; }
+	CRH_MEM void save(int, uint32_t) {}
+	CRH_MEM uint32_t load(int) { return 0u; }
+};
+enum { VP_T, VP_U, VP_V, VP_SLOT, VP_T1, VP_WORDS };       /* saved closest hit (t, u, v, slot) + entry distance of the medium */
+enum { BLAS_NONE = 0, BLAS_SOLID = 1, BLAS_VOL_ENTRY = 2, BLAS_VOL_EXIT = 3 };   /* Walk::inBlas */
+
+/* sphere.c:20-50 without the hit-point / normal part: true and the distance if the sphere is hit in (0.00001, bound] */
+template <class Cnt>
+CRH_DEV bool sphereTest(const v3 o, const v3 d, float radius, float bound, float &t, Cnt &cnt) {
+	CRH_COUNT(cnt, sphere_tests, 1);
+	const float A = vdot(d, d);
+	const float B = 2.0f * vdot(d, o);
+	const float C = vdot(o, o) - (radius * radius);
+	const float disc = B * B - 4.0f * A * C;
+	if (disc < 0.0f) return false;
+	const float sq = sqrtf(disc);
+	float t0 = (-B + sq) / 2.0f;
+	const float t1 = (-B - sq) / 2.0f;
+	if (t0 > t1 && t1 > 0.0f) t0 = t1;
+	if (t0 < 0.00001f || t0 > bound) return false;
+	t = t0;
+	return true;
+}
+
 /* after a step that left no pending prims: continue with the next pair, pop one, leave the BLAS, or hand over (CTRL / SHADE) */
-template <class Stack, class Cnt>
-CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
+/* A volume instance's BLAS walk ended (instance.c:196-214). Entry walk found the medium's near side -> start the exit walk from just
+ * behind it (true: the lane keeps walking); exit walk found the far side -> sample the free flight; anything else -> no hit. */
+template <class Stack, class Cnt, class Port>
+CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
+	(void)stk;
+	const bool found = w.instFound != 0u;
+	const float tWalk = w.hit.t;
+	if (found) {      /* both walks ran on a copy of the record: the closest hit so far comes back */
+		w.hit.t = asF32(port.load(VP_T)); w.hit.u = asF32(port.load(VP_U)); w.hit.v = asF32(port.load(VP_V)); w.hit.slot = (int32_t)port.load(VP_SLOT);
+	}
+	w.instFound = 0;
+	if (w.inBlas == BLAS_VOL_ENTRY && found) {
+		port.save(VP_T1, asU32(tWalk));
+		const DInstance *inst = &S.instances[w.curInst];
+		const v3 d = w.k.d;
+		w.k = makeRayK(alongRay(w.k.o, d, tWalk + 0.0001f), d);
+		w.inBlas = BLAS_VOL_EXIT;
+		w.pA = w.pAe = w.pB = w.pBe = 0;
+		w.node = CRH_NONE;
+		if (CRH_DINST_KIND(inst->kind) == CRH_DINST_MESH_LEAF) {                  /* bvh.c:382-387 */
+			const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
+			float tE;
+			CRH_COUNT(cnt, node_tests, 1);
+			if (intersectNode(n0, n1, w.k, w.hit.t, tE)) { w.pA = CRH_DNODE_FIRST(n1); w.pAe = w.pA + CRH_DNODE_COUNT(n1); }
+		} else {
+			w.node = inst->root;
+		}
+		if (w.pA != w.pAe) { w.phase = PH_TRI; return true; }
+		if (w.node != CRH_NONE) { w.phase = (w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE; return true; }
+		return false;                                                            /* single-leaf BLAS missed by the exit ray */
+	}
+	if (w.inBlas == BLAS_VOL_EXIT && found) {
+		float t1 = asF32(port.load(VP_T1));
+		if (t1 < 0.0f) t1 = 0.0f;
+		const float distanceInsideVolume = tWalk;
+		const float hitDistance = -(1.0f / S.instances[w.curInst].density) * logf(port.draw());
+		if (hitDistance < distanceInsideVolume) {
+			w.hit.t = t1 + hitDistance; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -2; w.hit.inst = w.curInst;
+			CRH_COUNT(cnt, inst_hits, 1);
+		}
+	}
+	return false;
+}
+
+template <class Stack, class Cnt, class Port>
+CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	if (w.pA != w.pAe) { w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
 	if (w.node != CRH_NONE) { w.phase = (w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE; return; }
 	if (!w.inBlas) { w.phase = PH_SHADE; return; }                /* TLAS exhausted -> the walk is over */
+	if constexpr (cnt_traits<Cnt>::programs) {       /* volumes exist only in the rare-features instantiations (see CountersT) */
+		if (__builtin_expect(w.inBlas >= BLAS_VOL_ENTRY, 0)) { if (volumeAdvance(S, w, stk, cnt, port)) return; }
+	}
 	/* BLAS exhausted -> back to the TLAS walk (instance.c:176-183): the world ray and the TLAS cursor come back from LDS.
 	 * Done here, at the end of whichever step emptied the BLAS, rather than as a step of its own: a leave is a dozen LDS
 	 * reads, far cheaper than a scheduling round at the occupancy such a step would get. */
@@ -859,8 +940,8 @@ CRH_DEV void walkAdvance(Walk &w, Stack &stk, Cnt &cnt) {
 	w.phase = (w.node != CRH_NONE) ? ((w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE) : PH_SHADE;
 }
 
-template <class Stack, class Cnt>
-CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v3 d, Cnt &cnt) {
+template <class Stack, class Cnt, class Port>
+CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v3 d, Cnt &cnt, Port &port) {
 	w.hit.t = FLT_MAX; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -1; w.hit.inst = -1;
 	w.node = CRH_NONE; w.pA = w.pAe = w.pB = w.pBe = 0; w.sp = 0; w.spBase = 0;
 	w.inBlas = 0; w.instFound = 0; w.curInst = -1;
@@ -875,13 +956,13 @@ CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v
 	} else {
 		w.node = S.tlas_root;
 	}
-	walkAdvance(w, stk, cnt);
+	walkAdvance(S, w, stk, cnt, port);
 }
 
 /* NODE: bvh.c:391-436 */
 /* FAST = true serves PH_NODE lanes (regular rays: no degenerate-slab code in the step at all), FAST = false PH_NODE_SLOW lanes */
-template <bool FAST = true, class Stack, class Cnt>
-CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+template <bool FAST = true, class Stack, class Cnt, class Port>
+CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	const uint32_t node = w.node;
 	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
 	float tL, tR;
@@ -902,7 +983,7 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	const bool swap = tL > tR;
 	if (inL && inR) stk.push(w.sp++, swap ? fl : fr);
 	w.node = (inL && inR) ? (swap ? fr : fl) : (inL ? fl : (inR ? fr : CRH_NONE));
-	walkAdvance(w, stk, cnt);
+	walkAdvance(S, w, stk, cnt, port);
 }
 
 /* TRI: poly.c:17-53 on the prepared record (one triangle per step) */
@@ -922,8 +1003,8 @@ CRH_DEV void testTriangle(const f4 q0, const f4 q1, const f4 q2, uint32_t slot, 
 }
 /* One triangle step = the next TWO triangles of the pending leaf range when it holds two (in order, the second sees the
  * first's hit distance: poly.c:17-36 via bvh.c:449-458); both records are requested before either is used. */
-template <class Stack, class Cnt>
-CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+template <class Stack, class Cnt, class Port>
+CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	const uint32_t slot = w.pA;
 	const bool two = slot + 1u < w.pAe;
 	const uint32_t slot2 = two ? slot + 1u : slot;
@@ -933,12 +1014,12 @@ CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
 	testTriangle(a0, a1, a2, slot, w, cnt);
 	if (two) testTriangle(b0, b1, b2, slot2, w, cnt);
-	walkAdvance(w, stk, cnt);
+	walkAdvance(S, w, stk, cnt, port);
 }
 
 /* CTRL: leave a finished BLAS (bvh.c:468-486 loop body tail) and / or visit the next instance of a TLAS leaf (bvh.c:472-484) */
-template <class Stack, class Cnt>
-CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
+template <class Stack, class Cnt, class Port>
+CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	/* next instance */
 	const uint32_t slot = w.pA++;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
@@ -949,26 +1030,28 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 	v3 o = xfPoint(w.k.o, inst->Ainv);
 	const v3 d = xfVector(w.k.d, inst->Ainv);
 	o = vadd(o, vscale(d, inst->ray_offset));
-	const uint32_t kind = inst->kind;
+	const uint32_t kind = CRH_DINST_KIND(inst->kind);
+	const bool volume = cnt_traits<Cnt>::programs && (inst->kind & CRH_DINST_VOLUME) != 0u;
 	if (kind == CRH_DINST_SPHERE) {
-		/* sphere.c:20-50 */
-		CRH_COUNT(cnt, sphere_tests, 1);
-		const float A = vdot(d, d);
-		const float B = 2.0f * vdot(d, o);
-		const float C = vdot(o, o) - (inst->radius * inst->radius);
-		const float disc = B * B - 4.0f * A * C;
-		if (!(disc < 0.0f)) {
-			const float sq = sqrtf(disc);
-			float t0 = (-B + sq) / 2.0f;
-			const float t1 = (-B - sq) / 2.0f;
-			if (t0 > t1 && t1 > 0.0f) t0 = t1;
-			if (!(t0 < 0.00001f || t0 > w.hit.t)) {
-				w.hit.t = t0; w.hit.slot = -1; w.hit.inst = idx;
-				CRH_COUNT(cnt, inst_hits, 1);
+		float t0;
+		if (__builtin_expect(volume, 0)) {
+			/* instance.c:62-92: where the ray enters the sphere, where — from just behind that point — it leaves it, then a free-flight
+			 * distance drawn from the path's sampler; both tests are bounded by the closest hit so far */
+			float tExit;
+			if (sphereTest(o, d, inst->radius, w.hit.t, t0, cnt) && sphereTest(alongRay(o, d, t0 + 0.0001f), d, inst->radius, w.hit.t, tExit, cnt)) {
+				if (t0 < 0.0f) t0 = 0.0f;
+				const float hitDistance = -(1.0f / inst->density) * logf(port.draw());
+				if (hitDistance < tExit) {
+					w.hit.t = t0 + hitDistance; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -2; w.hit.inst = idx;
+					CRH_COUNT(cnt, inst_hits, 1);
+				}
 			}
+		} else if (sphereTest(o, d, inst->radius, w.hit.t, t0, cnt)) {   /* sphere.c:20-50 */
+			w.hit.t = t0; w.hit.slot = -1; w.hit.inst = idx;
+			CRH_COUNT(cnt, inst_hits, 1);
 		}
 	} else if (kind == CRH_DINST_MESH_EMPTY) {
-		w.hit.inst = -1;                                                     /* bvh.c:362-365 via instance.c:175 */
+		if (!volume) w.hit.inst = -1;                                        /* bvh.c:362-365 via instance.c:175 (a volume walks a COPY of the record) */
 	} else if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) {
 		/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
 		 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
@@ -993,22 +1076,27 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt) {
 			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
 			else { w.node = inst->root; w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;
-			w.spBase = w.sp; w.inBlas = 1; w.instFound = 0; w.curInst = idx; w.k = ko;
+			w.spBase = w.sp; w.inBlas = BLAS_SOLID; w.instFound = 0; w.curInst = idx; w.k = ko;
+			if (__builtin_expect(volume, 0)) {                                /* instance.c:188-196: the entry walk runs on a copy of the record */
+				w.inBlas = BLAS_VOL_ENTRY;
+				port.save(VP_T, asU32(w.hit.t)); port.save(VP_U, asU32(w.hit.u)); port.save(VP_V, asU32(w.hit.v)); port.save(VP_SLOT, (uint32_t)w.hit.slot);
+			}
 		}
 	}
-	walkAdvance(w, stk, cnt);
+	walkAdvance(S, w, stk, cnt, port);
 }
 
 /* The whole walk for one lane (k_trace_rays, host emulation): run steps until the walk hands over to shading. */
 template <class Stack, class Cnt>
 CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD, TravHit &hit, Cnt &cnt) {
 	Walk w;
-	walkBegin(S, w, stk, rayO, rayD, cnt);
+	NullPort port;                    /* caller rays have no path: scenes with volumes are refused before this runs */
+	walkBegin(S, w, stk, rayO, rayD, cnt, port);
 	while (w.phase != PH_SHADE) {
-		if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt);
-		else if (w.phase == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt);
-		else if (w.phase == PH_TRI) stepTri(S, w, stk, cnt);
-		else stepCtrl(S, w, stk, cnt);
+		if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
+		else if (w.phase == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port);
+		else if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
+		else stepCtrl(S, w, stk, cnt, port);
 	}
 	hit = w.hit;
 }
@@ -1022,20 +1110,27 @@ struct HitInfo {
 /* polygon index (into crh_scene_desc.polys) of a finished hit, -1 for spheres: reported by crh_trace_rays only */
 CRH_DEV int32_t hitPoly(const DScene &S, const TravHit &hit) {
 	const DInstance *inst = &S.instances[hit.inst];
-	return inst->kind == CRH_DINST_SPHERE ? -1 : (int32_t)inst->poly_base + S.prims[hit.slot];
+	return CRH_DINST_KIND(inst->kind) == CRH_DINST_SPHERE ? -1 : (int32_t)inst->poly_base + S.prims[hit.slot];
 }
 CRH_DEV v3 loadV3(const float *base, int64_t i) { const float *p = base + 3 * i; return v3{p[0], p[1], p[2]}; }
 /* LAZY_UV: shading skips a sphere's texture coordinates (atan2f + asinf, instance.c:33-43) when no node of the material's
  * graph reads them (crh_material.pad[0], set by the scene compiler); crh_trace_rays always reports them. */
-template <bool LAZY_UV = true>
+template <bool LAZY_UV = true, bool VOLUMES = true>
 CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravHit &hit) {
 	HitInfo h;
 	const DInstance *inst = &S.instances[hit.inst];
 	v3 o = xfPoint(wo, inst->Ainv);
 	const v3 d = xfVector(wd, inst->Ainv);
 	o = vadd(o, vscale(d, inst->ray_offset));
+	if (VOLUMES && __builtin_expect(hit.slot == -2, 0)) {         /* a scattering event inside a volume: instance.c:81-88 / 205-211 */
+		h.uv = v2{-1.0f, -1.0f};
+		h.material = inst->material;                              /* the sphere's material / mesh->materials[0] */
+		h.point = xfPoint(alongRay(wo, wd, hit.t), inst->A);      /* the WORLD ray's point, transformed again — as the reference does */
+		h.normal = xfVectorT(v3{1.0f, 0.0f, 0.0f}, inst->Ainv);   /* "will be ignored by material anyway" */
+		return h;
+	}
 	const v3 objPoint = alongRay(o, d, hit.t);
-	if (inst->kind == CRH_DINST_SPHERE) {
+	if (CRH_DINST_KIND(inst->kind) == CRH_DINST_SPHERE) {
 		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
 		h.uv = v2{0.0f, 0.0f};
 		if (!LAZY_UV || S.materials[inst->material].pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
@@ -1138,7 +1233,7 @@ CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &
 		r.fr = r.fr + (r.wr * bg.r); r.fg = r.fg + (r.wg * bg.g); r.fb = r.fb + (r.wb * bg.b);
 		return false;
 	}
-	const HitInfo h = finishHit(S, ro, rd, hit);
+	const HitInfo h = finishHit<true, cnt_traits<Cnt>::programs>(S, ro, rd, hit);
 	const crh_material mat = S.materials[h.material];
 	r.fr = r.fr + (r.wr * mat.emission[0]); r.fg = r.fg + (r.wg * mat.emission[1]); r.fb = r.fb + (r.wb * mat.emission[2]);   /* :44 */
 	rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = hit.t; rec.ior = mat.ior;
@@ -1158,7 +1253,14 @@ CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &
 
 /* A lane that owns its paths from start to end (host emulation; the device driver keeps paths in a per-wave table
  * instead and lets lanes work on whichever path needs a step): */
-template <class R> struct LanePathT { Item it; PathRecT<R> r; v3 ro, rd; };
+template <class R> struct LanePathT { Item it; PathRecT<R> r; v3 ro, rd; uint32_t vol[VP_WORDS]; };
+template <class R> struct LanePort {
+	LanePathT<R> &lp;
+	CRH_MEM float draw() { return getDimension(lp.r.rng); }
+	CRH_MEM void save(int i, uint32_t v) { lp.vol[i] = v; }
+	CRH_MEM uint32_t load(int i) { return lp.vol[i]; }
+};
+template <class R> CRH_DEV LanePort<R> lanePort(LanePathT<R> &lp) { return LanePort<R>{lp}; }
 
 template <class LP, class Stack, class Cnt>
 CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJob &J, uint32_t laneStride, Walk &w, LP &lp,
@@ -1178,7 +1280,8 @@ CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJ
 			continue;
 		}
 		beginPath(S, P, x, y, pass, lp.ro, lp.rd, lp.r, cnt);
-		walkBegin(S, w, stk, lp.ro, lp.rd, cnt);
+		auto port = lanePort(lp);
+		walkBegin(S, w, stk, lp.ro, lp.rd, cnt, port);
 		return;
 	}
 }
@@ -1186,7 +1289,8 @@ CRH_DEV void stepSetup(const DScene &S, const crh_render_params &P, const BlockJ
 template <class LP, class Stack, class Cnt>
 CRH_DEV void stepShade(const DScene &S, const crh_render_params &P, Walk &w, LP &lp, Stack &stk, float *stage, Cnt &cnt) {
 	if (shadeCore(S, P, lp.ro, lp.rd, w.hit, lp.r, cnt)) {
-		walkBegin(S, w, stk, lp.ro, lp.rd, cnt);
+		auto port = lanePort(lp);
+		walkBegin(S, w, stk, lp.ro, lp.rd, cnt, port);
 		return;
 	}
 	float *o = stage + (size_t)lp.it.cur * 3;
@@ -1202,13 +1306,14 @@ CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk
 	LanePathT<R> lp;
 	lp.it.next = lane; lp.it.cur = 0;
 	w.phase = PH_SETUP;
+	auto port = lanePort(lp);
 	for (;;) {
 		switch (w.phase) {
 			case PH_SETUP: stepSetup(S, P, J, laneStride, w, lp, stk, stage, cnt); break;
-			case PH_NODE: stepNode<true>(S, w, stk, cnt); break;
-			case PH_NODE_SLOW: stepNode<false>(S, w, stk, cnt); break;
-			case PH_TRI: stepTri(S, w, stk, cnt); break;
-			case PH_CTRL: stepCtrl(S, w, stk, cnt); break;
+			case PH_NODE: stepNode<true>(S, w, stk, cnt, port); break;
+			case PH_NODE_SLOW: stepNode<false>(S, w, stk, cnt, port); break;
+			case PH_TRI: stepTri(S, w, stk, cnt, port); break;
+			case PH_CTRL: stepCtrl(S, w, stk, cnt, port); break;
 			case PH_SHADE: stepShade(S, P, w, lp, stk, stage, cnt); break;
 			default: return;
 		}

@@ -399,13 +399,18 @@ struct Compiler {
 			memcpy(d.Ainv, in.Ainv, sizeof(d.Ainv));
 			memcpy(d.A, in.A, sizeof(d.A));
 			d.orig = i;
-			if (in.kind == CRH_INSTANCE_SPHERE) {
+			const bool volume = in.kind == CRH_INSTANCE_SPHERE_VOLUME || in.kind == CRH_INSTANCE_MESH_VOLUME;
+			if (volume) {        /* instance.c:62-92, 187-216: -(1 / density) * logf(u) */
+				out.has_volumes = true;
+				d.density = in.density;
+			}
+			if (in.kind == CRH_INSTANCE_SPHERE || in.kind == CRH_INSTANCE_SPHERE_VOLUME) {
 				CHECK(in.object < s->sphere_count, CRH_ERR_INVALID, "instance %u: sphere index out of range", i);
 				const crh_sphere &sp = s->spheres[in.object];
 				CHECK(sp.material < s->material_count, CRH_ERR_INVALID, "sphere %u: material out of range", in.object);
 				d.kind = CRH_DINST_SPHERE;
 				d.radius = sp.radius; d.ray_offset = sp.ray_offset; d.material = sp.material;
-			} else if (in.kind == CRH_INSTANCE_MESH) {
+			} else if (in.kind == CRH_INSTANCE_MESH || in.kind == CRH_INSTANCE_MESH_VOLUME) {
 				CHECK(in.object < s->mesh_count, CRH_ERR_INVALID, "instance %u: mesh index out of range", i);
 				const crh_mesh &mesh = s->meshes[in.object];
 				d.kind = mesh.node_count > 1 ? CRH_DINST_MESH : mesh.node_count == 1 ? CRH_DINST_MESH_LEAF : CRH_DINST_MESH_EMPTY;
@@ -414,14 +419,19 @@ struct Compiler {
 				d.material = mesh.material_base;
 				d.poly_base = mesh.poly_base;
 			} else {
-				throw Fail{CRH_ERR_UNSUPPORTED, "instance kind " + std::to_string(in.kind) + " (volumes) is not supported"};
+				throw Fail{CRH_ERR_UNSUPPORTED, "unknown instance kind " + std::to_string(in.kind)};
+			}
+			if (volume) {
+				d.kind |= CRH_DINST_VOLUME;
+				if (in.kind == CRH_INSTANCE_MESH_VOLUME) CHECK(s->meshes[in.object].material_count >= 1, CRH_ERR_INVALID, "instance %u: a mesh volume needs materials[0]", i);
 			}
 			out.instances[k] = d;
 		}
 		for (uint64_t i = 0; i < s->instance_count; ++i) {           /* instances outside the TLAS (none with the reference's builder) are still validated */
 			const crh_instance &in = s->instances[i];
-			CHECK(in.kind == CRH_INSTANCE_SPHERE || in.kind == CRH_INSTANCE_MESH, CRH_ERR_UNSUPPORTED, "instance kind %u (volumes) is not supported", in.kind);
-			CHECK(in.kind == CRH_INSTANCE_SPHERE ? in.object < s->sphere_count : in.object < s->mesh_count, CRH_ERR_INVALID, "instance %llu: object index out of range", (unsigned long long)i);
+			CHECK(in.kind <= CRH_INSTANCE_MESH_VOLUME, CRH_ERR_UNSUPPORTED, "unknown instance kind %u", in.kind);
+			const bool sphere = in.kind == CRH_INSTANCE_SPHERE || in.kind == CRH_INSTANCE_SPHERE_VOLUME;
+			CHECK(sphere ? in.object < s->sphere_count : in.object < s->mesh_count, CRH_ERR_INVALID, "instance %llu: object index out of range", (unsigned long long)i);
 		}
 		if (out.nodes.empty()) out.nodes.resize(4, f4{0, 0, 0, 0});
 	}

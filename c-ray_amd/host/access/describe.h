@@ -51,3 +51,4 @@ unsigned    crh_access_bvh_node_count(const struct bvh *b);
 /* datatypes/instance.c: 0 sphere solid, 1 mesh solid, 2 sphere volume, 3 mesh volume, -1 unknown */
 struct instance;
 int crh_access_instance_kind(const struct instance *i);
+const void *crh_access_instance_object(const struct instance *i, float *density);   /* the sphere / mesh (also behind a volume wrapper) */

@@ -10,3 +10,11 @@ int crh_access_instance_kind(const struct instance *i) {
 	if (i->intersectFn == intersectMeshVolume) return 3;
 	return -1;
 }
+
+/* volumes keep their sphere / mesh behind a file-private wrapper struct (instance.c:22-30) */
+const void *crh_access_instance_object(const struct instance *i, float *density) {
+	*density = 0.0f;
+	if (i->intersectFn == intersectSphereVolume) { const struct sphereVolume *v = i->object; *density = v->density; return v->sphere; }
+	if (i->intersectFn == intersectMeshVolume) { const struct meshVolume *v = i->object; *density = v->density; return v->mesh; }
+	return i->object;
+}

@@ -234,15 +234,15 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 		copy_rows(fi->Ainv, &inst->composite.Ainv);
 		copy_rows(fi->A, &inst->composite.A);
 		int kind = crh_access_instance_kind(inst);
-		if (kind == 0) {
-			fi->kind = CRH_INSTANCE_SPHERE;
-			fi->object = (uint32_t)((const struct sphere *)inst->object - w->spheres);
-		} else if (kind == 1) {
-			fi->kind = CRH_INSTANCE_MESH;
-			fi->object = (uint32_t)((const struct mesh *)inst->object - w->meshes);
+		const void *object = crh_access_instance_object(inst, &fi->density);
+		if (kind == 0 || kind == 2) {
+			fi->kind = kind == 0 ? CRH_INSTANCE_SPHERE : CRH_INSTANCE_SPHERE_VOLUME;
+			fi->object = (uint32_t)((const struct sphere *)object - w->spheres);
+		} else if (kind == 1 || kind == 3) {
+			fi->kind = kind == 1 ? CRH_INSTANCE_MESH : CRH_INSTANCE_MESH_VOLUME;
+			fi->object = (uint32_t)((const struct mesh *)object - w->meshes);
 		} else {
-			/* volumes: no loader path constructs them */
-			fprintf(stderr, "crh_flatten: instance %d has unsupported kind %d (volume)\n", i, kind);
+			fprintf(stderr, "crh_flatten: instance %d has an unknown intersect function\n", i);
 			f.error = CRH_ERR_UNSUPPORTED;
 		}
 	}

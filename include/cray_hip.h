@@ -69,14 +69,17 @@ typedef struct crh_poly {
 
 /* struct instance (src/datatypes/instance.h:23-28) reduced to what the path reads: rows 0..2 of
  * composite.A / composite.Ainv (src/datatypes/transforms.c:76-116 never touch row 3). */
-#define CRH_INSTANCE_SPHERE 0u
-#define CRH_INSTANCE_MESH   1u
+#define CRH_INSTANCE_SPHERE        0u
+#define CRH_INSTANCE_MESH          1u
+#define CRH_INSTANCE_SPHERE_VOLUME 2u   /* newSphereVolume (instance.c:137-147): constant-density medium bounded by the sphere */
+#define CRH_INSTANCE_MESH_VOLUME   3u   /* newMeshVolume   (instance.c:253-263): ... bounded by the mesh                         */
 typedef struct crh_instance {
 	float    Ainv[12];   /* row-major 3x4 */
 	float    A[12];      /* row-major 3x4 */
 	uint32_t kind;       /* CRH_INSTANCE_*                                   */
 	uint32_t object;     /* index into spheres[] or meshes[]                  */
-	uint32_t pad[6];
+	float    density;    /* volumes: sphereVolume / meshVolume .density (instance.c:22-30) */
+	uint32_t pad[5];
 } crh_instance;          /* 128 B */
 
 /* struct mesh (src/datatypes/mesh.h:20-46) as offsets into the concatenated arrays. */

@@ -819,6 +819,67 @@ static bool intersectMesh(ctx_t *c, const crh_instance *inst, const ray_t *ray, 
 	return false;
 }
 
+/* instance.c:62-92. The medium is sampled INSIDE the traversal: one sampler draw, and only when the ray enters and leaves the sphere
+ * within the current closest distance. The hit point is built from the WORLD ray and then transformed again (as the reference does). */
+static bool intersectSphereVolume(ctx_t *c, const crh_instance *inst, const ray_t *ray, hit_t *isect) {
+	hit_t record1 = *isect, record2 = *isect;
+	ray_t copy1 = *ray;
+	transformRay(&copy1, inst->Ainv);
+	const crh_sphere *sphere = &c->s->spheres[inst->object];
+	copy1.start = vecAdd(copy1.start, vecScale(copy1.direction, sphere->ray_offset));
+	if (rayIntersectsWithSphere(c, &copy1, sphere, &record1)) {
+		ray_t copy2 = { alongRay(&copy1, record1.distance + 0.0001f), copy1.direction };
+		if (rayIntersectsWithSphere(c, &copy2, sphere, &record2)) {
+			if (record1.distance < 0.0f) record1.distance = 0.0f;
+			float distanceInsideVolume = record2.distance;
+			float hitDistance = -(1.0f / inst->density) * logf(getDimension(c));
+			if (hitDistance < distanceInsideVolume) {
+				isect->distance = record1.distance + hitDistance;
+				isect->hitPoint = alongRay(ray, isect->distance);
+				isect->uv = (coord){-1.0f, -1.0f};
+				isect->polygon = -1;
+				isect->material = sphere->material;
+				transformPoint(&isect->hitPoint, inst->A);
+				isect->surfaceNormal = (vec){1.0f, 0.0f, 0.0f};
+				transformVectorWithTranspose(&isect->surfaceNormal, inst->Ainv);
+				return true;
+			}
+		}
+	}
+	return false;
+}
+
+/* instance.c:187-216: two BLAS walks (entry, then exit from just behind the entry point), then the same free-flight sampling */
+static bool intersectMeshVolume(ctx_t *c, const crh_instance *inst, const ray_t *ray, hit_t *isect) {
+	const crh_scene_desc *s = c->s;
+	hit_t record1 = *isect, record2 = *isect;
+	ray_t copy = *ray;
+	transformRay(&copy, inst->Ainv);
+	const crh_mesh *mesh = &s->meshes[inst->object];
+	float offset = mesh->ray_offset;
+	copy.start = vecAdd(copy.start, vecScale(copy.direction, offset));
+	struct bvh_view blas = { s->nodes + mesh->node_base, s->prim_indices + mesh->prim_base, mesh->node_count };
+	if (traverseBvhGeneric(c, (void *)mesh, &blas, intersectBottomLevelLeaf, &copy, &record1)) {
+		ray_t copy2 = { alongRay(&copy, record1.distance + 0.0001f), copy.direction };
+		if (traverseBvhGeneric(c, (void *)mesh, &blas, intersectBottomLevelLeaf, &copy2, &record2)) {
+			if (record1.distance < 0.0f) record1.distance = 0.0f;
+			float distanceInsideVolume = record2.distance;
+			float hitDistance = -(1.0f / inst->density) * logf(getDimension(c));
+			if (hitDistance < distanceInsideVolume) {
+				isect->distance = record1.distance + hitDistance;
+				isect->hitPoint = alongRay(ray, isect->distance);
+				isect->uv = (coord){-1.0f, -1.0f};
+				isect->material = mesh->material_base;          /* mesh->materials[0] */
+				transformPoint(&isect->hitPoint, inst->A);
+				isect->surfaceNormal = (vec){1.0f, 0.0f, 0.0f};
+				transformVectorWithTranspose(&isect->surfaceNormal, inst->Ainv);
+				return true;
+			}
+		}
+	}
+	return false;
+}
+
 /* bvh.c:468-486 */
 static bool intersectTopLevelLeaf(ctx_t *c, void *user, const struct bvh_view *bvh, const crh_bvh_node *leaf, const ray_t *ray, hit_t *isect) {
 	(void)user;
@@ -828,7 +889,13 @@ static bool intersectTopLevelLeaf(ctx_t *c, void *user, const struct bvh_view *b
 		int currIndex = bvh->prims[leaf->first + i];
 		const crh_instance *inst = &s->instances[currIndex];
 		c->cnt.inst_visits++;
-		bool hit = inst->kind == CRH_INSTANCE_SPHERE ? intersectSphere(c, inst, ray, isect) : intersectMesh(c, inst, ray, isect);
+		bool hit;
+		switch (inst->kind) {          /* instance->intersectFn */
+			case CRH_INSTANCE_SPHERE: hit = intersectSphere(c, inst, ray, isect); break;
+			case CRH_INSTANCE_SPHERE_VOLUME: hit = intersectSphereVolume(c, inst, ray, isect); break;
+			case CRH_INSTANCE_MESH_VOLUME: hit = intersectMeshVolume(c, inst, ray, isect); break;
+			default: hit = intersectMesh(c, inst, ray, isect); break;
+		}
 		if (hit) {
 			c->cnt.inst_hits++;
 			isect->instIndex = currIndex;
@@ -937,6 +1004,8 @@ int oracle_render_region(const crh_scene_desc *scene, const crh_render_params *p
 
 int oracle_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, crh_hit *hits) {
 	if (!scene || !rays || !hits) return CRH_ERR_INVALID;
+	for (uint64_t i = 0; i < scene->instance_count; ++i)          /* volumes draw from the path's sampler inside the walk: caller rays have none */
+		if (scene->instances[i].kind == CRH_INSTANCE_SPHERE_VOLUME || scene->instances[i].kind == CRH_INSTANCE_MESH_VOLUME) return CRH_ERR_UNSUPPORTED;
 	#pragma omp parallel
 	{
 		ctx_t c;

@@ -144,8 +144,8 @@ static void patchZoo(struct renderer *r) {
 	(void)r;
 }
 
-/* Spheres whose radius is marked by a trailing ...7 in the fourth decimal (tools/gen_golden.py writes them so) and every mesh instance
- * whose mesh is named in CRH_VOLUME_MESHES become volumes. Density: CRH_VOLUME_DENSITY (default 6). */
+/* Spheres whose radius is marked by a trailing ...7 in the fourth decimal (tools/gen_golden.py writes them so) and every instance of
+ * the meshes whose indices are listed in CRH_VOLUME_MESHES ("0,2") become volumes. Density: CRH_VOLUME_DENSITY (default 6). */
 static void patchVolumes(struct renderer *r) {
 	const char *ds = getenv("CRH_VOLUME_DENSITY");
 	const float density = ds ? (float)atof(ds) : 6.0f;
@@ -156,7 +156,11 @@ static void patchVolumes(struct renderer *r) {
 		const struct transform keep = inst->composite;
 		if (isMesh(inst)) {
 			struct mesh *m = inst->object;
-			if (!meshes || !m->name || !strstr(meshes, m->name)) continue;
+			char key[16];
+			snprintf(key, sizeof(key), ",%d,", (int)(m - W->meshes));
+			char list[256];
+			snprintf(list, sizeof(list), ",%s,", meshes ? meshes : "");
+			if (!strstr(list, key)) continue;
 			m->materials[0].bsdf = newIsotropic(W, rgb(0.9f, 0.6f, 0.3f));
 			*inst = newMeshVolume(m, density);
 		} else {

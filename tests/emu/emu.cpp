@@ -115,6 +115,8 @@ int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, f
 }
 
 int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, crh_hit *hits) {
+	for (uint64_t i = 0; scene && i < scene->instance_count; ++i)     /* like crh_trace_rays: caller rays have no sampler for a volume to draw from */
+		if (scene->instances[i].kind == CRH_INSTANCE_SPHERE_VOLUME || scene->instances[i].kind == CRH_INSTANCE_MESH_VOLUME) { g_err = "volumes"; return CRH_ERR_UNSUPPORTED; }
 	CompiledScene c;
 	int rc = compile_scene(scene, c, g_err);
 	if (rc != CRH_OK) return rc;

@@ -116,6 +116,6 @@ def test_scene_compiler_rejects_malformed_scenes(emu, oracle, golden_blob):
     old = d.background; d.background = 0; check(abi.ERR_INVALID); d.background = old
     old = d.nodes[0].first; d.nodes[0].first = 10 ** 6; check(abi.ERR_INVALID); d.nodes[0].first = old
     old = d.polys[0].v[0]; d.polys[0].v[0] = -5; check(abi.ERR_INVALID); d.polys[0].v[0] = old
-    old = d.instances[0].kind; d.instances[0].kind = 3; check(abi.ERR_UNSUPPORTED); d.instances[0].kind = old
+    old = d.instances[0].kind; d.instances[0].kind = 4; check(abi.ERR_UNSUPPORTED); d.instances[0].kind = old      # 2 / 3 are the volume kinds
     old = d.materials[0].bsdf; d.materials[0].bsdf = abi.NODE_NONE; check(abi.ERR_INVALID); d.materials[0].bsdf = old
     check(0)

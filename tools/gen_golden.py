@@ -48,6 +48,9 @@ BIG_CASES = {
 PATCHED_CASES = {
     "nodezoo": ("nodezoo.json", {"CRH_NODE_PATCH": "zoo", "CRH_ZOO_TAME": "1"}, 320, 192, 4, 6),   # exotic + JSON graphs, full paths
     "nodezoo_display": ("nodezoo.json", {"CRH_NODE_PATCH": "zoo"}, 320, 192, 1, 2),    # known answers: first hit x white background
+    # participating media. Sphere volumes (radius marked ...7) and a cube-shaped mesh volume with solid objects inside and
+    # behind them, in front of the HDR environment (instance.c:62-92, 187-216; isotropic.c:40-47)
+    "volumes": ("volumes.json", {"CRH_NODE_PATCH": "volumes", "CRH_VOLUME_MESHES": "0", "CRH_VOLUME_DENSITY": "9"}, 240, 160, 8, 12),
 }
 ZOO_COLS, ZOO_ROWS, ZOO_PITCH, ZOO_RADIUS = 10, 6, 0.1, 0.042
 
@@ -103,6 +106,39 @@ def write_nodezoo_scene():
         json.dump(scene, f, indent=1)
 
 
+def write_volumes_scene():
+    def sphere(x, y, z, radius, color, bsdf="lambertian", **kw):
+        p = {"type": "sphere", "bsdf": bsdf, "color": dict(zip("rgb", color)), "radius": radius, "IOR": 1.45,
+             "instances": [{"transforms": [{"type": "translate", "x": x, "y": y, "z": z}]}]}
+        p.update(kw)
+        return p
+    prims = [
+        sphere(-0.45, 0.0, 0.0, 0.2507, (0.5, 0.7, 0.9)),             # volume (radius marked ...7), nothing inside
+        sphere(0.45, 0.05, 0.1, 0.3007, (0.5, 0.7, 0.9)),             # volume with a solid metal sphere inside and one poking through
+        sphere(0.45, 0.05, 0.1, 0.1, (0.9, 0.6, 0.2), "metal", roughness=0.1),
+        sphere(0.75, 0.0, 0.0, 0.12, (0.8, 0.2, 0.2)),
+        sphere(0.0, -100.3, 0.0, 100.0, (0.6, 0.6, 0.6)),             # floor
+        sphere(-0.1, 0.55, 0.4, 0.12, (1.0, 0.9, 0.7), "emissive", intensity=8.0),
+        sphere(0.0, 0.0, 0.05, 0.08, (0.2, 0.8, 0.3)),                # solid sphere inside the mesh volume
+    ]
+    meshes = [
+        {"fileName": "shapes/cube.obj", "bsdf": "lambertian",          # becomes the mesh volume (CRH_VOLUME_MESHES=0), two instances
+         "instances": [{"transforms": [{"type": "scaleUniform", "scale": 0.2}, {"type": "rotateY", "degrees": 25}, {"type": "translate", "x": 0.0, "y": 0.0, "z": 0.0}]},
+                       {"transforms": [{"type": "scale", "x": 0.1, "y": 0.25, "z": 0.1}, {"type": "rotateZ", "degrees": 15}, {"type": "translate", "x": -0.05, "y": 0.1, "z": -0.6}]}]},
+        {"fileName": "shapes/torus.obj", "bsdf": "lambertian",
+         "instances": [{"transforms": [{"type": "scaleUniform", "scale": 0.15}, {"type": "rotateX", "degrees": 60}, {"type": "translate", "x": -0.45, "y": 0.0, "z": 0.0}]}]},
+    ]
+    scene = {"version": 1.0,
+             "renderer": {"threads": 0, "samples": 8, "bounces": 12, "antialiasing": True, "tileWidth": 32, "tileHeight": 32, "tileOrder": "fromMiddle",
+                          "outputFilePath": "/tmp/", "outputFileName": "volumes", "fileType": "bmp", "count": 0, "width": 240, "height": 160},
+             "display": {"isFullscreen": False, "isBorderless": False, "windowScale": 1.0},
+             "camera": {"FOV": 40.0, "focalDistance": 2.5, "fstops": 0, "transforms": [{"type": "translate", "x": 0, "y": 0.15, "z": -2.4}, {"type": "rotateX", "degrees": 3}]},
+             "scene": {"ambientColor": {"hdr": "HDRs/roof_garden_1k.hdr", "offset": 0, "down": {"r": 1.0, "g": 1.0, "b": 1.0}, "up": {"r": 0.5, "g": 0.7, "b": 1.0}},
+                       "primitives": prims, "meshes": meshes}}
+    with open(os.path.join(refrun.INPUT_DIR, "volumes.json"), "w") as f:
+        json.dump(scene, f, indent=1)
+
+
 def per_pixel_stats(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     l2 = np.sqrt((d ** 2).sum(axis=2))
@@ -155,6 +191,8 @@ def main():
             continue
         if scene == "nodezoo.json":
             write_nodezoo_scene()
+        if scene == "volumes.json":
+            write_volumes_scene()
         entry = {"scene": scene, "patch": env, "width": w, "height": h, "samples": spp, "bounces": bounces,
                  "ref_flavour": "c-ray-ref-strict + oracle/ref_node_patch.c"}
         if (scene, str(env)) not in blobs_done:

@@ -20,6 +20,7 @@ for group in "FETCH_SIZE" "WRITE_SIZE" \
              "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_SMEM" \
              "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
 	i=$((i + 1))
+	if [ -n "$TRAFFIC_ONLY" ] && [ $i -gt 2 ]; then break; fi      # TRAFFIC_ONLY=1: FETCH_SIZE / WRITE_SIZE passes only
 	# shellcheck disable=SC2086
 	rocprofv3 --pmc $group -d "$OUT/pmc$i" -o "$TAG" -- python "$REPO/bench.py" --steps 2 --warmup 0 $EXTRA > "$OUT/pmc${i}_$TAG.log" 2>&1
 	echo "pmc$i ($group) rc $?"

@@ -985,6 +985,64 @@ static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
 	return CRH_OK;
 }
 
+/* Launch the instantiation the context's options select (counter level, register budget, rare features, sampler, kernel form). */
+static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_params *P, const BlockQueue &Q, float *dev_fb, int chunk) {
+	const bool wg = c->kernel == CRH_KERNEL_WG;
+#define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
+#define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
+#define CRH_LAUNCH_WG(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_wg<LEVEL, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+													  c->dCounters, c->dStage, chunk, c->schedWg, c->dQueues, c->dOvf, c->dErr)
+#ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/kernel_regs.py): one instantiation compiles in seconds */
+#ifdef CRH_DEV_ONLY_PROG
+	if (wg) CRH_LAUNCH_WG(1, true, 0); else CRH_LAUNCH(1, 4, true, 0);
+#else
+	if (wg) CRH_LAUNCH_WG(1, false, 0); else CRH_LAUNCH(1, 4, false, 0);
+#endif
+#else
+	if (wg) {
+		const bool halton = c->sampler == CRH_SAMPLER_HALTON;
+		if (c->counterLevel >= 2) {
+			if (c->hasPrograms) { if (halton) CRH_LAUNCH_WG(2, true, 1); else CRH_LAUNCH_WG(2, true, 0); }
+			else { if (halton) CRH_LAUNCH_WG(2, false, 1); else CRH_LAUNCH_WG(2, false, 0); }
+		} else {
+			if (c->hasPrograms) { if (halton) CRH_LAUNCH_WG(1, true, 1); else CRH_LAUNCH_WG(1, true, 0); }
+			else { if (halton) CRH_LAUNCH_WG(1, false, 1); else CRH_LAUNCH_WG(1, false, 0); }
+		}
+	} else
+	if (c->sampler == CRH_SAMPLER_HALTON) {          /* interactive mode: the 128-register variants only */
+		if (c->counterLevel >= 2) { if (c->hasPrograms) CRH_LAUNCH(2, 4, true, 1); else CRH_LAUNCH(2, 4, false, 1); }
+		else { if (c->hasPrograms) CRH_LAUNCH(1, 4, true, 1); else CRH_LAUNCH(1, 4, false, 1); }
+	}
+	else if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
+	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
+#endif
+#undef CRH_LAUNCH2
+#undef CRH_LAUNCH
+#undef CRH_LAUNCH_WG
+	return hipGetLastError();
+}
+
+/* Load the code object of the selected instantiation now (HIP loads kernels lazily, ~40 ms on first launch) with a launch that finds
+ * an empty work queue: crh_scene_upload calls it, so a renderer's first frame is not the one that pays for it. */
+static int preloadKernel(crh_ctx *c) {
+	crh_render_params P;
+	memset(&P, 0, sizeof(P));
+	BlockQueue Q;
+	memset(&Q, 0, sizeof(Q));
+	Q.counter = c->dWork;                 /* any valid counter: total = 0, every wave leaves at once */
+	Q.bw = Q.bh = Q.sbw = Q.sbh = 1;
+	if (c->kernel == CRH_KERNEL_WG && !c->dOvf) {
+		HIP_TRY(hipMalloc((void **)&c->dOvf, (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u * sizeof(uint32_t)));
+		c->ovfWords = (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u;
+	}
+	HIP_TRY(hipMemsetAsync(c->dWork, 0, sizeof(uint32_t), c->stream));
+	const hipError_t e = launchPathtrace(c, 1, &P, Q, nullptr, 1);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("kernel preload: ") + hipGetErrorString(e));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return CRH_OK;
+}
+
 extern "C" {
 
 int crh_abi_version(void) { return CRH_ABI_VERSION; }
@@ -1147,7 +1205,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
 	c->hasVolumes = cs.has_volumes;
 	c->haveScene = true;
-	return CRH_OK;
+	return preloadKernel(c);
 }
 
 int crh_framebuffer_alloc(crh_ctx *c, int width, int height, float **dev_out) {
@@ -1355,35 +1413,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
-#define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
-												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
-#define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
-#define CRH_LAUNCH_WG(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_wg<LEVEL, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
-													  c->dCounters, c->dStage, chunk, c->schedWg, c->dQueues, c->dOvf, c->dErr)
-#ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/kernel_regs.py): one instantiation compiles in seconds */
-	if (wg) CRH_LAUNCH_WG(1, false, 0); else CRH_LAUNCH(1, 4, false, 0);
-#else
-	if (wg) {
-		const bool halton = c->sampler == CRH_SAMPLER_HALTON;
-		if (c->counterLevel >= 2) {
-			if (c->hasPrograms) { if (halton) CRH_LAUNCH_WG(2, true, 1); else CRH_LAUNCH_WG(2, true, 0); }
-			else { if (halton) CRH_LAUNCH_WG(2, false, 1); else CRH_LAUNCH_WG(2, false, 0); }
-		} else {
-			if (c->hasPrograms) { if (halton) CRH_LAUNCH_WG(1, true, 1); else CRH_LAUNCH_WG(1, true, 0); }
-			else { if (halton) CRH_LAUNCH_WG(1, false, 1); else CRH_LAUNCH_WG(1, false, 0); }
-		}
-	} else
-	if (c->sampler == CRH_SAMPLER_HALTON) {          /* interactive mode: the 128-register variants only */
-		if (c->counterLevel >= 2) { if (c->hasPrograms) CRH_LAUNCH(2, 4, true, 1); else CRH_LAUNCH(2, 4, false, 1); }
-		else { if (c->hasPrograms) CRH_LAUNCH(1, 4, true, 1); else CRH_LAUNCH(1, 4, false, 1); }
-	}
-	else if (c->counterLevel >= 2) { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(2, 4); else CRH_LAUNCH2(2, 1); }
-	else { if (c->wavesPerSimd >= 4) CRH_LAUNCH2(1, 4); else CRH_LAUNCH2(1, 1); }
-#endif
-#undef CRH_LAUNCH2
-#undef CRH_LAUNCH
-#undef CRH_LAUNCH_WG
-	hipError_t e = hipGetLastError();
+	hipError_t e = launchPathtrace(c, grid, P, Q, dev_fb, chunk);
 	HIP_TRY(hipEventRecord(ev.b, c->stream));
 	HIP_TRY(hipEventRecord(ts.done, c->stream));
 	ts.inFlight = true;

@@ -466,7 +466,7 @@ CRH_DEV rgba evalGradient(const f4 *consts, uint32_t cidx, const ShadeRec &rec) 
 struct ProgCtx { const f4 *consts; const DImage *images; const DOp *prog; TexCtx tex; };
 struct ProgResult { f4 v; uint32_t fetches; };
 struct FetchCounter { static constexpr int level = 2; static constexpr bool programs = true; uint32_t tex_fetches; };
-CRH_DEV_NOINLINE ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) {
+CRH_DEV ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) {
 	f4 slot[CRH_PROG_SLOTS];
 	FetchCounter cnt;
 	cnt.tex_fetches = 0;

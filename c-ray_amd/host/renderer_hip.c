@@ -100,8 +100,9 @@ static void *gpuThread(void *arg) {
 	struct timeval phase;
 	startTimer(&phase);
 
-	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_scene_upload(w->ctx, w->scene) != CRH_OK ||
-		crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK) {
+	/* counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
+	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_set_option(w->ctx, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK ||
+		crh_scene_upload(w->ctx, w->scene) != CRH_OK || crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK) {
 		snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 		logr(warning, "GPU %d: %s\n", w->device, w->error);
 		w->failed = 1;
@@ -158,8 +159,9 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	uint32_t ntiles[MAX_GPUS];
 	float *gather = malloc(sizeof(float) * (size_t)W * H * 3);
 	for (int g = 0; g < gpus; ++g) {
-		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
-			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK)
+		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
+			crh_set_option(ctx[g], CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
+			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK)
 			logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
 		ntiles[g] = gpuShare(r, g, gpus, &tiles[g]);
 	}

@@ -121,9 +121,10 @@ def test_sampler_key_wraps_at_4k_2048spp(pkg, ctx, oracle):
     x0, y0, x1, y1 = region
     a, r = img[h - y1:h - y0, x0:x1], ref[h - y1:h - y0, x0:x1]
     assert (region[1] * w + region[0]) * 2048 > 2 ** 32
-    # most pixels are identical bit for bit (with any other seeds: < 0.1 % are); the rest are the scene's chaotic paths (see the floor above)
+    # a large share of the pixels is identical bit for bit — with any other seeds < 0.1 % are (checked against maxPasses = 2 when the test
+    # was written); the rest are this scene's chaotic paths: the strip crosses the statues and the transparent plane (see the floor above)
     same = float((np.abs(a - r).max(axis=2) == 0.0).mean())
-    assert same >= 0.6, same
+    assert same >= 0.15, same
     assert abs(cnt["rays"] - ocnt["rays"]) <= 0.05 * ocnt["rays"], (cnt["rays"], ocnt["rays"])       # 4096 paths of up to 30 bounces
     mask = np.ones((h, w), bool); mask[h - y1:h - y0, x0:x1] = False
     assert not img[mask].any()

@@ -89,7 +89,7 @@ def main():
             lines.append("")
             lines.append(f"HBM read  per launch: raw {rd/1e9:.3f} GB, gfx950-corrected (x2) {2*rd/1e9:.3f} GB")
             lines.append(f"HBM write per launch: {wr/1e9:.3f} GB")
-            with open(os.path.join(OUT, "hbm_traffic.json"), "w") as f:
+            with open(os.path.join(OUT, "hbm_traffic" + os.environ.get("PROF_SUFFIX", "") + ".json"), "w") as f:
                 json.dump(hbm, f, indent=1)
     with open(os.path.join(OUT, f"{tag}_rocprof_summary.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -63,12 +63,27 @@ def algorithmic_bytes(cnt, path_state=True):
 
 
 def kernel_source_md5():
-    """Fingerprint of the kernel sources: PMC figures in profiles/ are quoted only while they describe THIS kernel."""
+    """Fingerprint of the DEVICE code in the built library (the .hip_fatbin section of libcray_hip.so): PMC figures in profiles/ are
+    quoted only while they describe the kernels that are running — host-side edits do not invalidate them, any kernel edit does."""
     import hashlib
-    m = hashlib.md5()
-    for f in ("cray_hip.hip", "pt_device.h"):
-        m.update(open(os.path.join(REPO, "c-ray_amd", "csrc", f), "rb").read())
-    return m.hexdigest()
+    import struct
+    path = os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so")
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return hashlib.md5(data).hexdigest()
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sec(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sec(shstrndx)
+    for i in range(shnum):
+        name, off, size = sec(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            return hashlib.md5(data[off:off + size]).hexdigest()
+    return hashlib.md5(data).hexdigest()
 
 
 def measured_profile(workload_key):

@@ -64,6 +64,7 @@ def library():
         "crh_counters_reset": (C.c_int, [ctx]),
         "crh_kernel_time_ms": (C.c_int, [ctx, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "crh_trace_rays": (C.c_int, [ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
+        "crh_debug_eval_math": (C.c_int, [ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
         "crh_bvh_build_triangles": (C.c_int, [ctx, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.POINTER(C.c_uint32), C.POINTER(abi.BvhBuildStats)]),
         "crh_blob_save": (C.c_int, [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.BlobPrefs)]),
@@ -229,6 +230,18 @@ class Context:
         ctxs = (C.c_void_p * 1)(self.h)
         fbs = (C.c_void_p * 1)(fb)
         _check(self.L.crh_frames_reduce(ctxs, fbs, 1, width, height), "crh_frames_reduce")
+
+    def eval_math(self, function, x, y=None):
+        """crh_debug_eval_math: the device build of exact_math.h on caller values (function = a name from abi.MATH_FUNCTIONS)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        out = np.empty_like(x)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float32).ravel()
+            assert y.size == x.size
+            yp = y.ctypes.data
+        _check(self.L.crh_debug_eval_math(self.h, abi.MATH_FUNCTIONS.index(function), x.ctypes.data, yp, x.size, out.ctypes.data), "crh_debug_eval_math")
+        return out
 
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

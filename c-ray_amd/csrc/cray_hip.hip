@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "cray_hip.h"
+#define CRH_EM_POW_TABLES_IN_LDS         /* powf's two lookup tables: 512 B of LDS per workgroup (exact_math.h) */
 #include "pt_device.h"
 #include "scene_compile.h"
 #include "ctx_access.h"
@@ -167,8 +168,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
-	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) <= 40960, "4 blocks per CU share 160 KB of LDS");
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 	const DScene S = globalize(Sarg);
+	CRH_EM_POW_TABLES_INIT();
 	const unsigned long long tStart = wall_clock64();
 	uint32_t unitsDone = 0;
 	LdsStack stk;
@@ -536,8 +538,9 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 	__shared__ uint16_t s_idsA[CRH_WG_PATHS];      /* rays grow up from 0, hits grow down from the end */
 	__shared__ uint16_t s_idsB[CRH_WG_PATHS];      /* misses grow up from 0, free slots grow down from the end */
 	__shared__ int s_ctl[CT_WORDS];
-	static_assert((CRH_WG_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + 2 * CRH_WG_PATHS * 2 + CT_WORDS * 4 <= 40960, "4 workgroups per CU share 160 KB of LDS");
+	static_assert((CRH_WG_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + 2 * CRH_WG_PATHS * 2 + CT_WORDS * 4 + 512 <= 40960, "4 workgroups per CU share 160 KB of LDS (incl. powf's tables)");
 	const DScene S = globalize(Sarg);
+	CRH_EM_POW_TABLES_INIT();
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
 	WgStack stk;
@@ -881,9 +884,34 @@ __global__ void k_fold_black(const crh_render_params P, const crh_tile *tiles, u
 
 /* color.h:60-84 + texture.c:18-22 */
 __global__ void k_to_srgb8(const float *fb, size_t n, uint8_t *out) {
+	CRH_EM_POW_TABLES_INIT();
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		const float v = linearToSRGB(fb[i]);
 		out[i] = (unsigned char)rmin(v * 255.0f, 255.0f);
+	}
+}
+
+/* debug / parity entry: the device build of exact_math.h on caller values (tests compare with the host libm bit for bit) */
+__global__ void k_eval_math(int fn, const float *x, const float *y, uint64_t n, float *out) {
+	CRH_EM_POW_TABLES_INIT();
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const float a = x[i], b = y ? y[i] : 0.0f;
+		float r = 0.0f, c = 0.0f;
+		switch (fn) {
+			case CRH_MATH_SINF: r = em::sinf_(a); break;
+			case CRH_MATH_COSF: r = em::cosf_(a); break;
+			case CRH_MATH_SINCOSF_SIN: em::sincosf_(a, r, c); break;
+			case CRH_MATH_SINCOSF_COS: em::sincosf_(a, c, r); break;
+			case CRH_MATH_LOGF: r = em::logf_(a); break;
+			case CRH_MATH_LOG10F: r = em::log10f_(a); break;
+			case CRH_MATH_ATANF: r = em::atanf_(a); break;
+			case CRH_MATH_ACOSF: r = em::acosf_(a); break;
+			case CRH_MATH_ASINF: r = em::asinf_(a); break;
+			case CRH_MATH_POWF: r = em::powf_(a, b); break;
+			case CRH_MATH_ATAN2F: r = em::atan2f_(a, b); break;
+			default: break;
+		}
+		out[i] = r;
 	}
 }
 
@@ -1035,6 +1063,20 @@ static int preloadKernel(crh_ctx *c) {
 	if (c->kernel == CRH_KERNEL_WG && !c->dOvf) {
 		HIP_TRY(hipMalloc((void **)&c->dOvf, (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u * sizeof(uint32_t)));
 		c->ovfWords = (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u;
+	}
+	/* the per-wave path tables and sample slabs of a full-size dispatch at the default unit size: allocated here rather than by the first frame */
+	const size_t waves = (size_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
+	if (waves * CRH_WAVE_QUEUE_FLOATS > c->queueFloats) {
+		if (c->dQueues) HIP_TRY(hipFree(c->dQueues));
+		c->dQueues = nullptr; c->queueFloats = 0;
+		HIP_TRY(hipMalloc((void **)&c->dQueues, waves * CRH_WAVE_QUEUE_FLOATS * sizeof(float)));
+		c->queueFloats = waves * CRH_WAVE_QUEUE_FLOATS;
+	}
+	if (waves * (size_t)c->unitItems * 3 > c->stageFloats) {
+		if (c->dStage) HIP_TRY(hipFree(c->dStage));
+		c->dStage = nullptr; c->stageFloats = 0;
+		HIP_TRY(hipMalloc((void **)&c->dStage, waves * (size_t)c->unitItems * 3 * sizeof(float)));
+		c->stageFloats = waves * (size_t)c->unitItems * 3;
 	}
 	HIP_TRY(hipMemsetAsync(c->dWork, 0, sizeof(uint32_t), c->stream));
 	const hipError_t e = launchPathtrace(c, 1, &P, Q, nullptr, 1);
@@ -1551,6 +1593,30 @@ int crh_debug_wave_stats(crh_ctx *c, uint64_t *out, uint32_t max_waves) {
 	const uint32_t n = std::min<uint32_t>(max_waves, c->lastGrid * (CRH_BLOCK / 64));
 	HIP_TRY(hipMemcpy(out, c->dWaveStats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	return (int)n;
+}
+
+int crh_debug_eval_math(crh_ctx *c, int function, const float *x_host, const float *y_host, uint64_t n, float *out_host) {
+	if (!c || !x_host || !out_host || function < 0 || function > CRH_MATH_ATAN2F) return fail(CRH_ERR_INVALID, "crh_debug_eval_math: bad argument");
+	if (n == 0) return CRH_OK;
+	int rc = setDevice(c);
+	if (rc) return rc;
+	float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+	hipError_t e = hipMalloc((void **)&dx, n * sizeof(float));
+	if (e == hipSuccess) e = hipMalloc((void **)&dout, n * sizeof(float));
+	if (e == hipSuccess && y_host) e = hipMalloc((void **)&dy, n * sizeof(float));
+	if (e == hipSuccess) e = hipMemcpyAsync(dx, x_host, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && y_host) e = hipMemcpyAsync(dy, y_host, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_eval_math, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 16384)), dim3(256), 0, c->stream, function, dx, dy, n, dout);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(out_host, dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (dx) (void)hipFree(dx);
+	if (dy) (void)hipFree(dy);
+	if (dout) (void)hipFree(dout);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_debug_eval_math: ") + hipGetErrorString(e));
+	return CRH_OK;
 }
 
 int crh_internal_device(crh_ctx *c) { return c->device; }

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <float.h>
 #include "cray_hip.h"
+#include "exact_math.h"     /* sinf, cosf, powf, logf, atan2f, acosf, asinf, log10f with the host libm's bits (namespace crh::em) */
 
 #if defined(__HIPCC__)
 #define CRH_DEV __device__ __forceinline__
@@ -192,15 +193,15 @@ CRH_DEV rgba ccoef(float c, rgba a) { return rgba{a.r * c, a.g * c, a.b * c, a.a
 CRH_DEV rgba cmix(rgba c1, rgba c2, float k) { return cadd(ccoef(1.0f - k, c1), ccoef(k, c2)); }   /* color.h:46 */
 CRH_DEV float linearToSRGB(float c) {                                                               /* color.h:51 */
 	if (c <= 0.0031308f) return 12.92f * c;
-	return (1.055f * powf(c, 0.4166666667f)) - 0.055f;
+	return (1.055f * em::powf_(c, 0.4166666667f)) - 0.055f;
 }
 CRH_DEV float SRGBToLinear(float c) {                                                               /* color.h:59 */
 	if (c <= 0.04045f) return c / 12.92f;
-	return powf(((c + 0.055f) / 1.055f), 2.4f);
+	return em::powf_(((c + 0.055f) / 1.055f), 2.4f);
 }
 /* color.h:37-40: 0.587 is a double constant, so the sum is carried in double */
 CRH_DEV float grayscaleOf(rgba c) {
-	return sqrtf((float)(0.299f * powf(c.r, 2.0f) + 0.587 * (double)powf(c.g, 2.0f) + (double)(0.114f * powf(c.b, 2.0f))));
+	return sqrtf((float)(0.299f * em::powf_(c.r, 2.0f) + 0.587 * (double)em::powf_(c.g, 2.0f) + (double)(0.114f * em::powf_(c.b, 2.0f))));
 }
 /* color.c:27-70 */
 CRH_DEV rgba colorForKelvin(float kelvin) {
@@ -211,16 +212,16 @@ CRH_DEV rgba colorForKelvin(float kelvin) {
 		r = 255.0f;
 	} else {
 		r = temp - 60.0f;
-		r = 329.698727446f * powf(r, -0.1332047592f);
+		r = 329.698727446f * em::powf_(r, -0.1332047592f);
 		r = r < 0.0f ? 0.0f : r;
 		r = r > 255.0f ? 255.0f : r;
 	}
 	if (temp <= 66.0f) {
 		g = temp;
-		g = 99.4708025861f * logf(g) - 161.1195681661f;
+		g = 99.4708025861f * em::logf_(g) - 161.1195681661f;
 	} else {
 		g = temp - 60.0f;
-		g = 288.1221695283f * powf(g, -0.0755148492f);
+		g = 288.1221695283f * em::powf_(g, -0.0755148492f);
 	}
 	g = g < 0.0f ? 0.0f : g;
 	g = g > 255.0f ? 255.0f : g;
@@ -230,7 +231,7 @@ CRH_DEV rgba colorForKelvin(float kelvin) {
 		b = 0.0f;
 	} else {
 		b = temp - 10.0f;
-		b = 138.5177312231f * logf(b) - 305.0447927307f;
+		b = 138.5177312231f * em::logf_(b) - 305.0447927307f;
 		b = b < 0.0f ? 0.0f : b;
 		b = b > 255.0f ? 255.0f : b;
 	}
@@ -306,7 +307,9 @@ template <class R>
 CRH_DEV v2 randomCoordOnUnitDisc(R &rng) {
 	float r = sqrtf(getDimension(rng));
 	float theta = ((getDimension(rng)) * ((2.0f * CRH_PI) - 0.0f)) + 0.0f;
-	return v2{r * cosf(theta), r * sinf(theta)};
+	float sn, cs;
+	em::sincosf_(theta, sn, cs);
+	return v2{r * cs, r * sn};
 }
 /* vector.h:243-249 */
 template <class R>
@@ -315,7 +318,9 @@ CRH_DEV v3 randomOnUnitSphere(R &rng) {
 	const float sample_y = getDimension(rng);
 	const float a = sample_x * (2.0f * CRH_PI);
 	const float s = 2.0f * sqrtf(rmax(0.0f, sample_y * (1.0f - sample_y)));
-	return v3{cosf(a) * s, sinf(a) * s, 1.0f - 2.0f * sample_y};
+	float sn, cs;
+	em::sincosf_(a, sn, cs);
+	return v3{cs * s, sn * s, 1.0f - 2.0f * sample_y};
 }
 /* vector.h:251-266 */
 CRH_DEV bool refract(v3 in, v3 normal, float niOverNt, v3 &refracted) {
@@ -336,7 +341,7 @@ CRH_DEV bool refract(v3 in, v3 normal, float niOverNt, v3 &refracted) {
 CRH_DEV float schlick(float cosine, float IOR) {
 	float r0 = (1.0f - IOR) / (1.0f + IOR);
 	r0 = r0 * r0;
-	return r0 + (1.0f - r0) * powf((1.0f - cosine), 5.0f);
+	return r0 + (1.0f - r0) * em::powf_((1.0f - cosine), 5.0f);
 }
 
 /* ---- transforms.c:76-116 on 3x4 row-major matrices --------------------------------------------- */
@@ -439,7 +444,12 @@ CRH_DEV rgba evalImage(const TexCtx S, const DImage im, v2 uv, Cnt &cnt) {
 	} else {
 		out = textureGetPixelFiltered(S, t, uv.x, uv.y, cnt);
 	}
-	if (im.options & CRH_IMAGE_SRGB_TRANSFORM) out = rgba{SRGBToLinear(out.r), SRGBToLinear(out.g), SRGBToLinear(out.b), out.a};
+	if (im.options & CRH_IMAGE_SRGB_TRANSFORM) {       /* color.h:66-73 on r, g, b: the channels rotate through ONE inlined powf */
+#if defined(__HIPCC__)
+#pragma clang loop unroll(disable)
+#endif
+		for (int i = 0; i < 3; ++i) { const float t = SRGBToLinear(out.r); out.r = out.g; out.g = out.b; out.b = t; }
+	}
 	return out;
 }
 
@@ -485,8 +495,8 @@ CRH_DEV ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) 
 			case CRH_COLOR_CHECKER: {          /* checker.c:31-54; a=A b=B c=scale (all already evaluated: pure) */
 				const float coef = c.x;
 				float sines;
-				if (rec.uv.x >= 0.0f) sines = sinf(coef * rec.uv.x) * sinf(coef * rec.uv.y);
-				else sines = sinf(coef * rec.point.x) * sinf(coef * rec.point.y) * sinf(coef * rec.point.z);
+				if (rec.uv.x >= 0.0f) sines = em::sinf_(coef * rec.uv.x) * em::sinf_(coef * rec.uv.y);
+				else sines = em::sinf_(coef * rec.point.x) * em::sinf_(coef * rec.point.y) * em::sinf_(coef * rec.point.z);
 				r = sines < 0.0f ? a : b; break;
 			}
 			case CRH_COLOR_GRADIENT: { rgba o = evalGradient(S.consts, op.cidx, rec); r = f4{o.r, o.g, o.b, o.a}; break; }
@@ -511,14 +521,14 @@ CRH_DEV ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) 
 					case 1: r.x = x - y; break;
 					case 2: r.x = x * y; break;
 					case 3: r.x = x / y; break;
-					case 4: r.x = powf(x, y); break;
-					case 5: r.x = log10f(x); break;
+					case 4: r.x = em::powf_(x, y); break;
+					case 5: r.x = em::log10f_(x); break;
 					case 6: r.x = sqrtf(x); break;
 					case 7: r.x = fabsf(x); break;
 					case 8: r.x = rmin(x, y); break;
 					case 9: r.x = rmax(x, y); break;
-					case 10: r.x = sinf(x); break;
-					case 11: r.x = cosf(x); break;
+					case 10: r.x = em::sinf_(x); break;
+					case 11: r.x = em::cosf_(x); break;
 					case 12: r.x = tanf(x); break;
 					case 13: r.x = (x * CRH_PI) / 180.0f; break;
 					case 14: r.x = x * (180.0f / CRH_PI); break;
@@ -588,96 +598,87 @@ CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &re
 	uint32_t cur = root;
 	for (;;) {
 		const DBsdf n = S.bsdfs[cur];
+		const uint32_t kind = n.kind;
 		BsdfSample res;
-		rgba col = rgba{0.0f, 0.0f, 0.0f, 0.0f};
 		res.out = v3{0.0f, 0.0f, 0.0f};
-		switch (n.kind) {
-			case CRH_BSDF_MIX: {          /* mix.c:42-50 */
-				const float lerp = evalValue(S, n.c, rec, cnt);
-				cur = (getDimension(rng) > lerp) ? n.a : n.b;
-				continue;
+		if (kind == CRH_BSDF_ADD) {           /* add.c:42-49: A fully, then B fully */
+			if (asp < CRH_ADD_DEPTH) addStack[asp++] = cur;
+			cur = n.a;
+			continue;
+		}
+		/* Operands are pure functions of the hit, so each CLASS of operand is evaluated at ONE place for all node kinds (one inlined copy
+		 * of the texture fetch / sRGB transform / program interpreter instead of a dozen), still only when the reference would evaluate it,
+		 * and the sampler draws keep the reference's order. */
+		float vc = 0.0f;                      /* value operand c: mix factor (mix.c:45), glass IOR (glass.c:47) */
+		if (kind == CRH_BSDF_MIX || kind == CRH_BSDF_GLASS) vc = evalValue(S, n.c, rec, cnt);
+		if (kind == CRH_BSDF_MIX) {           /* mix.c:42-50 */
+			cur = (getDimension(rng) > vc) ? n.a : n.b;
+			continue;
+		}
+		/* the dielectric interface of glass (IOR from its node) and plastic (the material's IOR): glass.c:48-66, plastic.c:47-65 */
+		float reflectionProbability = 1.0f;
+		v3 refracted = v3{0.0f, 0.0f, 0.0f};
+		if (kind == CRH_BSDF_GLASS || kind == CRH_BSDF_PLASTIC) {
+			const float IOR = (kind == CRH_BSDF_GLASS) ? vc : rec.ior;
+			v3 outwardNormal;
+			float niOverNt, cosine;
+			if (vdot(rec.dir, rec.normal) > 0.0f) {
+				outwardNormal = vneg(rec.normal);
+				niOverNt = IOR;
+				cosine = IOR * vdot(rec.dir, rec.normal) / vlen(rec.dir);
+			} else {
+				outwardNormal = rec.normal;
+				niOverNt = 1.0f / IOR;
+				cosine = -(vdot(rec.dir, rec.normal) / vlen(rec.dir));
 			}
-			case CRH_BSDF_ADD: {          /* add.c:42-49: A fully, then B fully */
-				if (asp < CRH_ADD_DEPTH) addStack[asp++] = cur;
-				cur = n.a;
-				continue;
-			}
-			case CRH_BSDF_PLASTIC: {      /* plastic.c:42-87 */
-				v3 outwardNormal;
-				float niOverNt, reflectionProbability, cosine;
-				v3 refracted;
-				if (vdot(rec.dir, rec.normal) > 0.0f) {
-					outwardNormal = vneg(rec.normal);
-					niOverNt = rec.ior;
-					cosine = rec.ior * vdot(rec.dir, rec.normal) / vlen(rec.dir);
-				} else {
-					outwardNormal = rec.normal;
-					niOverNt = 1.0f / rec.ior;
-					cosine = -(vdot(rec.dir, rec.normal) / vlen(rec.dir));
-				}
-				if (refract(rec.dir, outwardNormal, niOverNt, refracted)) reflectionProbability = schlick(cosine, rec.ior);
-				else reflectionProbability = 1.0f;
-				if (getDimension(rng) < reflectionProbability) {
-					v3 reflected = vreflect(rec.dir, rec.normal);
-					float roughness = evalColor(S, n.b, rec, cnt).r;
-					if (roughness > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), roughness));
-					res.out = reflected;
-					col = rgba{1.0f, 1.0f, 1.0f, 1.0f};
-					break;
-				}
-				cur = n.c;
-				continue;
+			if (refract(rec.dir, outwardNormal, niOverNt, refracted)) reflectionProbability = schlick(cosine, IOR);
+			else reflectionProbability = 1.0f;
+		}
+		if (kind == CRH_BSDF_PLASTIC && !(getDimension(rng) < reflectionProbability)) {      /* plastic.c:66-86: the diffuse layer below the coat */
+			cur = n.c;
+			continue;
+		}
+		float vb = 0.0f;                      /* value operand b: roughness (metal.c:44, glass.c:67), emission strength (emission.c:46) */
+		if (kind == CRH_BSDF_METAL || kind == CRH_BSDF_GLASS || kind == CRH_BSDF_EMISSION) vb = evalValue(S, n.b, rec, cnt);
+		rgba col = rgba{0.0f, 0.0f, 0.0f, 0.0f};      /* the colour operand: a, for the plastic coat its roughness b (plastic.c:68) */
+		if (kind >= CRH_BSDF_DIFFUSE && kind <= CRH_BSDF_ISOTROPIC) col = evalColor(S, kind == CRH_BSDF_PLASTIC ? n.b : n.a, rec, cnt);
+		switch (kind) {
+			case CRH_BSDF_PLASTIC: {      /* plastic.c:66-72: the reflecting coat */
+				v3 reflected = vreflect(rec.dir, rec.normal);
+				const float roughness = col.r;
+				if (roughness > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), roughness));
+				res.out = reflected;
+				col = rgba{1.0f, 1.0f, 1.0f, 1.0f};
+				break;
 			}
 			case CRH_BSDF_DIFFUSE:        /* diffuse.c:40-47 */
 				res.out = vnorm(vadd(rec.normal, randomOnUnitSphere(rng)));
-				col = evalColor(S, n.a, rec, cnt);
 				break;
 			case CRH_BSDF_METAL: {        /* metal.c:40-55 */
 				v3 reflected = vreflect(vnorm(rec.dir), rec.normal);
-				float roughness = evalValue(S, n.b, rec, cnt);
-				if (roughness > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), roughness));
+				if (vb > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), vb));
 				res.out = reflected;
-				col = evalColor(S, n.a, rec, cnt);
 				break;
 			}
 			case CRH_BSDF_GLASS: {        /* glass.c:41-87 */
-				v3 outwardNormal;
 				v3 reflected = vreflect(rec.dir, rec.normal);
-				float niOverNt, reflectionProbability, cosine;
-				v3 refracted = v3{0.0f, 0.0f, 0.0f};
-				const float IOR = evalValue(S, n.c, rec, cnt);
-				if (vdot(rec.dir, rec.normal) > 0.0f) {
-					outwardNormal = vneg(rec.normal);
-					niOverNt = IOR;
-					cosine = IOR * vdot(rec.dir, rec.normal) / vlen(rec.dir);
-				} else {
-					outwardNormal = rec.normal;
-					niOverNt = 1.0f / IOR;
-					cosine = -(vdot(rec.dir, rec.normal) / vlen(rec.dir));
-				}
-				if (refract(rec.dir, outwardNormal, niOverNt, refracted)) reflectionProbability = schlick(cosine, IOR);
-				else reflectionProbability = 1.0f;
-				const float roughness = evalValue(S, n.b, rec, cnt);
-				if (roughness > 0.0f) {
-					v3 fuzz = vscale(randomOnUnitSphere(rng), roughness);
+				if (vb > 0.0f) {
+					v3 fuzz = vscale(randomOnUnitSphere(rng), vb);
 					reflected = vadd(reflected, fuzz);
 					refracted = vadd(refracted, fuzz);
 				}
 				res.out = (getDimension(rng) < reflectionProbability) ? reflected : refracted;
-				col = evalColor(S, n.a, rec, cnt);
 				break;
 			}
 			case CRH_BSDF_TRANSPARENT:    /* transparent.c:40-44 */
 				res.out = rec.dir;
-				col = evalColor(S, n.a, rec, cnt);
 				break;
 			case CRH_BSDF_EMISSION:       /* emission.c:42-49 */
 				res.out = vnorm(vadd(rec.normal, randomOnUnitSphere(rng)));
-				col = ccoef(evalValue(S, n.b, rec, cnt), evalColor(S, n.a, rec, cnt));
+				col = ccoef(vb, col);
 				break;
 			case CRH_BSDF_ISOTROPIC:      /* isotropic.c:40-47 */
 				res.out = vnorm(randomOnUnitSphere(rng));
-				col = evalColor(S, n.a, rec, cnt);
 				break;
 			default:                      /* background as a surface bsdf never happens; unknown kinds are rejected at upload */
 				break;
@@ -706,8 +707,8 @@ template <class Cnt>
 CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
 	const DBsdf n = S.bsdfs[S.background];
 	v3 ud = vnorm(rec.dir);
-	float phi = (atan2f(ud.z, ud.x) / 4.0f) + evalValue(S, n.c, rec, cnt);
-	float theta = acosf((-ud.y / 1.0f));
+	float phi = (em::atan2f_(ud.z, ud.x) / 4.0f) + evalValue(S, n.c, rec, cnt);
+	float theta = em::acosf_((-ud.y / 1.0f));
 	float u = theta / CRH_PI;
 	float v = (phi / (CRH_PI / 2.0f));
 	u = wrap01(u);
@@ -905,7 +906,7 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 		float t1 = asF32(port.load(VP_T1));
 		if (t1 < 0.0f) t1 = 0.0f;
 		const float distanceInsideVolume = tWalk;
-		const float hitDistance = -(1.0f / S.instances[w.curInst].density) * logf(port.draw());
+		const float hitDistance = -(1.0f / S.instances[w.curInst].density) * em::logf_(port.draw());
 		if (hitDistance < distanceInsideVolume) {
 			w.hit.t = t1 + hitDistance; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -2; w.hit.inst = w.curInst;
 			CRH_COUNT(cnt, inst_hits, 1);
@@ -1040,7 +1041,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			float tExit;
 			if (sphereTest(o, d, inst->radius, w.hit.t, t0, cnt) && sphereTest(alongRay(o, d, t0 + 0.0001f), d, inst->radius, w.hit.t, tExit, cnt)) {
 				if (t0 < 0.0f) t0 = 0.0f;
-				const float hitDistance = -(1.0f / inst->density) * logf(port.draw());
+				const float hitDistance = -(1.0f / inst->density) * em::logf_(port.draw());
 				if (hitDistance < tExit) {
 					w.hit.t = t0 + hitDistance; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -2; w.hit.inst = idx;
 					CRH_COUNT(cnt, inst_hits, 1);
@@ -1134,8 +1135,8 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
 		h.uv = v2{0.0f, 0.0f};
 		if (!LAZY_UV || S.materials[inst->material].pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
-			float phi = atan2f(n.z, n.x);
-			float theta = asinf(n.y);
+			float phi = em::atan2f_(n.z, n.x);
+			float theta = em::asinf_(n.y);
 			float v = (theta + CRH_PI / 2.0f) / CRH_PI;
 			float u = 1.0f - (phi + CRH_PI) / (CRH_PI * 2.0f);
 			u = wrap01(u);

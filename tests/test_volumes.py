@@ -71,7 +71,6 @@ def test_gpu_volumes_vs_reference(pkg, manifest, golden_blob, golden_ref):
         ctx.close()
     img, cnt = frames[0]
     assert np.array_equal(img, frames[1][0]) and cnt == frames[1][1]        # both kernel forms: same frame
-    st = image_stats(img, golden_ref("volumes"))
-    assert np.isfinite(img).all()
-    assert st["rmse"] <= 5e-3 and st["frac_gt_1e-3"] <= 5e-3, st
-    assert abs(cnt["rays"] - m["rays"]) <= 0.002 * m["rays"], (cnt["rays"], m["rays"])
+    ref = golden_ref("volumes")
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), image_stats(img, ref)        # logf of the free-flight draw included
+    assert cnt["rays"] == m["rays"], (cnt["rays"], m["rays"])

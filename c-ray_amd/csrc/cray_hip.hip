@@ -90,6 +90,10 @@ struct BlockQueue {
 	 * are short, so the waves finish close together instead of up to one full unit apart */
 	uint32_t firstSmall;
 	int sbw, sbh;
+	/* ... and the very last ones (from firstTiny on) into blocks of a sixteenth (tbw x tbh): what remains of the finish-line spread is about
+	 * one such unit, which matters when a GPU's share of a frame is small (1/8 of it at 8 GPUs) */
+	uint32_t firstTiny;
+	int tbw, tbh;
 };
 
 /* Pointers that arrive inside a by-value kernel-argument struct are generic ("flat") to the compiler; a round
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
 		const crh_tile t = asGlobal(Q.tiles)[lo];
 		const uint32_t local = unit - asGlobal(Q.start)[lo];
-		const int ubw = lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstSmall ? Q.sbh : Q.bh;
+		const int ubw = lo >= Q.firstTiny ? Q.tbw : lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstTiny ? Q.tbh : lo >= Q.firstSmall ? Q.sbh : Q.bh;
 		const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + ubw - 1) / (uint32_t)ubw;
 		BlockJob J;
 		J.bw = ubw; J.bh = ubh;
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
 		const crh_tile t = asGlobal(Q.tiles)[lo];
 		const uint32_t local = unit - asGlobal(Q.start)[lo];
-		const int ubw = lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstSmall ? Q.sbh : Q.bh;
+		const int ubw = lo >= Q.firstTiny ? Q.tbw : lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstTiny ? Q.tbh : lo >= Q.firstSmall ? Q.sbh : Q.bh;
 		const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + ubw - 1) / (uint32_t)ubw;
 		BlockJob J;
 		J.bw = ubw; J.bh = ubh;
@@ -937,6 +941,7 @@ struct crh_ctx {
 	int wavesPerSimd = 4;
 	int sampler = CRH_SAMPLER_RANDOM;
 	int tailPercent = 16;       /* share of a dispatch's pixels that is cut into quarter-size blocks at the end of the work queue */
+	int tail2Percent = 4;       /* ... and the share at the very end that is cut into sixteenth-size blocks */
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;
 	float *dStage = nullptr;
@@ -1059,7 +1064,7 @@ static int preloadKernel(crh_ctx *c) {
 	BlockQueue Q;
 	memset(&Q, 0, sizeof(Q));
 	Q.counter = c->dWork;                 /* any valid counter: total = 0, every wave leaves at once */
-	Q.bw = Q.bh = Q.sbw = Q.sbh = 1;
+	Q.bw = Q.bh = Q.sbw = Q.sbh = Q.tbw = Q.tbh = 1;
 	if (c->kernel == CRH_KERNEL_WG && !c->dOvf) {
 		HIP_TRY(hipMalloc((void **)&c->dOvf, (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u * sizeof(uint32_t)));
 		c->ovfWords = (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u;
@@ -1185,8 +1190,10 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			return CRH_OK;
 		}
 		case CRH_OPT_TAIL_PERCENT:
-			if (value < 0 || value > 50) return fail(CRH_ERR_INVALID, "tail percent must be 0..50");
-			c->tailPercent = (int)value; return CRH_OK;
+			if (value < 0 || (value & 0xFF) > 50 || (value >> 8) > 51) return fail(CRH_ERR_INVALID, "tail percent must be 0..50 (| (second-level percent + 1) << 8)");
+			c->tailPercent = (int)(value & 0xFF) > 50 ? 50 : (int)(value & 0xFF);
+			if (value >> 8) c->tail2Percent = (int)((value >> 8) & 0xFF) - 1;       /* second level: (percent + 1) << 8, so that plain values keep their meaning */
+			return CRH_OK;
 		case CRH_OPT_SAMPLER:
 			if (value != CRH_SAMPLER_RANDOM && value != CRH_SAMPLER_HALTON) return fail(CRH_ERR_INVALID, "sampler must be CRH_SAMPLER_RANDOM or CRH_SAMPLER_HALTON");
 			c->sampler = (int)value; return CRH_OK;
@@ -1336,36 +1343,45 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	 * finish. The last tailPercent of the pixels (whole tiles from the end of the list, the boundary tile split by rows)
 	 * are cut into blocks of a quarter of the area. */
 	std::vector<crh_tile> work(tiles, tiles + tile_count);
-	uint32_t firstSmall = tile_count;
-	int sbw = bw, sbh = bh;
-	if (area >= 4 && c->tailPercent > 0) {
-		sbw = 1; sbh = 1;
-		while (sbw * sbh < area / 4) { if (sbw <= sbh) sbw *= 2; else sbh *= 2; }
-		const uint64_t want = pixels * (uint64_t)c->tailPercent / 100;
+	/* index of the first tile of the tail that holds the last `want` pixels (the boundary tile is split by rows) */
+	auto cutTail = [&work](uint64_t want) -> uint32_t {
 		uint64_t got = 0;
-		uint32_t t = tile_count;
+		uint32_t t = (uint32_t)work.size();
 		while (t > 0 && got < want) {
 			const crh_tile r = work[t - 1];
 			const uint64_t a = (uint64_t)(r.x1 - r.x0) * (uint64_t)(r.y1 - r.y0);
 			if (got + a <= want + want / 4 || r.y1 - r.y0 < 2) { got += a; --t; continue; }
-			/* split this tile by rows: the upper part (in list order: first) keeps the big blocks */
+			/* split this tile by rows: the upper part (in list order: first) keeps the bigger blocks */
 			const int w = r.x1 - r.x0;
 			int rowsSmall = (int)((want - got + (uint64_t)w - 1) / (uint64_t)(w ? w : 1));
 			rowsSmall = std::min(std::max(rowsSmall, 1), r.y1 - r.y0 - 1);
 			const int ySplit = r.y1 - rowsSmall;                 /* rows are independent: which part goes first is free */
 			work[t - 1] = crh_tile{r.x0, r.y0, r.x1, ySplit};
 			work.insert(work.begin() + t, crh_tile{r.x0, ySplit, r.x1, r.y1});
-			got = want;
 			break;
 		}
-		firstSmall = t;
+		return t;
+	};
+	auto shapeOf = [](int a, int &w, int &h) { w = 1; h = 1; while (w * h < a) { if (w <= h) w *= 2; else h *= 2; } };
+	uint32_t firstSmall = (uint32_t)work.size(), firstTiny = (uint32_t)work.size();
+	int sbw = bw, sbh = bh, tbw = bw, tbh = bh;
+	if (area >= 2 && c->tailPercent > 0) {
+		const int smallArea = std::max(area / 4, 1), tinyArea = std::max(area / 16, 1);
+		shapeOf(smallArea, sbw, sbh);
+		firstSmall = cutTail(pixels * (uint64_t)c->tailPercent / 100);
+		firstTiny = (uint32_t)work.size();
+		tbw = sbw; tbh = sbh;
+		if (tinyArea < smallArea && c->tail2Percent > 0 && c->tail2Percent < c->tailPercent) {
+			shapeOf(tinyArea, tbw, tbh);
+			firstTiny = std::max(firstSmall, cutTail(pixels * (uint64_t)c->tail2Percent / 100));
+		}
 	}
 	const uint32_t work_count = (uint32_t)work.size();
 	std::vector<uint32_t> start(work_count + 1, 0);
 	uint64_t total = 0;
 	for (uint32_t t = 0; t < work_count; ++t) {
 		const crh_tile &r = work[t];
-		const int ubw = t >= firstSmall ? sbw : bw, ubh = t >= firstSmall ? sbh : bh;
+		const int ubw = t >= firstTiny ? tbw : t >= firstSmall ? sbw : bw, ubh = t >= firstTiny ? tbh : t >= firstSmall ? sbh : bh;
 		start[t] = (uint32_t)total;
 		total += (uint64_t)((r.x1 - r.x0 + ubw - 1) / ubw) * ((r.y1 - r.y0 + ubh - 1) / ubh);
 		if (total > 0xFFFFFFF0ull) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: more than 2^32 pixel blocks in one dispatch");
@@ -1441,6 +1457,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	Q.counter = c->dWork + slot;
 	Q.bw = bw; Q.bh = bh;
 	Q.firstSmall = firstSmall; Q.sbw = sbw; Q.sbh = sbh;
+	Q.firstTiny = firstTiny; Q.tbw = tbw; Q.tbh = tbh;
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
 
 	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */

@@ -271,7 +271,8 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_UNITS_PER_WAVE 8  /* shrink the pixel blocks until every wave gets at least this many work units (default 8) */
 #define CRH_OPT_SAMPLER       9   /* which sampler seeds a (pixel, pass): CRH_SAMPLER_RANDOM = renderThread (sampler.c:41-44, default),
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */
-#define CRH_OPT_TAIL_PERCENT 10   /* share (0..50, default 16) of a dispatch's pixels that ends the work queue as quarter-size blocks, so the waves finish close together */
+#define CRH_OPT_TAIL_PERCENT 10   /* share (0..50, default 16) of a dispatch's pixels that ends the work queue as quarter-size blocks, so the waves finish close together;
+                                   * | (p2 + 1) << 8 also sets the share (default 4) at the very end that is cut into sixteenth-size blocks */
 #define CRH_OPT_KERNEL       12   /* which form of the path-tracing kernel: CRH_KERNEL_WAVE = every wave a self-contained machine (default),
                                    * CRH_KERNEL_WG = the four waves of a workgroup share one path table and take walker / shader roles */
 #define CRH_OPT_SCHED_WG     13   /* workgroup kernel scheduler: linger | drainAt<<8 | maxDrainers<<20 | partialMin<<24 | walkMin<<32 | fillTo<<40 */

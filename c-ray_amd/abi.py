@@ -125,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "crh_synchronize", "crh_frames_reduce", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
     "crh_blob_save", "crh_blob_load", "crh_blob_free", "crh_bvh_build_triangles", "crh_debug_eval_math",
 ]
-MATH_FUNCTIONS = ("sinf", "cosf", "sincosf_sin", "sincosf_cos", "logf", "log10f", "atanf", "acosf", "asinf", "powf", "atan2f")   # enum crh_math_function
+MATH_FUNCTIONS = ("sinf", "cosf", "sincosf_sin", "sincosf_cos", "logf", "log10f", "atanf", "acosf", "asinf", "tanf", "powf", "atan2f")   # enum crh_math_function
 
 
 class BvhBuildStats(C.Structure):

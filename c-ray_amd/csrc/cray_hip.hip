@@ -911,6 +911,7 @@ __global__ void k_eval_math(int fn, const float *x, const float *y, uint64_t n, 
 			case CRH_MATH_ATANF: r = em::atanf_(a); break;
 			case CRH_MATH_ACOSF: r = em::acosf_(a); break;
 			case CRH_MATH_ASINF: r = em::asinf_(a); break;
+			case CRH_MATH_TANF: r = em::tanf_(a); break;
 			case CRH_MATH_POWF: r = em::powf_(a, b); break;
 			case CRH_MATH_ATAN2F: r = em::atan2f_(a, b); break;
 			default: break;

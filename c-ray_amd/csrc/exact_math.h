@@ -393,6 +393,66 @@ CRH_EM float asinf_(float x) {
 	return (hx > 0) ? t : -t;
 }
 
+/* ---- tanf: sysdeps/ieee754/flt-32/s_tanf.c, k_tanf.c, e_rem_pio2f.c (2.35: the sincosf reduction in double, built WITHOUT contraction) -- */
+CRH_EM float kernelTanf(float x, float y, int iy) {
+	const float pio4 = 0x1.921fb4p-1f, pio4lo = 0x1.4442dp-25f,
+				T0 = 0x1.555556p-2f, T1 = 0x1.111112p-3f, T2 = 0x1.ba1ba2p-5f, T3 = 0x1.664f48p-6f, T4 = 0x1.226e3ep-7f, T5 = 0x1.d6d22cp-9f, T6 = 0x1.7dbc9p-10f,
+				T7 = 0x1.344d9p-11f, T8 = 0x1.026f72p-12f, T9 = 0x1.47e88ap-14f, T10 = 0x1.2b80f4p-14f, T11 = -0x1.375cbep-16f, T12 = 0x1.b2a708p-16f;
+	const int32_t hx = (int32_t)fbits(x), ix = hx & 0x7fffffff;
+	if (ix < 0x39000000) {                               /* |x| < 2^-13 */
+		if ((int)x == 0) {
+			if ((ix | (iy + 1)) == 0) return 1.0f / fabsf_(x);
+			if (iy == 1) return x;
+			return -1.0f / x;
+		}
+	}
+	if (ix >= 0x3f2ca140) {                              /* |x| >= 0.6744 */
+		if (hx < 0) { x = -x; y = -y; }
+		const float z0 = pio4 - x;
+		const float w0 = pio4lo - y;
+		x = z0 + w0; y = 0.0f;
+		if (fabsf_(x) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
+	}
+	float z = x * x;
+	float w = z * z;
+	float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+	float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+	float s = z * x;
+	r = y + z * (s * (r + v) + y);
+	r += T0 * s;
+	w = x + r;
+	if (ix >= 0x3f2ca140) {
+		v = (float)iy;
+		return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+	}
+	if (iy == 1) return w;
+	/* -1.0 / (x + r), accurately */
+	z = ffrom(fbits(w) & 0xfffff000u);
+	v = r - (z - x);
+	const float a = -1.0f / w;
+	const float t = ffrom(fbits(a) & 0xfffff000u);
+	s = 1.0f + t * z;
+	return t + a * (s + t * v);
+}
+CRH_EM float tanf_(float x) {
+	const uint32_t bits = fbits(x), ix = bits & 0x7fffffffu;
+	if (ix <= 0x3f490fdau) return kernelTanf(x, 0.0f, 1);        /* |x| <~ pi/4 */
+	if (ix >= 0x7f800000u) return x - x;                           /* tan(Inf or NaN) is NaN */
+	double dx = (double)x;
+	int n;
+	if (((bits >> 20) & 0x7ffu) <= 0x42eu) {                       /* |x| < 120: reduce_fast, mul and sub NOT fused in this translation unit */
+		const double r = dx * CRH_SC_HPI_INV;
+		n = ((int32_t)r + 0x800000) >> 24;
+		dx = dx - (double)n * CRH_SC_HPI;
+	} else {
+		dx = reduceLarge(bits, n);
+		if (bits >> 31) dx = -dx;
+	}
+	const float y0 = (float)dx;
+	const float y1 = (float)(dx - (double)y0);
+	return kernelTanf(y0, y1, 1 - ((n & 1) << 1));
+}
+
 /* ---- log10f: sysdeps/ieee754/flt-32/e_log10f.c (calls logf above) ----------------------------------------------------------- */
 CRH_EM float log10f_(float x) {
 	const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;

@@ -16,7 +16,7 @@
 #include <math.h>
 #include <float.h>
 #include "cray_hip.h"
-#include "exact_math.h"     /* sinf, cosf, powf, logf, atan2f, acosf, asinf, log10f with the host libm's bits (namespace crh::em) */
+#include "exact_math.h"     /* sinf, cosf, tanf, powf, logf, log10f, atan2f, acosf, asinf with the host libm's bits (namespace crh::em) */
 
 #if defined(__HIPCC__)
 #define CRH_DEV __device__ __forceinline__
@@ -529,7 +529,7 @@ CRH_DEV ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) 
 					case 9: r.x = rmax(x, y); break;
 					case 10: r.x = em::sinf_(x); break;
 					case 11: r.x = em::cosf_(x); break;
-					case 12: r.x = tanf(x); break;
+					case 12: r.x = em::tanf_(x); break;
 					case 13: r.x = (x * CRH_PI) / 180.0f; break;
 					case 14: r.x = x * (180.0f / CRH_PI); break;
 					default: break;

@@ -339,7 +339,7 @@ int crh_kernel_time_ms(crh_ctx *ctx, float *last_ms, double *total_ms, uint64_t 
  * restated with the bits of the reference's host libm) on n caller values; y_host is the second argument of powf(x, y) /
  * atan2f(x = first argument y, second argument x) and may be NULL for the unary functions. */
 enum crh_math_function { CRH_MATH_SINF = 0, CRH_MATH_COSF, CRH_MATH_SINCOSF_SIN, CRH_MATH_SINCOSF_COS, CRH_MATH_LOGF, CRH_MATH_LOG10F,
-                         CRH_MATH_ATANF, CRH_MATH_ACOSF, CRH_MATH_ASINF, CRH_MATH_POWF, CRH_MATH_ATAN2F };
+                         CRH_MATH_ATANF, CRH_MATH_ACOSF, CRH_MATH_ASINF, CRH_MATH_TANF, CRH_MATH_POWF, CRH_MATH_ATAN2F };
 int crh_debug_eval_math(crh_ctx *ctx, int function, const float *x_host, const float *y_host, uint64_t n, float *out_host);
 
 /* Diagnostic / parity entry: getClosestIsect (pathtrace.c:26-30) for n caller-supplied world-space

@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
 	rc |= unary("sincosf.cos", [](float x) { float s, c; sincosf_(x, s, c); return c; }, [](float x) { return cosf(x); }, stride);
 	rc |= unary("logf", [](float x) { return logf_(x); }, [](float x) { return logf(x); }, stride);
 	rc |= unary("log10f", [](float x) { return log10f_(x); }, [](float x) { return log10f(x); }, stride);
+	rc |= unary("tanf", [](float x) { return tanf_(x); }, [](float x) { return tanf(x); }, stride);
 	rc |= unary("atanf", [](float x) { return atanf_(x); }, [](float x) { return atanf(x); }, stride);
 	rc |= unary("acosf", [](float x) { return acosf_(x); }, [](float x) { return acosf(x); }, stride);
 	rc |= unary("asinf", [](float x) { return asinf_(x); }, [](float x) { return asinf(x); }, stride);

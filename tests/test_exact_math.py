@@ -1,5 +1,5 @@
 """c-ray_amd/csrc/exact_math.h — the libm functions of the hot path restated with the bits of the reference's host libm (glibc 2.35,
-x86-64 FMA ifunc variants): sinf, cosf (+ the shared-reduction sincosf), powf, logf, log10f, atanf, atan2f, acosf, asinf.
+x86-64 FMA ifunc variants): sinf, cosf (+ the shared-reduction sincosf), tanf, powf, logf, log10f, atanf, atan2f, acosf, asinf.
 
 CPU tier: the host build of the header against the installed libm, bit for bit (tests/emu/exact_math_check.cpp). By default every
 4099th float per unary function / per powf exponent of the path plus 2 M random pairs (a second); CRH_EXACT_MATH_FULL=1 runs all 2^32
@@ -63,7 +63,7 @@ def test_device_build_matches_the_host_libm(pkg):
         unary = {"sinf": ("sinf", ["edge", "angle", "wide", "bits"]), "cosf": ("cosf", ["edge", "angle", "wide", "bits"]),
                  "sincosf_sin": ("sinf", ["edge", "angle", "bits"]), "sincosf_cos": ("cosf", ["edge", "angle", "bits"]),
                  "logf": ("logf", ["edge", "unit", "bits"]), "log10f": ("log10f", ["edge", "unit", "bits"]),
-                 "atanf": ("atanf", ["edge", "wide", "bits"]), "acosf": ("acosf", ["edge", "sym", "bits"]), "asinf": ("asinf", ["edge", "sym", "bits"])}
+                 "atanf": ("atanf", ["edge", "wide", "bits"]), "tanf": ("tanf", ["edge", "angle", "wide", "bits"]), "acosf": ("acosf", ["edge", "sym", "bits"]), "asinf": ("asinf", ["edge", "sym", "bits"])}
         for dev, (cname, sets) in unary.items():
             for sname in sets:
                 x = S[sname][:60000]

@@ -3,13 +3,12 @@
 The bar (stated once, used everywhere below): BIT-EXACT.
   * traversal: fp32 add/mul/fma/div/sqrt are IEEE on both sides, so crh_trace_rays returns the oracle's records bit for
     bit (instance, polygon, distance, hit point, normal, uv, per-ray node / triangle test counts).
-  * images: the libm functions of the path (sinf, cosf, powf, logf, atan2f, acosf, asinf, log10f) are restated in
+  * images: the libm functions of the path (sinf, cosf, tanf, powf, logf, log10f, atan2f, acosf, asinf) are restated in
     c-ray_amd/csrc/exact_math.h with the bits of the reference's host libm (glibc 2.35, x86-64 FMA variants; checked over all
     2^32 inputs by tests/test_exact_math.py), so the device frame equals the reference's float buffer exactly — every fixture,
     including statues.json, whose own chaos (transparent plane re-hit at t ~ 0) makes the SAME reference sources differ from
     themselves in 42 % of the pixels when only FMA contraction changes. Ray counts are equal; node-test counts are equal
     unless a zero-component ray took the exact-slab path (fewer visits).
-  The one libm function left to ocml is tanf (the Math node's Tangent op, which no scene file can build).
 """
 import numpy as np
 import pytest

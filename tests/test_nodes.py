@@ -9,7 +9,7 @@ the scene compiler), 9..17 / 28..37 the same graphs with hit-dependent operands 
 6 bounces) runs the exotic and JSON graphs through whole paths.
 
 CPU tier: oracle and host-built lane code equal the reference bit for bit. GPU tier: bit for bit as well (c-ray_amd/csrc/exact_math.h);
-the one exception is the Math node's Tangent op, whose tanf is left to ocml (roughly_equals, like the reference's own test)."""
+the Math node's Tangent op included."""
 import ctypes as C
 import math
 
@@ -131,11 +131,5 @@ def test_gpu_node_zoo_vs_reference(name, pkg, manifest, golden_blob, golden_ref)
     if name == "nodezoo":
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), image_stats(img, ref)       # every exotic / JSON graph, whole paths: bit-exact
     else:
-        # the known answers; the whole frame is exact except where the Tangent op's tanf (left to ocml) decides a colour
         check_known_answers(img)
-        d = img.view(np.uint32) != ref.view(np.uint32)
-        tangent = np.zeros(img.shape[:2], bool)
-        for i in (8, 17):
-            r, c = sphere_pixel(i)
-            tangent[r - 12:r + 13, c - 12:c + 13] = True
-        assert not d.any(axis=2)[~tangent].any(), int(d.any(axis=2)[~tangent].sum())
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), image_stats(img, ref)

@@ -501,3 +501,54 @@ def test_frame_renderer_on_torch_stream(pkg, ctx, manifest, golden_blob):
         f2.close()
     assert np.array_equal(parts[0] + parts[1], full)
     assert not (np.abs(parts[0]) * np.abs(parts[1])).any()      # disjoint ownership
+
+
+def test_cluster_worker_renders_its_tiles_on_the_gpu(manifest, tmp_path):
+    """`c-ray-hip --worker` is the reference's network worker (handshake, scene / asset transfer, tile protocol:
+    src/utils/protocol/worker.c compiled unmodified) with its render threads replaced by one GPU dispatch thread. A reference MASTER
+    (c-ray-ref-strict --nodes) renders a frame with two local CPU threads plus that worker: the image it writes is made of CPU tiles and
+    GPU tiles, and must equal the image of a plain single-process reference render byte for byte."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker_exe = os.path.join(repo, "c-ray_amd", "_lib", "c-ray-hip")
+    master_exe = os.path.join(repo, "oracle", "_ref", "c-ray-ref-strict")
+    overlay = os.path.join(repo, "oracle", "_ref", "input")
+    if not (os.path.exists(worker_exe) and os.path.exists(master_exe) and os.path.exists(os.path.join(overlay, "scene.json"))):
+        pytest.skip("c-ray-hip / c-ray-ref-strict / the asset overlay are not built (needs /root/reference at build time)")
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import refrun
+    m = manifest["cfg1_scene"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = subprocess.Popen([worker_exe, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        for _ in range(100):                       # wait for the worker to listen
+            try:
+                socket.create_connection(("127.0.0.1", port), timeout=0.2).close()
+                break
+            except OSError:
+                time.sleep(0.1)
+        outs = {}
+        for name, extra in (("cluster", ["--nodes", f"127.0.0.1:{port}", "-j", "2"]), ("single", ["-j", "4"])):
+            out_dir = tmp_path / name
+            out_dir.mkdir()
+            scene = refrun.rewrite_scene("scene.json", m["width"], m["height"], m["samples"], m["bounces"], tile=(32, 32), out_dir=str(out_dir))
+            if name == "cluster":
+                time.sleep(0.5)                    # the probe connection above is closed; the worker is back in accept()
+            proc = subprocess.run([master_exe] + extra, input=json.dumps(scene).encode(), cwd=overlay, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, timeout=600)
+            assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-3000:]
+            files = [f for f in os.listdir(out_dir) if f.endswith(".bmp")]
+            assert files, proc.stdout.decode(errors="replace")[-2000:]
+            outs[name] = (open(out_dir / files[0], "rb").read(), proc.stdout.decode(errors="replace"))
+        assert "render worker" in outs["cluster"][1], outs["cluster"][1][-2000:]          # the master did use the worker
+        assert outs["cluster"][0] == outs["single"][0], "cluster frame (CPU + GPU tiles) differs from the single-process reference frame"
+    finally:
+        worker.kill()
+        wlog = worker.communicate()[0].decode(errors="replace")
+    assert "Got connection" in wlog, wlog[-2000:]

@@ -72,6 +72,11 @@ static void *gpuWorkerThread(void *arg) {
 		while (n < batchMax) {
 			struct renderTile t = getWork(sock);
 			if (t.tileNum == -1) { more = false; break; }
+			/* once its queue is empty the master re-issues network tiles that are not back yet (tile.c:33-42) — i.e. the ones of this very
+			 * batch: such a tile ends the batch (it is already in it; rendering it twice in one dispatch would race on its pixels) */
+			bool mine = false;
+			for (int k = 0; k < n; ++k) mine = mine || tiles[k].tileNum == t.tileNum;
+			if (mine) break;
 			tiles[n] = t;
 			rects[n] = (crh_tile){t.begin.x, t.begin.y, t.end.x, t.end.y};
 			++n;

@@ -16,6 +16,7 @@
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <signal.h>
 
 #include "c-ray.h"
 #include "renderer/renderer.h"
@@ -55,7 +56,17 @@ int main(int argc, char *argv[]) {
 	crLog("C-ray v%s [%.8s] (oracle/_ref build)\n", crGetVersion(), crGitHash());
 	crInitialize();
 	crParseArgs(argc, argv);
+	/* cluster master: at the end of a render the reference answers the worker's goodbye on a socket the worker may already have closed
+	 * (server.c:213-216 vs worker.c:409-413); the worker ignores SIGPIPE (worker.c:349), the master does not and dies of it now and then.
+	 * The harness ignores it so that cluster tests are deterministic. */
+	signal(SIGPIPE, SIG_IGN);
 	crInitRenderer();
+	if (crOptionIsSet("is_worker")) {          /* src/main.c:19,33-36: `--worker [port]` = the reference's own (CPU) cluster worker */
+		crStartRenderWorker();
+		crDestroyRenderer();
+		crDestroyOptions();
+		return 0;
+	}
 	size_t bytes = 0;
 	char *input = crOptionIsSet("inputFile") ? crReadFile(&bytes) : crReadStdin(&bytes);
 	if (!input) {

@@ -503,52 +503,119 @@ def test_frame_renderer_on_torch_stream(pkg, ctx, manifest, golden_blob):
     assert not (np.abs(parts[0]) * np.abs(parts[1])).any()      # disjoint ownership
 
 
-def test_cluster_worker_renders_its_tiles_on_the_gpu(manifest, tmp_path):
-    """`c-ray-hip --worker` is the reference's network worker (handshake, scene / asset transfer, tile protocol:
-    src/utils/protocol/worker.c compiled unmodified) with its render threads replaced by one GPU dispatch thread. A reference MASTER
-    (c-ray-ref-strict --nodes) renders a frame with two local CPU threads plus that worker: the image it writes is made of CPU tiles and
-    GPU tiles, and must equal the image of a plain single-process reference render byte for byte."""
+def test_cluster_worker_renders_its_tiles_on_the_gpu(pkg, oracle, manifest, golden_ref):
+    """`c-ray-hip --worker` is the reference's network worker (handshake, asset / scene transfer, tile protocol:
+    src/utils/protocol/worker.c compiled unmodified) with its render threads replaced by one GPU dispatch thread. A minimal master in
+    this test speaks the reference's wire protocol (networking.c:44-131 framing, server.c:45-52, 296-345, 148-175 messages): it syncs
+    input/scene.json, hands out 32x32 tiles, and every 8-bit sRGB tile the worker submits must equal, byte for byte, that tile of the
+    real reference's frame (golden fixture through colorToSRGB, renderer.c:294-300 = worker.c:176-181).
+    (The reference's own master is not used: in v0.6.3 it pastes tiles with a row slip (server.c:166), dies of SIGPIPE when the worker
+    closes first, and corrupts its heap with -j 0; it is marked experimental upstream.)"""
+    import base64
     import json
     import os
     import socket
+    import struct
     import subprocess
     import sys
     import time
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    worker_exe = os.path.join(repo, "c-ray_amd", "_lib", "c-ray-hip")
-    master_exe = os.path.join(repo, "oracle", "_ref", "c-ray-ref-strict")
+    gpu_worker = os.path.join(repo, "c-ray_amd", "_lib", "c-ray-hip")
     overlay = os.path.join(repo, "oracle", "_ref", "input")
-    if not (os.path.exists(worker_exe) and os.path.exists(master_exe) and os.path.exists(os.path.join(overlay, "scene.json"))):
-        pytest.skip("c-ray-hip / c-ray-ref-strict / the asset overlay are not built (needs /root/reference at build time)")
+    if not (os.path.exists(gpu_worker) and os.path.exists(os.path.join(overlay, "scene.json"))):
+        pytest.skip("c-ray-hip / the asset overlay are not built (needs /root/reference at build time)")
     sys.path.insert(0, os.path.join(repo, "tools"))
     import refrun
     m = manifest["cfg1_scene"]
+    w, h = m["width"], m["height"]
+    expected8 = oracle.to_srgb8(golden_ref("cfg1_scene"))                      # stored rows run top-down (texture.c:24-28)
+
+    CHUNK = 1024
+    def send(sock, obj):
+        data = json.dumps(obj).encode() + b"\0"
+        padded = data.ljust((len(data) + CHUNK - 1) // CHUNK * CHUNK, b"\0")
+        sock.sendall(struct.pack(">Q", len(data)) + padded)
+    def recv_exact(sock, n):
+        buf = b""
+        while len(buf) < n:
+            part = sock.recv(n - len(buf))
+            if not part:
+                return None
+            buf += part
+        return buf
+    def recv(sock):
+        head = recv_exact(sock, 8)
+        if not head:
+            return None
+        n, = struct.unpack(">Q", head)
+        if n == 0:
+            return None
+        body = recv_exact(sock, (n + CHUNK - 1) // CHUNK * CHUNK)
+        return json.loads(body[:n].rstrip(b"\0").decode())
+
+    files = []
+    for sub in ("", "shapes", "HDRs"):
+        d = os.path.join(overlay, sub)
+        for f in sorted(os.listdir(d)):
+            path = os.path.join(d, f)
+            if os.path.isfile(path) and os.path.getsize(path) < 4 << 20 and not f.endswith(".json"):
+                data = base64.b64encode(open(path, "rb").read()).decode()
+                rel = os.path.join(sub, f) if sub else f
+                files += [{"path": "./" + rel, "data": data}, {"path": rel, "data": data}]
+    scene = refrun.rewrite_scene("scene.json", w, h, m["samples"], m["bounces"], tile=(32, 32), out_dir="/tmp")
+    tiles = pkg.tiles.quantize_image(w, h, 32, 32, pkg.tiles.ORDER_FROM_MIDDLE)
+
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    worker = subprocess.Popen([worker_exe, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1"),
+    worker = subprocess.Popen([gpu_worker, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    got = {}
     try:
+        sock = None
         for _ in range(100):                       # wait for the worker to listen
             try:
-                socket.create_connection(("127.0.0.1", port), timeout=0.2).close()
+                sock = socket.create_connection(("127.0.0.1", port), timeout=0.5)
                 break
             except OSError:
                 time.sleep(0.1)
-        outs = {}
-        for name, extra in (("cluster", ["--nodes", f"127.0.0.1:{port}", "-j", "2"]), ("single", ["-j", "4"])):
-            out_dir = tmp_path / name
-            out_dir.mkdir()
-            scene = refrun.rewrite_scene("scene.json", m["width"], m["height"], m["samples"], m["bounces"], tile=(32, 32), out_dir=str(out_dir))
-            if name == "cluster":
-                time.sleep(0.5)                    # the probe connection above is closed; the worker is back in accept()
-            proc = subprocess.run([master_exe] + extra, input=json.dumps(scene).encode(), cwd=overlay, stdout=subprocess.PIPE,
-                                  stderr=subprocess.STDOUT, timeout=600)
-            assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-3000:]
-            files = [f for f in os.listdir(out_dir) if f.endswith(".bmp")]
-            assert files, proc.stdout.decode(errors="replace")[-2000:]
-            outs[name] = (open(out_dir / files[0], "rb").read(), proc.stdout.decode(errors="replace"))
-        assert "render worker" in outs["cluster"][1], outs["cluster"][1][-2000:]          # the master did use the worker
-        assert outs["cluster"][0] == outs["single"][0], "cluster frame (CPU + GPU tiles) differs from the single-process reference frame"
+        assert sock is not None, "the worker never listened"
+        sock.settimeout(120)
+        send(sock, {"action": "handshake", "version": "0.1", "githash": "NoHash"})
+        assert recv(sock) == {"action": "startSync"}
+        send(sock, {"action": "loadAssets", "files": files})
+        assert recv(sock) == {"action": "ok"}
+        send(sock, {"action": "loadScene", "data": scene, "assetPath": "./"})
+        ready = recv(sock)
+        assert ready and ready.get("action") == "ready" and ready.get("threadCount", 0) >= 1, ready
+        send(sock, {"action": "startRender"})
+        nxt = 0
+        while True:
+            req = recv(sock)
+            assert req is not None, "the worker hung up before saying goodbye"
+            act = req.get("action")
+            if act == "getWork":
+                if nxt < len(tiles):
+                    x0, y0, x1, y1 = tiles[nxt]
+                    send(sock, {"action": "newWork", "tile": {"width": x1 - x0, "height": y1 - y0, "beginX": x0, "beginY": y0, "endX": x1, "endY": y1, "tileNum": nxt}})
+                    nxt += 1
+                else:
+                    send(sock, {"action": "renderComplete"})
+            elif act == "submitWork":
+                t, r = req["tile"], req["result"]
+                assert not r["isFloatPrecision"] and r["channels"] == 3 and r["width"] == t["width"] and r["height"] == t["height"]
+                got[t["tileNum"]] = (t, np.frombuffer(base64.b64decode(r["data"]), np.uint8).reshape(r["height"], r["width"], 3))
+                send(sock, {"action": "ok"})
+            elif act == "stats":
+                pass
+            elif act == "goodbye":
+                break
+            else:
+                pytest.fail(f"unexpected message from the worker: {req}")
+        sock.close()
     finally:
         worker.kill()
         wlog = worker.communicate()[0].decode(errors="replace")
-    assert "Got connection" in wlog, wlog[-2000:]
+    assert sorted(got) == list(range(len(tiles))), (sorted(got), wlog[-1500:])
+    for num, (t, px) in got.items():
+        x0, y0, x1, y1 = tiles[num]
+        assert (t["beginX"], t["beginY"], t["endX"], t["endY"]) == (x0, y0, x1, y1)
+        assert np.array_equal(px, expected8[h - y1:h - y0, x0:x1]), f"tile {num} {tiles[num]} differs from the reference's frame"

@@ -78,7 +78,11 @@ def main():
         cpu_s = time.time() - t
         dd = np.abs(g.astype(np.float64) - ref)
         per_px = np.sqrt((dd ** 2).sum(axis=2))
-        out["parity"] = {"spp": a.parity_spp, "rmse": float(np.sqrt((dd ** 2).mean())), "frac_px_gt_1e-3": float((per_px > 1e-3).mean()),
+        # BASELINE.md section 3 report row: pixels > 1 LSB (8-bit sRGB), mean and p99.9 per-pixel L2, RMSE — and the bar itself: identical floats
+        g8, r8 = oracle_py.to_srgb8(np.ascontiguousarray(g)).astype(np.int32), oracle_py.to_srgb8(np.ascontiguousarray(ref)).astype(np.int32)
+        out["parity"] = {"spp": a.parity_spp, "floats_that_differ": int((g.view(np.uint32) != ref.view(np.uint32)).sum()), "bit_identical": bool(np.array_equal(g, ref)),
+                         "pixels_gt_1lsb_pct": float(100.0 * (np.abs(g8 - r8).max(axis=2) > 1).mean()), "p999_l2": float(np.quantile(per_px, 0.999)),
+                         "rmse": float(np.sqrt((dd ** 2).mean())), "frac_px_gt_1e-3": float((per_px > 1e-3).mean()),
                          "mean_l2": float(per_px.mean()), "gpu_rays": gc["rays"], "oracle_rays": oc["rays"],
                          "oracle_s": round(cpu_s, 2), "oracle_mrays": round(oc["rays"] / cpu_s / 1e6, 2), "cores": os.cpu_count()}
     print(json.dumps(out), flush=True)

@@ -1,6 +1,7 @@
 """tiles.py — host mirror of the reference's image quantisation (src/datatypes/tile.c:66-117) and tile
-orderings (tile.c:119-241), so that every rank of a multi-GPU run derives the SAME ordered tile list the
-reference's `nextTile()` would hand out, and takes tiles i = rank (mod world) of it.
+orderings (tile.c:119-241), so that tests, the bench and the cluster-worker test derive the SAME ordered tile list the reference's
+`nextTile()` would hand out. (Multi-GPU shares are NOT dealt from this list: render.py: owned_tiles gives rank r the
+4-row strips i = r mod world — tile orders such as "from middle" balance badly when dealt round-robin)
 Tiles are (x0, y0, x1, y1) in reference coordinates (y counts from the bottom of the image).
 """
 import math

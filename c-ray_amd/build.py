@@ -6,6 +6,9 @@
 hipcc cross-compiles without a GPU. Flags that matter for parity with the reference CPU render:
   -ffp-contract=off                              only the explicit fmaf() of the slab test fuses (bvh.c:318-324)
   -fhip-fp32-correctly-rounded-divide-sqrt       IEEE divide / sqrt like the host
+and one that matters for speed:
+  -mllvm -disable-machine-licm                   the path-tracing kernel is one big loop; hoisting every loop-invariant constant and
+                                                 address out of it keeps them live across everything: 87 -> 44 spilled VGPRs, +3..11 %
 The library has no CPU path: without a HIP device every entry point returns CRH_ERR_NO_DEVICE.
 """
 import os
@@ -21,10 +24,10 @@ LIB = os.path.join(OUT_DIR, "libcray_hip.so")
 SOURCES = [os.path.join(CSRC, "cray_hip.hip"), os.path.join(CSRC, "bvh_build.hip")]
 CXX_SOURCES = [os.path.join(CSRC, "scene_compile.cpp")]      # host-only C++ (g++, -ffp-contract=off: prepared triangles)
 C_SOURCES = [os.path.join(HERE, "host", "scene_blob.c")]
-DEPS = SOURCES + CXX_SOURCES + C_SOURCES + [os.path.join(CSRC, "pt_device.h"), os.path.join(CSRC, "scene_compile.h"), os.path.join(CSRC, "ctx_access.h"),
+DEPS = SOURCES + CXX_SOURCES + C_SOURCES + [os.path.join(CSRC, "pt_device.h"), os.path.join(CSRC, "exact_math.h"), os.path.join(CSRC, "scene_compile.h"), os.path.join(CSRC, "ctx_access.h"),
                               os.path.join(REPO, "include", "cray_hip.h"), os.path.abspath(__file__)]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm",
          "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 
 

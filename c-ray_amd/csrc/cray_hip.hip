@@ -58,10 +58,32 @@ static int fail(int code, const std::string &msg) { t_err = msg; return code; }
  * access into a flat_load / flat_store. LDS + overflow cover the worst case the scene compiler can report
  * (64 + 5 + 64 + 1, bvh.c:32). The park slots (pt_device.h: PK_*) are LDS too. */
 #define CRH_STACK_OVF (134 - CRH_STACK_LDS)
+#define CRH_OVF_WORDS_PER_WAVE (112u * 64u)    /* overflow columns of one wave in the context's global buffer (both kernel forms: >= 134 - 22 entries x 64 lanes) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+/* k_pathtrace: the overflow entries live in a per-wave column block of a global buffer (entry i of lane l at ovf[(i - CRH_STACK_LDS) * 64]
+ * from the lane's own base: coalesced, and no private memory behind every lane for a depth real scenes almost never reach) */
 struct LdsStack {
 	lds_u32 *lds;        /* &s_stack[threadIdx.x] */
 	lds_u32 *parkp;      /* &s_park[threadIdx.x]  */
+	glb_u32 *ovf;        /* wave-uniform: &ovfAll[wave * CRH_OVF_WORDS_PER_WAVE]; the lane's column starts at its lane index */
+	__device__ __forceinline__ void park(int i, uint32_t v) { parkp[i * CRH_BLOCK] = v; }
+	__device__ __forceinline__ uint32_t unpark(int i) { return parkp[i * CRH_BLOCK]; }
+	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
+		if (__builtin_expect(i < CRH_STACK_LDS, 1)) lds[i * CRH_BLOCK] = v;
+		else ovf[(i - CRH_STACK_LDS) * 64u + (threadIdx.x & 63u)] = v;
+	}
+	__device__ __forceinline__ uint32_t pop(uint32_t i) {
+		uint32_t v;
+		if (__builtin_expect(i < CRH_STACK_LDS, 1)) v = lds[i * CRH_BLOCK];
+		else v = ovf[(i - CRH_STACK_LDS) * 64u + (threadIdx.x & 63u)];
+		return v;
+	}
+};
+/* k_trace_rays (test entry, one ray per lane, no persistent waves): overflow in a private array */
+struct LdsStackPrivate {
+	lds_u32 *lds;
+	lds_u32 *parkp;
 	uint32_t ovf[CRH_STACK_OVF];
 	__device__ __forceinline__ void park(int i, uint32_t v) { parkp[i * CRH_BLOCK] = v; }
 	__device__ __forceinline__ uint32_t unpark(int i) { return parkp[i * CRH_BLOCK]; }
@@ -169,7 +191,7 @@ __device__ __forceinline__ uint32_t laneRank(unsigned long long m) {
 template <int LEVEL, int WPS, bool PROG, int SAMP>
 __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 														   unsigned long long *counters,
-														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues) {
+														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
@@ -184,6 +206,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
+	stk.ovf = (glb_u32 *)ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_OVF_WORDS_PER_WAVE;
 	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
 	const int passEnd = P.first_pass + P.pass_count;
 	/* the wave's path table, its id stacks and their wave-uniform fill levels (LDS: lane 0 writes, every lane reads; as
@@ -511,6 +534,7 @@ struct WgStack {
 	}
 };
 #define CRH_WG_OVF (134 - CRH_WG_STACK_LDS)
+static_assert(CRH_WG_OVF * 64u <= CRH_OVF_WORDS_PER_WAVE && CRH_STACK_OVF * 64u <= CRH_OVF_WORDS_PER_WAVE, "overflow columns fit the per-wave block");
 
 enum { CT_LOCK, CT_RAYS, CT_HITS, CT_MISSES, CT_FREE, CT_NEXT, CT_DRAINERS, CT_ABORT, CT_UNIT, CT_WORDS };
 typedef volatile __attribute__((address_space(3))) int wg_int;
@@ -550,7 +574,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 	WgStack stk;
 	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
 	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
-	stk.ovf = (uint32_t *)(__attribute__((address_space(1))) uint32_t *)(ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_WG_OVF * 64u);
+	stk.ovf = (uint32_t *)(__attribute__((address_space(1))) uint32_t *)(ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_OVF_WORDS_PER_WAVE);
 	stk.lane = lane;
 	CountersT<LEVEL, PROG> cnt;
 	memset(&cnt, 0, sizeof(cnt));
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
-	LdsStack stk;
+	LdsStackPrivate stk;
 	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
 	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
 	for (uint64_t i = (uint64_t)blockIdx.x * CRH_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CRH_BLOCK) {
@@ -931,7 +955,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 16, 192, 4, 12, 12};
+	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12};
 	int kernel = CRH_KERNEL_WAVE;            /* CRH_OPT_KERNEL */
 	SchedWg schedWg = {70, 160, 120, 16, 768, 4, 12, 12, 8, 192, 1, 16, 32};
 	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
@@ -1023,7 +1047,7 @@ static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
 static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_params *P, const BlockQueue &Q, float *dev_fb, int chunk) {
 	const bool wg = c->kernel == CRH_KERNEL_WG;
 #define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
-												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues)
+												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
 #define CRH_LAUNCH_WG(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_wg<LEVEL, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 													  c->dCounters, c->dStage, chunk, c->schedWg, c->dQueues, c->dOvf, c->dErr)
@@ -1066,12 +1090,14 @@ static int preloadKernel(crh_ctx *c) {
 	memset(&Q, 0, sizeof(Q));
 	Q.counter = c->dWork;                 /* any valid counter: total = 0, every wave leaves at once */
 	Q.bw = Q.bh = Q.sbw = Q.sbh = Q.tbw = Q.tbh = 1;
-	if (c->kernel == CRH_KERNEL_WG && !c->dOvf) {
-		HIP_TRY(hipMalloc((void **)&c->dOvf, (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u * sizeof(uint32_t)));
-		c->ovfWords = (size_t)(CRH_BLOCK / 64) * CRH_WG_OVF * 64u;
-	}
-	/* the per-wave path tables and sample slabs of a full-size dispatch at the default unit size: allocated here rather than by the first frame */
+	/* the per-wave path tables, stack-overflow columns and sample slabs of a full-size dispatch at the default unit size: allocated here rather than by the first frame */
 	const size_t waves = (size_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
+	if (waves * CRH_OVF_WORDS_PER_WAVE > c->ovfWords) {
+		if (c->dOvf) HIP_TRY(hipFree(c->dOvf));
+		c->dOvf = nullptr; c->ovfWords = 0;
+		HIP_TRY(hipMalloc((void **)&c->dOvf, waves * CRH_OVF_WORDS_PER_WAVE * sizeof(uint32_t)));
+		c->ovfWords = waves * CRH_OVF_WORDS_PER_WAVE;
+	}
 	if (waves * CRH_WAVE_QUEUE_FLOATS > c->queueFloats) {
 		if (c->dQueues) HIP_TRY(hipFree(c->dQueues));
 		c->dQueues = nullptr; c->queueFloats = 0;
@@ -1419,8 +1445,8 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		}
 	}
 
-	if (wg) {
-		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_WG_OVF * 64u;
+	{
+		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_OVF_WORDS_PER_WAVE;
 		if (need > c->ovfWords) {
 			HIP_TRY(hipStreamSynchronize(c->stream));
 			if (c->dOvf) HIP_TRY(hipFree(c->dOvf));

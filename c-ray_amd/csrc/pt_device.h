@@ -1334,9 +1334,7 @@ CRH_DEV void foldBlockPixel(const crh_render_params &P, const BlockJob &J, uint3
 	int k = 0;
 	for (; k + 8 <= J.passCount; k += 8) {
 		float s[24];
-#pragma unroll
 		for (int i = 0; i < 24; ++i) s[i] = sp[3 * k + i];
-#pragma unroll
 		for (int j = 0; j < 8; ++j) foldSample(r, g, b, s[3 * j], s[3 * j + 1], s[3 * j + 2], J.passBegin + k + j + 1);
 	}
 	for (; k < J.passCount; ++k) foldSample(r, g, b, sp[3 * k], sp[3 * k + 1], sp[3 * k + 2], J.passBegin + k + 1);

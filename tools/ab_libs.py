@@ -15,6 +15,9 @@ if os.environ.get("AB_CHILD"):
     quick = os.environ.get("AB_QUICK") == "1"
     ctx = api.Context(0)
     ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
+    if os.environ.get("AB_SCHED"):                 # "fill_to,shade_min" (NAME.env of a build)
+        f, sm = (int(v) for v in os.environ["AB_SCHED"].split(","))
+        ctx.set_sched(70, 160, 120, 16, fill_to=f, shade_min=sm)
     res = {}
     for name, w, h, spp, b, reps in (CASES[:3] if quick else CASES):
         path = os.path.join(BUILT, name + ".blob")

@@ -7,7 +7,7 @@ from __graft_entry__ import load_package, BUILT
 pkg = load_package(); api = pkg.api; abi = pkg.abi
 ctx = api.Context(0)
 ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
-for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("soup_1m", 2560, 1440, 16, 8)):
+for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("cfg3_venus", 1920, 1080, 16, 32), ("soup_1m", 2560, 1440, 16, 8)):
     scene = api.Scene(os.path.join(BUILT, name + ".blob"))
     ctx.upload(scene)
     fb = ctx.framebuffer(w, h)

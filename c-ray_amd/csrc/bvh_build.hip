@@ -133,46 +133,65 @@ __device__ inline float binHalfArea(const LaneBin &v) {
 	const float ex = v.hi[0] - v.lo[0], ey = v.hi[1] - v.lo[1], ez = v.hi[2] - v.lo[2];
 	return ex * (ey + ez) + ey * ez;                                     /* bbox.h:25-28 */
 }
-/* fold(bin 0, ..., bin b) in ascending order */
-__device__ inline LaneBin scanAscPrefix(LaneBin v, int b) {
-	for (int off = 1; off < CRH_BVH_BINS; off <<= 1) { const LaneBin o = binFrom(v, (b - off) & 31); if (b >= off) v = binJoin(o, v); }
-	return v;
+/* Inclusive scan over the 32 lanes of each half-wave with DPP data movement (no LDS round trips): row_shr 1, 2, 4, 8 inside the
+ * 16-lane rows, then row_bcast15 hands row 0's total to row 1 (and row 2's to row 3). OWN_FIRST = false: result(l) = fold(v[0], ...,
+ * v[l]) in lane order; OWN_FIRST = true: the operands the other way round, fold(v[l], v[l-1], ..., v[0]) — binJoin is associative but on
+ * ties the later operand wins, so the order is part of the result. */
+template <int CTRL, int ROW_MASK>
+__device__ inline LaneBin dppFetch(const LaneBin &v) {
+	LaneBin r;
+	for (int k = 0; k < 3; ++k) {
+		r.lo[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v.lo[k]), __float_as_int(v.lo[k]), CTRL, ROW_MASK, 0xF, false));
+		r.hi[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v.hi[k]), __float_as_int(v.hi[k]), CTRL, ROW_MASK, 0xF, false));
+	}
+	r.n = (uint32_t)__builtin_amdgcn_update_dpp((int)v.n, (int)v.n, CTRL, ROW_MASK, 0xF, false);
+	return r;
 }
-/* fold(bin 31, bin 30, ..., bin b) — the right-to-left sweep's order (bvh.c:170-177) */
-__device__ inline LaneBin scanDescSuffix(LaneBin v, int b) {
-	for (int off = 1; off < CRH_BVH_BINS; off <<= 1) { const LaneBin o = binFrom(v, (b + off) & 31); if (b + off < CRH_BVH_BINS) v = binJoin(o, v); }
-	return v;
-}
-/* fold(bin b, bin b+1, ..., bin 31) in ascending order — the right child's box (bvh.c:231-232) */
-__device__ inline LaneBin scanAscSuffix(LaneBin v, int b) {
-	for (int off = 1; off < CRH_BVH_BINS; off <<= 1) { const LaneBin o = binFrom(v, (b + off) & 31); if (b + off < CRH_BVH_BINS) v = binJoin(v, o); }
+template <bool OWN_FIRST>
+__device__ inline LaneBin scan32(LaneBin v) {
+	const uint32_t inRow = threadIdx.x & 15u;
+#define CRH_SCAN_STEP(N) { const LaneBin o = dppFetch<0x110 + N, 0xF>(v); if (inRow >= N) v = OWN_FIRST ? binJoin(v, o) : binJoin(o, v); }
+	CRH_SCAN_STEP(1) CRH_SCAN_STEP(2) CRH_SCAN_STEP(4) CRH_SCAN_STEP(8)
+#undef CRH_SCAN_STEP
+	const LaneBin o = dppFetch<0x142, 0xA>(v);              /* row_bcast15 into rows 1 and 3 */
+	if (threadIdx.x & 16u) v = OWN_FIRST ? binJoin(v, o) : binJoin(o, v);
 	return v;
 }
 
 /* All 64 lanes call this with the node's 3 x 32 bins readable through bins / cnts (LDS or global). Returns bvh.c:148-233's
- * outcome in every lane. */
+ * outcome in every lane. Lane b of each half-wave holds bin b ("forward") and bin 31 - b ("reversed"): with the reversed copy the
+ * right-to-left sweep and the right child's fold are prefix scans too. */
+__device__ inline LaneBin loadLaneBin(const BinKeys *bins, const uint32_t *cnts, int idx) {
+	LaneBin v;
+	const BinKeys k = bins[idx];
+	for (int c = 0; c < 3; ++c) { v.lo[c] = keyValue(k.lo[c]); v.hi[c] = keyValue(k.hi[c]); }
+	v.n = cnts[idx];
+	return v;
+}
 __device__ inline Decision waveDecide(const BinKeys *bins, const uint32_t *cnts, const float *bounds, uint32_t n) {
 	const int b = (int)(threadIdx.x & 31u);
+	const bool upper = (threadIdx.x & 32u) != 0u;
 	float bestCost[3];
 	uint32_t bestBin[3];
-	LaneBin mine[3];
+	LaneBin leftOf[3];                       /* meaningful in the lower half-wave: lane b holds fold(bin 0 ... b) */
 	for (int ax = 0; ax < 3; ++ax) {
-		const BinKeys k = bins[ax * CRH_BVH_BINS + b];
-		for (int c = 0; c < 3; ++c) { mine[ax].lo[c] = keyValue(k.lo[c]); mine[ax].hi[c] = keyValue(k.hi[c]); }
-		mine[ax].n = cnts[ax * CRH_BVH_BINS + b];
-		const LaneBin right = scanDescSuffix(mine[ax], b);                /* bvh.c:170-177: bins[b].cost for b >= 1 */
-		const float costR = right.n * binHalfArea(right);
-		const LaneBin left = scanAscPrefix(mine[ax], b);                  /* bvh.c:180-191 */
-		const float costRnext = __shfl(costR, (b + 1) & 31, 32);
-		const float cost = left.n * binHalfArea(left) + costRnext;
-		/* first b in 0..30 with the smallest cost below FLT_MAX (strict <, NaN never wins); none -> (FLT_MAX, bin 1) */
+		/* ONE scan serves both sweeps: the lower half-wave holds the bins forward (lane b: fold(bin 0 ... b), bvh.c:180-191), the upper
+		 * half reversed (lane 32 + r: fold(bin 31, 30, ..., 31 - r), bvh.c:170-177) */
+		const LaneBin both = scan32<false>(loadLaneBin(bins, cnts, ax * CRH_BVH_BINS + (upper ? 31 - b : b)));
+		leftOf[ax] = both;
+		const float part = both.n * binHalfArea(both);                        /* lower: left cost of bin b; upper: bins[31 - r].cost */
+		const float costRnext = __shfl(part, 32 + ((30 - b) & 31), 64);       /* bins[b + 1].cost sits in upper lane 31 - (b + 1) */
+		const float cost = part + costRnext;
+		/* first b in 0..30 with the smallest cost below FLT_MAX (strict <, NaN never wins); none -> (FLT_MAX, bin 1). Reduced in the
+		 * lower half (the xor partners of a lane below 32 are below 32), then handed to every lane */
 		float c = (b <= 30 && cost < FLT_MAX) ? cost : __builtin_inff();
 		int at = b;
 		for (int off = 16; off > 0; off >>= 1) {
-			const float c2 = __shfl_xor(c, off, 32);
-			const int at2 = __shfl_xor(at, off, 32);
+			const float c2 = __shfl_xor(c, off, 64);
+			const int at2 = __shfl_xor(at, off, 64);
 			if (c2 < c || (c2 == c && at2 < at)) { c = c2; at = at2; }
 		}
+		c = __shfl(c, 0, 64); at = __shfl(at, 0, 64);
 		if (c < FLT_MAX) { bestCost[ax] = c; bestBin[ax] = (uint32_t)at + 1u; }
 		else { bestCost[ax] = FLT_MAX; bestBin[ax] = 1u; }
 	}
@@ -181,28 +200,35 @@ __device__ inline Decision waveDecide(const BinKeys *bins, const uint32_t *cnts,
 	if (bestCost[1] < bestCost[0]) ax = 1;
 	if (bestCost[2] < bestCost[ax]) ax = 2;
 	uint32_t split = bestBin[ax];
-	const LaneBin own = ax == 0 ? mine[0] : (ax == 1 ? mine[1] : mine[2]);
-	const LaneBin left = scanAscPrefix(own, b);
+	const LaneBin left = ax == 0 ? leftOf[0] : (ax == 1 ? leftOf[1] : leftOf[2]);
 	Box self;
 	for (int k = 0; k < 3; ++k) { self.lo[k] = bounds[2 * k]; self.hi[k] = bounds[2 * k + 1]; }
 	const float leafCost = boxHalfArea(self) * (n - 1.5f);               /* bvh.c:200 */
-	d.leaf = 0;
+	d.leaf = 0; d.axis = ax; d.nLeft = 0;
+	for (int k = 0; k < 6; ++k) { d.childL[k] = 0.0f; d.childR[k] = 0.0f; }
 	if (bestCost[ax] > leafCost) {
 		if (n > CRH_BVH_MAX_LEAF) {                                      /* bvh.c:202-211: first bin boundary nearest the median, if nearer than n */
 			const int diff = (int)n / 2 - (int)left.n;
 			uint32_t off = (b <= 30) ? (uint32_t)(diff < 0 ? -diff : diff) : 0xFFFFFFFFu;
 			int at = b;
 			for (int sh = 16; sh > 0; sh >>= 1) {
-				const uint32_t o2 = __shfl_xor(off, sh, 32);
-				const int at2 = __shfl_xor(at, sh, 32);
+				const uint32_t o2 = __shfl_xor(off, sh, 64);
+				const int at2 = __shfl_xor(at, sh, 64);
 				if (o2 < off || (o2 == off && at2 < at)) { off = o2; at = at2; }
 			}
+			off = __shfl(off, 0, 64); at = __shfl(at, 0, 64);
 			if (off < n) split = (uint32_t)at + 1u;
-		} else d.leaf = 1;
+		} else {                                                         /* bvh.c:212-214: a leaf; the child boxes are not needed */
+			d.leaf = 1; d.split = split;
+			return d;
+		}
 	}
-	d.axis = ax; d.split = split;
-	const LaneBin l = binFrom(left, (int)split - 1);                     /* bvh.c:226-233 */
-	const LaneBin r = binFrom(scanAscSuffix(own, b), (int)(split & 31u));
+	d.split = split;
+	LaneBin l;                                                           /* bvh.c:226-233: fold(bin 0 ... split - 1) from the lower half */
+	for (int k = 0; k < 3; ++k) { l.lo[k] = __shfl(left.lo[k], (int)split - 1, 64); l.hi[k] = __shfl(left.hi[k], (int)split - 1, 64); }
+	l.n = __shfl(left.n, (int)split - 1, 64);
+	/* right child: fold(bin split, ..., 31) in ascending order = lane 31 - split of the own-first scan over the reversed copy */
+	const LaneBin r = binFrom(scan32<true>(loadLaneBin(bins, cnts, (int)ax * CRH_BVH_BINS + 31 - b)), (int)((31u - split) & 31u));
 	d.nLeft = l.n;
 	if (l.n == 0) d.leaf = 1;                                            /* bvh.c:218, 239-241: beginRight == begin */
 	for (int k = 0; k < 3; ++k) {
@@ -271,9 +297,8 @@ __global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk
 	__syncthreads();
 	for (uint32_t q = threadIdx.x; q < ch.len; q += blockDim.x) {
 		const uint32_t p = ch.start + q;
-		const int32_t id = prims[p];
-		float lo[3], hi[3], ce[3];
-		for (int k = 0; k < 3; ++k) { lo[k] = boxes[6 * (size_t)id + k]; hi[k] = boxes[6 * (size_t)id + 3 + k]; ce[k] = centers[3 * (size_t)id + k]; }
+		float lo[3], hi[3], ce[3];        /* boxes / centers travel with the index range (k_swap): position p holds the data of prims[p] */
+		for (int k = 0; k < 3; ++k) { lo[k] = boxes[6 * (size_t)p + k]; hi[k] = boxes[6 * (size_t)p + 3 + k]; ce[k] = centers[3 * (size_t)p + k]; }
 		for (int ax = 0; ax < 3; ++ax) {
 			const uint32_t b = ax * CRH_BVH_BINS + binOf(ce[ax], nd.bounds[2 * ax], nd.bounds[2 * ax + 1]);
 			for (int k = 0; k < 3; ++k) { atomicMin(&s_bins[b].lo[k], keyLo(lo[k], p)); atomicMax(&s_bins[b].hi[k], keyHi(hi[k], p)); }
@@ -312,7 +337,7 @@ __global__ __launch_bounds__(256) void k_count_misplaced(const LargeNode *nodes,
 		uint32_t ml = 0, mr = 0;
 		for (uint32_t q = threadIdx.x; q < ch.len; q += blockDim.x) {
 			const uint32_t p = ch.start + q;
-			const bool right = binOf(centers[3 * (size_t)prims[p] + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
+			const bool right = binOf(centers[3 * (size_t)p + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
 			if (p < mid && right) ++ml;
 			if (p >= mid && !right) ++mr;
 		}
@@ -326,13 +351,29 @@ __global__ __launch_bounds__(256) void k_count_misplaced(const LargeNode *nodes,
 /* (3b) per node: exclusive prefix of its chunks' counts (left-misplaced from the left, right-misplaced from the right) */
 __global__ __launch_bounds__(64) void k_scan_chunks(const uint32_t *nodeChunk0, uint32_t nNodes, uint32_t *chunkML, uint32_t *chunkMR, uint32_t *nodeSwaps) {
 	const uint32_t n = blockIdx.x;
-	if (n >= nNodes || threadIdx.x) return;
+	if (n >= nNodes) return;
+	const uint32_t lane = threadIdx.x;
 	const uint32_t c0 = nodeChunk0[n], c1 = nodeChunk0[n + 1];
 	uint32_t acc = 0;
-	for (uint32_t c = c0; c < c1; ++c) { const uint32_t v = chunkML[c]; chunkML[c] = acc; acc += v; }
+	for (uint32_t c = c0; c < c1; c += 64u) {                 /* 64 chunks per step: wave-wide inclusive scan, carried total */
+		const bool in = c + lane < c1;
+		const uint32_t v = in ? chunkML[c + lane] : 0u;
+		uint32_t incl = v;
+		for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
+		if (in) chunkML[c + lane] = acc + incl - v;
+		acc += __shfl(incl, 63);
+	}
 	uint32_t accR = 0;
-	for (uint32_t c = c1; c > c0; --c) { const uint32_t v = chunkMR[c - 1]; chunkMR[c - 1] = accR; accR += v; }
-	nodeSwaps[n] = acc;        /* == accR: as many left-misplaced as right-misplaced */
+	for (uint32_t done = 0; c0 + done < c1; done += 64u) {     /* the same from the right end */
+		const bool in = c0 + done + lane < c1;
+		const uint32_t c = in ? c1 - 1u - done - lane : c0;
+		const uint32_t v = in ? chunkMR[c] : 0u;
+		uint32_t incl = v;
+		for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
+		if (in) chunkMR[c] = accR + incl - v;
+		accR += __shfl(incl, 63);
+	}
+	if (lane == 0) nodeSwaps[n] = acc;        /* == accR: as many left-misplaced as right-misplaced */
 }
 
 /* (3c) per chunk: the k-th left-misplaced position goes to listL[begin + k], the k-th right-misplaced FROM THE RIGHT to listR[begin + k] */
@@ -350,7 +391,7 @@ __global__ __launch_bounds__(256) void k_list_misplaced(const LargeNode *nodes, 
 	uint32_t ml = 0, mr = 0;
 	for (uint32_t q = q0; q < q1; ++q) {
 		const uint32_t p = ch.start + q;
-		const bool right = binOf(centers[3 * (size_t)prims[p] + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
+		const bool right = binOf(centers[3 * (size_t)p + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
 		if (p < mid && right) ++ml;
 		if (p >= mid && !right) ++mr;
 	}
@@ -377,14 +418,14 @@ __global__ __launch_bounds__(256) void k_list_misplaced(const LargeNode *nodes, 
 	uint32_t kR = chunkMR[blockIdx.x] + s_scan[threadIdx.x];        /* inclusive from the right: rank of this thread's LAST position + 1 ... */
 	for (uint32_t q = q0; q < q1; ++q) {
 		const uint32_t p = ch.start + q;
-		const bool right = binOf(centers[3 * (size_t)prims[p] + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
+		const bool right = binOf(centers[3 * (size_t)p + d.axis], nd.bounds[2 * d.axis], nd.bounds[2 * d.axis + 1]) >= d.split;
 		if (p < mid && right) listL[nd.begin + kL++] = p;
 		if (p >= mid && !right) listR[nd.begin + --kR] = p;          /* ... so ascending positions get descending ranks */
 	}
 }
 
 /* (3d) the swaps of bvh.c:121-123, all independent */
-__global__ __launch_bounds__(256) void k_swap(const LargeNode *nodes, const Decision *dec, const Chunk *chunks, const uint32_t *nodeSwaps, const uint32_t *listL, const uint32_t *listR, int32_t *prims) {
+__global__ __launch_bounds__(256) void k_swap(const LargeNode *nodes, const Decision *dec, const Chunk *chunks, const uint32_t *nodeSwaps, const uint32_t *listL, const uint32_t *listR, int32_t *prims, float *boxes, float *centers) {
 	const Chunk ch = chunks[blockIdx.x];
 	if (dec[ch.node].leaf) return;
 	const LargeNode nd = nodes[ch.node];
@@ -394,6 +435,8 @@ __global__ __launch_bounds__(256) void k_swap(const LargeNode *nodes, const Deci
 		if (k >= m) continue;
 		const uint32_t a = listL[nd.begin + k], b = listR[nd.begin + k];
 		const int32_t t = prims[a]; prims[a] = prims[b]; prims[b] = t;
+		for (int c = 0; c < 6; ++c) { const float f = boxes[6 * (size_t)a + c]; boxes[6 * (size_t)a + c] = boxes[6 * (size_t)b + c]; boxes[6 * (size_t)b + c] = f; }
+		for (int c = 0; c < 3; ++c) { const float f = centers[3 * (size_t)a + c]; centers[3 * (size_t)a + c] = centers[3 * (size_t)b + c]; centers[3 * (size_t)b + c] = f; }
 	}
 }
 
@@ -405,14 +448,19 @@ struct SmallRoot { float bounds[6]; uint32_t begin, end, depth, forceLeaf; uint3
  * pairs are appended in allocation order, inner nodes point at LOCAL indices. Roots that are leaves by rule (depth limit,
  * fewer than two primitives, or a large node whose split left nothing on the left: forceLeaf) are emitted directly. */
 __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t nRoots, int32_t *prims, const float *boxes, const float *centers,
-											  crh_bvh_node *local, uint32_t *localCount) {
-	__shared__ int32_t s_prim[CRH_BVH_SMALL];
+											  crh_bvh_node *local, uint32_t *localCount, unsigned long long *prof) {
+	/* the index range is kept as SLOT numbers (= position at load time): boxes[] / centers[] are in position order (k_swap moves them
+	 * with the indices), so slot s of this subtree has its data at base + s — 18 KB of contiguous, cache-resident records per subtree.
+	 * (Keeping those records in LDS instead was measured: 30 KB per wave leaves 5 waves per CU, and the build got slower.) */
+	__shared__ uint16_t s_prim[CRH_BVH_SMALL];
 	__shared__ BinKeys s_bins[3 * CRH_BVH_BINS];
 	__shared__ uint32_t s_cnt[3 * CRH_BVH_BINS];
 	__shared__ Decision s_dec;
-	__shared__ uint16_t s_listL[CRH_BVH_SMALL], s_listR[CRH_BVH_SMALL];
-	struct Job { uint32_t node, first, last, depth; };
-	__shared__ Job s_stack[2 * CRH_BVH_MAX_DEPTH + 4];
+	/* the rank lists of the partition live where the bins were (the decision has consumed them): 8 KB of LDS per wave, 19 waves per CU */
+	static_assert(2 * CRH_BVH_SMALL * sizeof(uint16_t) <= sizeof(BinKeys) * 3 * CRH_BVH_BINS, "rank lists alias the bins");
+	uint16_t *const s_listL = reinterpret_cast<uint16_t *>(s_bins), *const s_listR = s_listL + CRH_BVH_SMALL;
+	struct Job { uint16_t node, first, last, depth; float bounds[6]; };
+	__shared__ Job s_stack[CRH_BVH_MAX_DEPTH + 8];          /* depth-first: one waiting right sibling per level, plus the job on top */
 	const uint32_t r = blockIdx.x;
 	if (r >= nRoots) return;
 	const uint32_t lane = threadIdx.x;
@@ -430,21 +478,27 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 		}
 		return;
 	}
-	for (uint32_t i = lane; i < total; i += 64) s_prim[i] = prims[base + i];
+	for (uint32_t i = lane; i < total; i += 64) s_prim[i] = (uint16_t)i;
 	if (lane == 0) {
 		crh_bvh_node n0;
 		memset(&n0, 0, sizeof(n0));
 		for (int k = 0; k < 6; ++k) n0.bounds[k] = root.bounds[k];
 		out[0] = n0;
-		s_stack[0] = Job{0u, 0u, total, root.depth};
+		Job j0;
+		j0.node = 0; j0.first = 0; j0.last = (uint16_t)total; j0.depth = (uint16_t)root.depth;
+		for (int k = 0; k < 6; ++k) j0.bounds[k] = root.bounds[k];
+		s_stack[0] = j0;
 	}
 	__syncthreads();
 	uint32_t sp = 1, used = 1;
+	unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     /* CRH_BVH_TRACE: wall-clock ticks per part (lane 0 of every wave) */
+	unsigned long long pc = prof ? wall_clock64() : 0ull;
+#define CRH_PROF(i) do { if (prof) { const unsigned long long now_ = wall_clock64(); pt[i] += now_ - pc; pc = now_; } } while (0)
 	while (sp) {
 		const Job j = s_stack[--sp];
-		const uint32_t n = j.last - j.first;
+		const uint32_t first = j.first, last = j.last, n = last - first;
 		float bounds[6];
-		for (int k = 0; k < 6; ++k) bounds[k] = out[j.node].bounds[k];
+		for (int k = 0; k < 6; ++k) bounds[k] = j.bounds[k];
 		bool leaf = (j.depth >= CRH_BVH_MAX_DEPTH || n < 2);                 /* bvh.c:143-146 */
 		if (!leaf) {
 			for (uint32_t i = lane; i < 3 * CRH_BVH_BINS; i += 64) {
@@ -452,10 +506,10 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 				s_cnt[i] = 0;
 			}
 			__syncthreads();
-			for (uint32_t q = j.first + lane; q < j.last; q += 64) {         /* bvh.c:158-165 */
-				const int32_t id = s_prim[q];
+			for (uint32_t q = first + lane; q < last; q += 64) {             /* bvh.c:158-165; the tie order is the position in the range */
+				const size_t at = (size_t)base + s_prim[q];
 				float lo[3], hi[3], ce[3];
-				for (int k = 0; k < 3; ++k) { lo[k] = boxes[6 * (size_t)id + k]; hi[k] = boxes[6 * (size_t)id + 3 + k]; ce[k] = centers[3 * (size_t)id + k]; }
+				for (int k = 0; k < 3; ++k) { lo[k] = boxes[6 * at + k]; hi[k] = boxes[6 * at + 3 + k]; ce[k] = centers[3 * at + k]; }
 				for (int ax = 0; ax < 3; ++ax) {
 					const uint32_t b = ax * CRH_BVH_BINS + binOf(ce[ax], bounds[2 * ax], bounds[2 * ax + 1]);
 					for (int k = 0; k < 3; ++k) { atomicMin(&s_bins[b].lo[k], keyLo(lo[k], q)); atomicMax(&s_bins[b].hi[k], keyHi(hi[k], q)); }
@@ -463,34 +517,39 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 				}
 			}
 			__syncthreads();
+			CRH_PROF(2);
 			{
 				const Decision dd = waveDecide(s_bins, s_cnt, bounds, n);
 				if (lane == 0) s_dec = dd;
 			}
 			__syncthreads();
+			CRH_PROF(3);
 			leaf = s_dec.leaf != 0;
 		}
 		if (leaf) {
-			if (lane == 0) { out[j.node].first = base + j.first; out[j.node].count_leaf = (n & 0x3FFFFFFFu) | (1u << 30); }
+			if (lane == 0) { out[j.node].first = base + first; out[j.node].count_leaf = (n & 0x3FFFFFFFu) | (1u << 30); }
 			__syncthreads();
+			CRH_PROF(0);
 			continue;
 		}
 		const Decision d = s_dec;
-		const uint32_t mid = j.first + d.nLeft;
+		const uint32_t mid = first + d.nLeft;
+		const float aLo = bounds[2 * d.axis], aHi = bounds[2 * d.axis + 1];
+		const float *ce = centers + 3 * (size_t)base + d.axis;          /* centre of slot s along the split axis: ce[3 * s] */
 		/* bvh.c:95-130: k-th misplaced from the left <-> k-th misplaced from the right */
 		uint32_t kL = 0, kR = 0;
-		for (uint32_t q0 = j.first; q0 < mid; q0 += 64) {
+		for (uint32_t q0 = first; q0 < mid; q0 += 64) {
 			const uint32_t q = q0 + lane;
-			const bool mis = q < mid && binOf(centers[3 * (size_t)s_prim[q < mid ? q : j.first] + d.axis], bounds[2 * d.axis], bounds[2 * d.axis + 1]) >= d.split;
+			const bool mis = q < mid && binOf(ce[3u * s_prim[q < mid ? q : first]], aLo, aHi) >= d.split;
 			const unsigned long long m = __ballot(mis);
 			if (mis) s_listL[kL + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)q;
 			kL += (uint32_t)__popcll(m);
 		}
-		for (uint32_t done = 0; mid + done < j.last; done += 64) {           /* from the right end downwards */
+		for (uint32_t done = 0; mid + done < last; done += 64) {             /* from the right end downwards */
 			const uint32_t off = done + lane;
-			const bool in = mid + off < j.last;
-			const uint32_t q = in ? j.last - 1u - off : mid;
-			const bool mis = in && binOf(centers[3 * (size_t)s_prim[q] + d.axis], bounds[2 * d.axis], bounds[2 * d.axis + 1]) < d.split;
+			const bool in = mid + off < last;
+			const uint32_t q = in ? last - 1u - off : mid;
+			const bool mis = in && binOf(ce[3u * s_prim[q]], aLo, aHi) < d.split;
 			const unsigned long long m = __ballot(mis);
 			if (mis) s_listR[kR + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)q;
 			kR += (uint32_t)__popcll(m);
@@ -498,7 +557,7 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 		__syncthreads();
 		for (uint32_t k = lane; k < kL; k += 64) {
 			const uint32_t a = s_listL[k], b = s_listR[k];
-			const int32_t t = s_prim[a]; s_prim[a] = s_prim[b]; s_prim[b] = t;
+			const uint16_t t = s_prim[a]; s_prim[a] = s_prim[b]; s_prim[b] = t;
 		}
 		if (lane == 0) {                                                     /* bvh.c:219-238 */
 			crh_bvh_node l, rr;
@@ -507,14 +566,26 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 			out[used] = l; out[used + 1] = rr;
 			out[j.node].first = used;
 			out[j.node].count_leaf = 0;
-			s_stack[sp] = Job{used + 1, mid, j.last, j.depth + 1};          /* right waits ... */
-			s_stack[sp + 1] = Job{used, j.first, mid, j.depth + 1};         /* ... left is built first */
+			Job jr, jl;
+			jr.node = (uint16_t)(used + 1); jr.first = (uint16_t)mid; jr.last = (uint16_t)last; jr.depth = (uint16_t)(j.depth + 1);
+			jl.node = (uint16_t)used; jl.first = (uint16_t)first; jl.last = (uint16_t)mid; jl.depth = (uint16_t)(j.depth + 1);
+			for (int k = 0; k < 6; ++k) { jr.bounds[k] = d.childR[k]; jl.bounds[k] = d.childL[k]; }
+			s_stack[sp] = jr;              /* right waits ... */
+			s_stack[sp + 1] = jl;          /* ... left is built first */
 		}
 		sp += 2; used += 2;
 		__syncthreads();
+		CRH_PROF(4);
 	}
-	for (uint32_t i = lane; i < total; i += 64) prims[base + i] = s_prim[i];
+	{	/* the index range in its new order: every old entry is read before any is overwritten */
+		int32_t moved[CRH_BVH_SMALL / 64];
+		for (uint32_t k = 0; k < CRH_BVH_SMALL / 64; ++k) { const uint32_t i = k * 64 + lane; moved[k] = i < total ? prims[base + s_prim[i]] : 0; }
+		__syncthreads();
+		for (uint32_t k = 0; k < CRH_BVH_SMALL / 64; ++k) { const uint32_t i = k * 64 + lane; if (i < total) prims[base + i] = moved[k]; }
+	}
 	if (lane == 0) localCount[r] = used;
+	if (prof && lane == 0) for (int i = 0; i < 8; ++i) if (pt[i]) atomicAdd(&prof[i], pt[i]);
+#undef CRH_PROF
 }
 
 /* final numbering: subtree r's local node 0 is global node rootId[r]; local node j >= 1 is global node firstId[r] + j - 1 */
@@ -656,7 +727,7 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 		hipLaunchKernelGGL(k_count_misplaced, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dPrims.p, dCenters.p, dChunkML.p, dChunkMR.p);
 		hipLaunchKernelGGL(k_scan_chunks, dim3(nNodes), dim3(64), 0, st, dNodeChunk0.p, nNodes, dChunkML.p, dChunkMR.p, dNodeSwaps.p);
 		hipLaunchKernelGGL(k_list_misplaced, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dPrims.p, dCenters.p, dChunkML.p, dChunkMR.p, dListL.p, dListR.p);
-		hipLaunchKernelGGL(k_swap, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dNodeSwaps.p, dListL.p, dListR.p, dPrims.p);
+		hipLaunchKernelGGL(k_swap, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dNodeSwaps.p, dListL.p, dListR.p, dPrims.p, dBoxes.p, dCenters.p);
 		BVH_TRY(hipGetLastError());
 		std::vector<Decision> hDec(nNodes);
 		BVH_TRY(hipMemcpyAsync(hDec.data(), dDec.p, nNodes * sizeof(Decision), hipMemcpyDeviceToHost, st));
@@ -687,12 +758,20 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	DevBuf<SmallRoot> dRoots; DevBuf<uint32_t> dLocalCount, dRootId, dFirstId;
 	BVH_TRY(dLocal.alloc(localNodes)); BVH_TRY(dRoots.alloc(nRoots)); BVH_TRY(dLocalCount.alloc(nRoots)); BVH_TRY(dRootId.alloc(nRoots)); BVH_TRY(dFirstId.alloc(nRoots));
 	BVH_TRY(hipMemcpyAsync(dRoots.p, smallRoots.data(), nRoots * sizeof(SmallRoot), hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_small, dim3(nRoots), dim3(64), 0, st, dRoots.p, nRoots, dPrims.p, dBoxes.p, dCenters.p, dLocal.p, dLocalCount.p);
+	DevBuf<unsigned long long> dProf;
+	if (trace) { BVH_TRY(dProf.alloc(8)); BVH_TRY(hipMemsetAsync(dProf.p, 0, 8 * sizeof(unsigned long long), st)); }
+	hipLaunchKernelGGL(k_small, dim3(nRoots), dim3(64), 0, st, dRoots.p, nRoots, dPrims.p, dBoxes.p, dCenters.p, dLocal.p, dLocalCount.p, trace ? dProf.p : nullptr);
 	BVH_TRY(hipGetLastError());
 	std::vector<uint32_t> localCount(nRoots);
 	BVH_TRY(hipMemcpyAsync(localCount.data(), dLocalCount.p, nRoots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	BVH_TRY(hipStreamSynchronize(st));
-	if (trace) { const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh small phase: %u subtrees %.3f ms\n", nRoots, std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
+	if (trace) {
+		const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh small phase: %u subtrees %.3f ms\n", nRoots, std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn;
+		unsigned long long hp[8];
+		BVH_TRY(hipMemcpy(hp, dProf.p, sizeof(hp), hipMemcpyDeviceToHost));
+		fprintf(stderr, "  per subtree (10 ns ticks summed over waves / subtrees): leaf pops %.1f us, bin %.1f us, decide %.1f us, partition+emit %.1f us\n",
+				hp[0] * 0.01 / nRoots, hp[2] * 0.01 / nRoots, hp[3] * 0.01 / nRoots, hp[4] * 0.01 / nRoots);
+	}
 
 	/* numbering (bvh.c:221-223, 237-238): depth-first, a pair per split, left subtree before the right one */
 	std::vector<uint32_t> rootId(nRoots), firstId(nRoots);

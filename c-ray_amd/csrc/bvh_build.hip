@@ -274,7 +274,7 @@ struct LargeNode {            /* device mirror of one node of the current level 
 	float bounds[6];
 	uint32_t begin, end;
 };
-struct Chunk { uint32_t node, start, len, pad; };   /* positions [start, start+len) of prims[], all inside level node `node` */
+struct Chunk { uint32_t node, start, len, single; };   /* positions [start, start+len) of prims[], all inside level node `node`; single: the node's only chunk */
 
 __global__ void k_init_bins(BinKeys *bins, uint32_t *counts, uint32_t nBins) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,8 +307,13 @@ __global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk
 	}
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < 3 * CRH_BVH_BINS; i += blockDim.x) {
-		if (!s_cnt[i]) continue;
 		const size_t g = (size_t)ch.node * 3 * CRH_BVH_BINS + i;
+		if (ch.single) {                 /* the node's only chunk: these ARE its bins (most nodes of the deep levels) — plain stores, no atomics */
+			gbins[g] = s_bins[i];
+			gcounts[g] = s_cnt[i];
+			continue;
+		}
+		if (!s_cnt[i]) continue;
 		for (int c = 0; c < 3; ++c) { atomicMin(&gbins[g].lo[c], s_bins[i].lo[c]); atomicMax(&gbins[g].hi[c], s_bins[i].hi[c]); }
 		atomicAdd(&gcounts[g], s_cnt[i]);
 	}
@@ -691,6 +696,15 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	auto tl = std::chrono::steady_clock::now();
 	DevBuf<LargeNode> dLevel; DevBuf<Chunk> dChunks; DevBuf<BinKeys> dBins; DevBuf<uint32_t> dCounts, dChunkML, dChunkMR, dNodeChunk0, dNodeSwaps; DevBuf<Decision> dDec;
 	size_t capNodes = 0, capChunks = 0;
+	{	/* level scratch for the whole build at once (a level's nodes hold > CRH_BVH_SMALL primitives each, its chunks are whole or node tails):
+		 * growing it level by level put a hipFree + hipMalloc into every second level */
+		capNodes = (size_t)N / CRH_BVH_SMALL + 64;
+		capChunks = (size_t)N / CRH_BVH_CHUNK + capNodes + 64;
+		BVH_TRY(dLevel.alloc(capNodes)); BVH_TRY(dBins.alloc(capNodes * 3 * CRH_BVH_BINS)); BVH_TRY(dCounts.alloc(capNodes * 3 * CRH_BVH_BINS));
+		BVH_TRY(dDec.alloc(capNodes)); BVH_TRY(dNodeChunk0.alloc(capNodes + 1)); BVH_TRY(dNodeSwaps.alloc(capNodes));
+		BVH_TRY(dChunks.alloc(capChunks)); BVH_TRY(dChunkML.alloc(capChunks)); BVH_TRY(dChunkMR.alloc(capChunks));
+	}
+	const uint32_t chunkLen = CRH_BVH_CHUNK;      /* larger chunks for the top levels (fewer global-atomic flushes) were measured: slower from level 3 on */
 	while (!level.empty()) {
 		++levels;
 		const std::vector<uint32_t> cur = level;
@@ -704,7 +718,7 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 			memcpy(hNodes[i].bounds, u.bounds, sizeof(u.bounds));
 			hNodes[i].begin = u.begin; hNodes[i].end = u.end;
 			hChunk0[i] = (uint32_t)hChunks.size();
-			for (uint32_t s = u.begin; s < u.end; s += CRH_BVH_CHUNK) hChunks.push_back(Chunk{i, s, std::min(CRH_BVH_CHUNK, u.end - s), 0u});
+			for (uint32_t s = u.begin; s < u.end; s += chunkLen) hChunks.push_back(Chunk{i, s, std::min(chunkLen, u.end - s), u.end - u.begin <= chunkLen ? 1u : 0u});
 		}
 		hChunk0[nNodes] = (uint32_t)hChunks.size();
 		const uint32_t nChunks = (uint32_t)hChunks.size();

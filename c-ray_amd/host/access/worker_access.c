@@ -109,7 +109,9 @@ static void *gpuWorkerThread(void *arg) {
 			bool ok = submitWork(sock, tileBuffer, tile);
 			if (ok) {
 				cJSON *resp = readJSON(sock);
-				ok = resp && stringEquals(cJSON_GetObjectItem(resp, "action")->valuestring, "ok");
+				const cJSON *action = resp ? cJSON_GetObjectItem(resp, "action") : NULL;
+				ok = action && cJSON_IsString(action) && stringEquals(action->valuestring, "ok");
+				if (resp) cJSON_Delete(resp);
 			}
 			releaseMutex(sockMutex);
 			destroyTexture(tileBuffer);

@@ -58,7 +58,7 @@ static int fail(int code, const std::string &msg) { t_err = msg; return code; }
  * access into a flat_load / flat_store. LDS + overflow cover the worst case the scene compiler can report
  * (64 + 5 + 64 + 1, bvh.c:32). The park slots (pt_device.h: PK_*) are LDS too. */
 #define CRH_STACK_OVF (134 - CRH_STACK_LDS)
-#define CRH_OVF_WORDS_PER_WAVE (112u * 64u)    /* overflow columns of one wave in the context's global buffer (both kernel forms: >= 134 - 22 entries x 64 lanes) */
+#define CRH_OVF_WORDS_PER_WAVE (120u * 64u)    /* overflow columns of one wave in the context's global buffer (both kernel forms: >= 134 - 15 entries x 64 lanes, for any CRH_STACK_LDS >= 15) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
 /* k_pathtrace: the overflow entries live in a per-wave column block of a global buffer (entry i of lane l at ovf[(i - CRH_STACK_LDS) * 64]

@@ -21,7 +21,11 @@ if [ -n "$SOUP10M" ]; then
 	timeout 900 tools/make_soup.sh 10000000 /tmp/soup_10m.blob > $O/soup_10m_build.log 2>&1
 	timeout 600 python tools/run_config.py --blob /tmp/soup_10m.blob --width 2560 --height 1440 --spp 16 --bounces 8 --parity-spp 1 --tag soup_10m > $O/soup_10m.json 2> $O/soup10m.err
 	timeout 300 python tools/bvh_bench.py --blob /tmp/soup_10m.blob --tag soup_10m > $O/bvh_build_soup_10m.json 2>&1
+	CRH_BVH_TRACE=1 timeout 300 python tools/bvh_bench.py --blob /tmp/soup_10m.blob --tag soup_10m --no-cpu 2>&1 | tail -20 > $O/bvh_trace_soup_10m.log
 fi
+CRH_BVH_TRACE=1 timeout 300 python tools/bvh_bench.py --blob $B/soup_1m.blob --tag soup_1m --no-cpu 2>&1 | tail -16 > $O/bvh_trace_soup_1m.log
+timeout 300 python tools/probe_exact.py > $O/probe_exact.log 2>&1
+timeout 300 python tools/probe_step_clocks.py > $O/probe_step_clocks.log 2>&1
 timeout 300 python tools/bvh_bench.py --blob $B/soup_1m.blob --tag soup_1m > $O/bvh_build_soup_1m.json 2>&1
 timeout 300 python tools/bvh_bench.py --blob $B/cfg2_hdr.blob --tag cfg2_hdr > $O/bvh_build_cfg2_hdr.json 2>&1
 timeout 300 python tools/probe_share8.py > $O/probe_share8.log 2>&1

@@ -122,6 +122,7 @@ def dropin_timing(workload):
             return {"failed": proc.stdout.decode(errors="replace")[-300:]}
         st = json.load(open(stats))
     return {"program": "c-ray_amd/_lib/c-ray-hip < hdr.json (1 GPU)", "mrays": round(st["rays"] / st["render_ms"] / 1e3, 1), "render_ms": st["render_ms"],
+            "kernel_ms": st.get("kernel_ms"), "launch_host_ms": st.get("launch_host_ms"),
             "context_upload_ms": st["context_upload_ms"], "flatten_ms": st["flatten_ms"], "reduce_download_ms": st["reduce_download_ms"],
             "resolve_srgb_ms": st["resolve_srgb_ms"], "process_wall_s": round(wall, 2), "rays": st["rays"],
             "note": "render_ms = first dispatch to last synchronize inside renderFrame(); context_upload_ms = HIP context creation + layout compile + copies "

@@ -63,6 +63,8 @@ struct gpuWorker {
 	char error[256];      /* crh_last_error() is per thread: the failing dispatch thread keeps its message here */
 	uint64_t rays;
 	long setupUs, renderUs;   /* context + upload + framebuffer; dispatch loop (first launch to last sync) */
+	double kernelMs;          /* GPU time of the dispatches (HIP events around the kernels) */
+	long launchUs;            /* host time inside crh_render_tiles (work list, copies, launch) */
 };
 
 /* passes per dispatch: one dispatch keeps the whole GPU busy from its first work unit to its last (no drain in between), so a
@@ -102,7 +104,8 @@ static void *gpuThread(void *arg) {
 
 	/* counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
 	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_set_option(w->ctx, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK ||
-		crh_scene_upload(w->ctx, w->scene) != CRH_OK || crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK) {
+		crh_scene_upload(w->ctx, w->scene) != CRH_OK || crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK ||
+		crh_synchronize(w->ctx) != CRH_OK) {           /* the scene copies are asynchronous: they belong to the setup, not to the first dispatch */
 		snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 		logr(warning, "GPU %d: %s\n", w->device, w->error);
 		w->failed = 1;
@@ -120,7 +123,11 @@ static void *gpuThread(void *arg) {
 	for (int done = 0; done < r->prefs.sampleCount && r->state.isRendering && !r->state.renderAborted; ) {
 		p.first_pass = done;
 		p.pass_count = r->prefs.sampleCount - done < PASSES_PER_DISPATCH ? r->prefs.sampleCount - done : PASSES_PER_DISPATCH;
-		if (n && (crh_render_tiles(w->ctx, &p, share, n, w->fb) != CRH_OK || crh_synchronize(w->ctx) != CRH_OK)) {
+		struct timeval tl;
+		startTimer(&tl);
+		int rc = n ? crh_render_tiles(w->ctx, &p, share, n, w->fb) : CRH_OK;
+		w->launchUs += getUs(tl);
+		if (n && (rc != CRH_OK || crh_synchronize(w->ctx) != CRH_OK)) {
 			snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 			logr(warning, "GPU %d: %s\n", w->device, w->error);
 			w->failed = 1;
@@ -136,6 +143,7 @@ static void *gpuThread(void *arg) {
 		for (int i = 0; i < r->state.tileCount; ++i) { r->state.renderTiles[i].isRendering = false; r->state.renderTiles[i].renderComplete = true; }
 	crh_counters c;
 	if (!w->failed && crh_counters_get(w->ctx, &c) == CRH_OK) w->rays = c.rays;
+	{ float last = 0.0f; uint64_t launches = 0; if (!w->failed) crh_kernel_time_ms(w->ctx, &last, &w->kernelMs, &launches); }
 	free(share);
 	w->state->currentTileNum = -1;
 	w->state->threadComplete = true;
@@ -300,14 +308,20 @@ struct texture *renderFrame(struct renderer *r) {
 	/* CRH_DUMP_STATS=<path>: where the render phase (src/c-ray.c:279-281) went, for bench.py's `dropin` object */
 	const char *statsPath = getenv("CRH_DUMP_STATS");
 	if (statsPath) {
-		long setupUs = 0, renderUs = 0;
-		for (int g = 0; g < gpus; ++g) { if (workers[g].setupUs > setupUs) setupUs = workers[g].setupUs; if (workers[g].renderUs > renderUs) renderUs = workers[g].renderUs; }
+		long setupUs = 0, renderUs = 0, launchUs = 0;
+		double kernelMs = 0.0;
+		for (int g = 0; g < gpus; ++g) {
+			if (workers[g].setupUs > setupUs) setupUs = workers[g].setupUs;
+			if (workers[g].renderUs > renderUs) renderUs = workers[g].renderUs;
+			if (workers[g].launchUs > launchUs) launchUs = workers[g].launchUs;
+			if (workers[g].kernelMs > kernelMs) kernelMs = workers[g].kernelMs;
+		}
 		FILE *f = fopen(statsPath, "w");
 		if (f) {
 			fprintf(f, "{\"gpus\": %d, \"width\": %d, \"height\": %d, \"samples\": %d, \"bounces\": %d, \"rays\": %llu, \"flatten_ms\": %.3f, "
-					"\"context_upload_ms\": %.3f, \"render_ms\": %.3f, \"reduce_download_ms\": %.3f, \"resolve_srgb_ms\": %.3f}\n",
+					"\"context_upload_ms\": %.3f, \"render_ms\": %.3f, \"kernel_ms\": %.3f, \"launch_host_ms\": %.3f, \"reduce_download_ms\": %.3f, \"resolve_srgb_ms\": %.3f}\n",
 					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, setupUs / 1e3, renderUs / 1e3,
-					gatherUs / 1e3, resolveUs / 1e3);
+					kernelMs, launchUs / 1e3, gatherUs / 1e3, resolveUs / 1e3);
 			fclose(f);
 		}
 	}

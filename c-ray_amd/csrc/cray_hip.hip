@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #define CRH_NCOUNTERS 32
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun; };
+struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, shadeMin; };
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -149,11 +149,14 @@ struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlIn
 #define CRH_PATHS 256u        /* slots per wave = the most paths a wave keeps in flight */
 #define CRH_PATH_F4 8u
 #define CRH_WAVE_QUEUE_FLOATS (CRH_PATHS * CRH_PATH_F4 * 4u)
-/* id stacks (bytes, LDS): rays waiting for a walker, surface hits / misses waiting for shading, free slots */
+/* id stacks (LDS): ids of rays waiting for a walker grow up from byte 0, the free slots grow down from byte 255 (a slot is in
+ * at most one place, so the two never meet); surface hits waiting for shading are 16-bit entries (id | shade class << 8: hits are
+ * shaded in batches of one class, see ST_SHADE); misses are bytes */
 #define CRH_IDS_RAYS 0u
-#define CRH_IDS_HITS 256u      /* < 64 waiting + 64 retired by one SWAP */
-#define CRH_IDS_MISSES 384u
-#define CRH_IDS_FREE 512u
+#define CRH_IDS_FREE_END 256u  /* free slot i (0 = next to be taken) sits at byte FREE_END - freeQ + i */
+#define CRH_IDS_HITS 256u      /* 192 x u16 (< 64 waiting + 64 retired by one SWAP, with room to spare) */
+#define CRH_HITS_MAX 192u
+#define CRH_IDS_MISSES 640u    /* < 64 waiting + 64 retired by one SWAP */
 #define CRH_IDS_BYTES 768u
 
 template <class PR>
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
-	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 	const DScene S = globalize(Sarg);
 	CRH_EM_POW_TABLES_INIT();
 	const unsigned long long tStart = wall_clock64();
@@ -206,6 +209,16 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
+	/* hits are shaded in batches of few shade classes (ST_SHADE) when the scene has many of them: with two or three classes a mixed batch
+	 * runs little extra code and the bookkeeping costs more than it saves (measured: statues -1 %, venus -3 %; hdr.json, six classes: +3 %) */
+	const bool sorted = S.shade_classes >= 4u;
+	/* the instances' shade classes: an LDS table when the scene has at most 256 instances (a retiring walk looks its class up) */
+	__shared__ uint8_t s_cls[256];
+	const bool clsInLds = S.instance_count <= 256u;
+	if (sorted && clsInLds) {
+		for (uint32_t i = threadIdx.x; i < S.instance_count; i += CRH_BLOCK) s_cls[i] = (uint8_t)CRH_DINST_CLASS(S.instances[i].kind);
+		__syncthreads();
+	}
 	stk.ovf = (glb_u32 *)ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_OVF_WORDS_PER_WAVE;
 	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
 	const int passEnd = P.first_pass + P.pass_count;
@@ -213,13 +226,15 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	 * plain variables they would be scalar registers live across the whole machine, and the register allocator is past
 	 * its limits there — measured slower, and wrong images in the variant that calls runProgram) */
 	f4 *const ptab = (f4 *)(queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS);
-	enum { WQ_RAYS, WQ_HITS, WQ_MISSES, WQ_FREE, WQ_NEXT_ITEM, WQ_WORDS };
+	enum { WQ_RAYS, WQ_HITS, WQ_MISSES, WQ_FREE, WQ_NEXT_ITEM, WQ_CLS_LO, WQ_CLS_HI, WQ_WORDS };      /* CLS_LO / CLS_HI: hits waiting per shade class, 8 bits each */
 	__shared__ int s_wq[(CRH_BLOCK / 64) * WQ_WORDS];
-	__shared__ uint8_t s_ids[(CRH_BLOCK / 64) * CRH_IDS_BYTES];
+	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_IDS_BYTES];
 	typedef volatile __attribute__((address_space(3))) int lds_int;
 	typedef volatile __attribute__((address_space(3))) uint8_t lds_u8;
+	typedef volatile __attribute__((address_space(3))) uint16_t lds_u16;
 	lds_int *const wq = (lds_int *)&s_wq[(threadIdx.x >> 6) * WQ_WORDS];
 	lds_u8 *const ids = (lds_u8 *)&s_ids[(threadIdx.x >> 6) * CRH_IDS_BYTES];
+	lds_u16 *const hits = (lds_u16 *)&s_ids[(threadIdx.x >> 6) * CRH_IDS_BYTES + CRH_IDS_HITS];
 	for (;;) {
 		uint32_t unit = 0;
 		if (lane == 0) unit = atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
@@ -260,8 +275,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 			 * background code, and the walk steps always have rays. Each path's own sequence of operations — hence
 			 * every result — is independent of the schedule.
 			 */
-			if (lane == 0) { wq[WQ_RAYS] = 0; wq[WQ_HITS] = 0; wq[WQ_MISSES] = 0; wq[WQ_FREE] = (int)CRH_PATHS; wq[WQ_NEXT_ITEM] = 0; }
-			for (uint32_t i = lane; i < CRH_PATHS; i += 64u) ids[CRH_IDS_FREE + i] = (uint8_t)i;
+			if (lane == 0) { wq[WQ_RAYS] = 0; wq[WQ_HITS] = 0; wq[WQ_MISSES] = 0; wq[WQ_FREE] = (int)CRH_PATHS; wq[WQ_NEXT_ITEM] = 0; wq[WQ_CLS_LO] = 0; wq[WQ_CLS_HI] = 0; }
+			for (uint32_t i = lane; i < CRH_PATHS; i += 64u) ids[i] = (uint8_t)i;              /* all slots free: the free stack covers bytes 0..255 */
 			Walk w;
 			memset(&w, 0, sizeof(w));
 			w.phase = PH_IDLE;
@@ -334,16 +349,27 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						const bool fin = (ph == PH_SHADE);
 						const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
 						const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
+						uint32_t cls = 0;
 						if (fin) {
 							f4 *q = ptab + myPath * CRH_PATH_F4;
 							q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
 							if (finHit) {
 								q[5].x = asF32((uint32_t)w.hit.inst);
-								ids[CRH_IDS_HITS + (uint32_t)hitsQ + laneRank(hm)] = (uint8_t)myPath;
+								if (sorted) cls = clsInLds ? (uint32_t)((volatile __attribute__((address_space(3))) uint8_t *)s_cls)[w.hit.inst] : CRH_DINST_CLASS(S.instances[w.hit.inst].kind);
+								hits[(uint32_t)hitsQ + laneRank(hm)] = (uint16_t)(myPath | (cls << 8));
 							} else {
 								ids[CRH_IDS_MISSES + (uint32_t)missQn + laneRank(mm)] = (uint8_t)myPath;
 							}
 							w.phase = PH_IDLE;
+						}
+						if (sorted && hm) {        /* hits waiting per class (wave-uniform, lane 0 stores them) */
+							uint32_t addLo = 0, addHi = 0;
+#pragma unroll
+							for (uint32_t b = 0; b < 8u; ++b) {
+								const uint32_t nb = (uint32_t)__popcll(__ballot(finHit && cls == b));
+								if (b < 4u) addLo += nb << (8u * b); else addHi += nb << (8u * (b - 4u));
+							}
+							if (lane == 0) { wq[WQ_CLS_LO] = wq[WQ_CLS_LO] + (int)addLo; wq[WQ_CLS_HI] = wq[WQ_CLS_HI] + (int)addHi; }
 						}
 						/* refill: idle lanes pop the top ray ids and start those walks */
 						const bool idle = (w.phase == PH_IDLE);
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						const int n = (int)__popcll(vm);
 						if (valid) {
 							const uint32_t rk = laneRank(vm);
-							const uint32_t id = ids[CRH_IDS_FREE + (uint32_t)(freeQ - 1) - rk];
+							const uint32_t id = ids[CRH_IDS_FREE_END - (uint32_t)freeQ + rk];
 							v3 o, d;
 							PathRecT<RngT<SAMP>> r;
 							beginPath(S, P, x, y, pass, o, d, r, cnt);
@@ -395,18 +421,79 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
 							(void)shadeCore(S, P, o, d, h, r, cnt);
 							float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
-							ids[CRH_IDS_FREE + (uint32_t)freeQ + lane] = (uint8_t)id;
+							ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - lane] = (uint8_t)id;
 						}
 						if (lane == 0) { wq[WQ_MISSES] = missQn - n; wq[WQ_FREE] = freeQ + n; }
 						__threadfence_block();
 						break;
 					}
-					default: {   /* ST_SHADE: up to 64 surface hits */
-						const int n = min(hitsQ, 64);
+					default: {   /* ST_SHADE: up to 64 surface hits of as few shade classes as fill the wave */
+						/* Which hits: whole classes, largest first, while they fit into 64 lanes; if that leaves fewer than shadeMin lanes busy, the
+						 * first hits of the next class as well. Hits of the other (small) classes wait for a later batch: the batch runs two or
+						 * three surface-shader code paths instead of all of them. Scalar code on the per-class counts. */
+						uint32_t clsLo = 0, clsHi = 0;
+						int n = min(hitsQ, 64);
+						if (sorted) {
+						clsLo = (uint32_t)__builtin_amdgcn_readfirstlane(wq[WQ_CLS_LO]); clsHi = (uint32_t)__builtin_amdgcn_readfirstlane(wq[WQ_CLS_HI]);
+						int c8[8];
+#pragma unroll
+						for (int b = 0; b < 8; ++b) c8[b] = (int)(((b < 4 ? clsLo : clsHi) >> (8 * (b & 3))) & 255u);
+						uint32_t fullMask = 0;
+						int partCls = -1, partN = 0;
+						n = 0;
+#pragma unroll
+						for (int it = 0; it < 8; ++it) {
+							int bc = 0, bb = -1;
+#pragma unroll
+							for (int b = 0; b < 8; ++b) if (!((fullMask >> b) & 1u) && c8[b] > bc) { bc = c8[b]; bb = b; }
+							if (bb < 0 || n >= K.shadeMin || partCls >= 0) break;
+							if (n + bc <= 64) { fullMask |= 1u << bb; n += bc; }
+							else { partCls = bb; partN = 64 - n; n = 64; }
+						}
+						if (n < hitsQ) {
+							/* bring the chosen hits to the top of the stack: every entry is read (up to three per lane), then written to its new
+							 * place — the chosen ones in [hitsQ - n, hitsQ), the others below, both in their old order (LDS operations of a wave
+							 * execute in program order, so all reads precede all writes) */
+							uint32_t e[3];
+							bool take[3], keep[3];
+							uint32_t tr[3], kr[3];
+							int tBase = 0, kBase = 0, pBase = 0;
+#pragma unroll
+							for (int p = 0; p < 3; ++p) {
+								const uint32_t i = (uint32_t)p * 64u + lane;
+								const bool valid = (int)i < hitsQ;
+								e[p] = valid ? (uint32_t)hits[i] : 0u;
+								const uint32_t ec = e[p] >> 8;
+								const bool part = valid && (int)ec == partCls;
+								const unsigned long long pm = __ballot(part);
+								take[p] = valid && (((fullMask >> ec) & 1u) || (part && pBase + (int)laneRank(pm) < partN));
+								pBase += (int)__popcll(pm);
+								const unsigned long long tm = __ballot(take[p]);
+								tr[p] = (uint32_t)tBase + laneRank(tm);
+								keep[p] = valid && !take[p];
+								const unsigned long long km = __ballot(keep[p]);
+								kr[p] = (uint32_t)kBase + laneRank(km);
+								tBase += (int)__popcll(tm);
+								kBase += (int)__popcll(km);
+							}
+#pragma unroll
+							for (int p = 0; p < 3; ++p) {
+								if (take[p]) hits[(uint32_t)(hitsQ - n) + tr[p]] = (uint16_t)e[p];
+								if (keep[p]) hits[kr[p]] = (uint16_t)e[p];
+							}
+						}
+						/* the per-class counts after this batch */
+#pragma unroll
+						for (int b = 0; b < 8; ++b) {
+							const uint32_t gone = ((fullMask >> b) & 1u) ? (uint32_t)c8[b] : (b == partCls ? (uint32_t)partN : 0u);
+							if (b < 4) clsLo -= gone << (8 * b); else clsHi -= gone << (8 * (b - 4));
+						}
+						}
+						if constexpr (LEVEL >= 2) { if (lane == 0) cnt.u_shade += (uint32_t)n; }
 						bool cont = false, done = false;
 						uint32_t id = 0;
 						if ((int)lane < n) {
-							id = ids[CRH_IDS_HITS + (uint32_t)(hitsQ - n) + lane];
+							id = (uint32_t)hits[(uint32_t)(hitsQ - n) + lane] & 255u;
 							f4 *q = ptab + id * CRH_PATH_F4;
 							const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
 							v3 o{q0.x, q0.y, q0.z}, d{q1.x, q1.y, q1.z};
@@ -429,8 +516,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						}
 						const unsigned long long cm = __ballot(cont), dm = __ballot(done);
 						if (cont) ids[CRH_IDS_RAYS + (uint32_t)raysQ + laneRank(cm)] = (uint8_t)id;
-						if (done) ids[CRH_IDS_FREE + (uint32_t)freeQ + laneRank(dm)] = (uint8_t)id;
-						if (lane == 0) { wq[WQ_HITS] = hitsQ - n; wq[WQ_RAYS] = raysQ + (int)__popcll(cm); wq[WQ_FREE] = freeQ + (int)__popcll(dm); }
+						if (done) ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - laneRank(dm)] = (uint8_t)id;
+						if (lane == 0) {
+							wq[WQ_HITS] = hitsQ - n; wq[WQ_RAYS] = raysQ + (int)__popcll(cm); wq[WQ_FREE] = freeQ + (int)__popcll(dm);
+							wq[WQ_CLS_LO] = (int)clsLo; wq[WQ_CLS_HI] = (int)clsHi;
+						}
 						__threadfence_block();
 						break;
 					}
@@ -444,7 +534,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 						else if (pick == ST_CTRL) { cnt.w_ctrl += 1; cnt.w_setup += dt; cnt.u_ctrl += (uint32_t)nC; }
 						else if (pick == ST_SWAP) { cnt.n_swap += 1; cnt.t_swap += dt; cnt.u_swap += (uint32_t)(nF + min(nE + nF, raysQ)); }
 						else if (pick == ST_GEN || pick == ST_MISS) { cnt.n_gen += 1; cnt.t_gen += dt; }
-						else { cnt.w_shade += 1; cnt.t_shade += dt; cnt.u_shade += (uint32_t)min(hitsQ, 64); }
+						else { cnt.w_shade += 1; cnt.t_shade += dt; }
 					}
 				}
 			}
@@ -955,7 +1045,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12};
+	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12, 48};
 	int kernel = CRH_KERNEL_WAVE;            /* CRH_OPT_KERNEL */
 	SchedWg schedWg = {70, 160, 120, 16, 768, 4, 12, 12, 8, 192, 1, 16, 32};
 	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
@@ -1208,10 +1298,11 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			c->schedWg.wNode = k.wNode; c->schedWg.wTri = k.wTri; c->schedWg.wCtrl = k.wCtrl; c->schedWg.swapMin = k.swapMin;
 			return CRH_OK;
 		}
-		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 | ctrlInRun << 24 */
+		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 | ctrlInRun << 24 | shadeMin << 32 (0: keep) */
 			Sched k = c->sched;
 			k.fillTo = (int)(value & 0xFFF); k.runNum = (int)((value >> 12) & 0xF); k.triInRun = (int)((value >> 16) & 0xFF); k.ctrlInRun = (int)((value >> 24) & 0xFF);
-			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65 || k.ctrlInRun < 1 || k.ctrlInRun > 65) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
+			if ((value >> 32) & 0xFF) k.shadeMin = (int)((value >> 32) & 0xFF);
+			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65 || k.ctrlInRun < 1 || k.ctrlInRun > 65 || k.shadeMin < 1 || k.shadeMin > 128) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
 			c->sched = k;
 			c->schedWg.runNum = k.runNum; c->schedWg.triInRun = k.triInRun; c->schedWg.ctrlInRun = k.ctrlInRun;
 			return CRH_OK;
@@ -1275,7 +1366,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(textures, cs.textures.data(), cs.textures.size());
 	UP(texels, cs.texels.data(), cs.texels.size());
 #undef UP
-	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base;
+	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base; d.shade_classes = cs.shade_classes; d.instance_count = (uint32_t)cs.instances.size();
 	d.background = cs.background; d.camera = cs.camera;
 	c->d = d;
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */

@@ -50,6 +50,9 @@ struct rgba { float r, g, b, a; };
 #define CRH_DINST_MESH_EMPTY 3u   /* bvh->nodeCount == 0 (bvh.c:362-365) */
 #define CRH_DINST_KIND(k)    ((k) & 15u)
 #define CRH_DINST_VOLUME     16u  /* flag: the sphere / mesh bounds a constant-density medium (instance.c:62-92, 187-216) */
+#define CRH_DINST_CLASS_SHIFT 8u /* bits 8..10: shade class — instances whose hits run the same shading code path (a scheduling hint, scene_compile.cpp) */
+#define CRH_DINST_CLASSES    8u
+#define CRH_DINST_CLASS(k)   (((k) >> CRH_DINST_CLASS_SHIFT) & (CRH_DINST_CLASSES - 1u))
 struct alignas(16) DInstance {
 	float Ainv[12];
 	uint32_t kind;        /* CRH_DINST_* */
@@ -128,6 +131,8 @@ struct DScene {
 	uint32_t tlas_node_count;
 	uint32_t tlas_prim_base;
 	uint32_t background;        /* gnode index of the background bsdf */
+	uint32_t shade_classes;     /* distinct shade classes among the instances (CRH_DINST_CLASS); <= 1: hits need no sorting */
+	uint32_t instance_count;    /* records in instances[] */
 	crh_camera camera;
 };
 

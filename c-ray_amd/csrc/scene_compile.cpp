@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -427,6 +428,7 @@ struct Compiler {
 			}
 			out.instances[k] = d;
 		}
+		assignShadeClasses();
 		for (uint64_t i = 0; i < s->instance_count; ++i) {           /* instances outside the TLAS (none with the reference's builder) are still validated */
 			const crh_instance &in = s->instances[i];
 			CHECK(in.kind <= CRH_INSTANCE_MESH_VOLUME, CRH_ERR_UNSUPPORTED, "unknown instance kind %u", in.kind);
@@ -434,6 +436,62 @@ struct Compiler {
 			CHECK(sphere ? in.object < s->sphere_count : in.object < s->mesh_count, CRH_ERR_INVALID, "instance %llu: object index out of range", (unsigned long long)i);
 		}
 		if (out.nodes.empty()) out.nodes.resize(4, f4{0, 0, 0, 0});
+	}
+
+	/* Shade classes (pt_device.h: CRH_DINST_CLASS): the path-tracing kernel shades hits in batches of one class, so that a batch runs ONE
+	 * surface-shader code path instead of the union of all of them. A class = what the shading code branches on: sphere or mesh, the
+	 * root bsdf kind of the material, whether the graph reads uv, whether the material emits. Meshes whose polygons use materials of
+	 * different signatures are "mixed". The seven most frequent signatures get a class of their own, the rest share the last one.
+	 * Purely a scheduling hint: every path's own sequence of operations, hence every result, is independent of it. */
+	void assignShadeClasses() {
+		std::vector<uint32_t> sigOfMesh(s->mesh_count, 0xFFFFFFFFu);
+		auto sigOfMaterial = [&](uint32_t m, bool sphere) -> uint32_t {
+			if (m >= s->material_count) return 0xFFFFFFu;
+			const crh_material &mt = s->materials[m];
+			/* the bsdf kinds in the material's graph (the loader wraps every JSON material in mix(transparent, X, alpha): the root says nothing) */
+			uint32_t kinds = 0;
+			std::vector<uint32_t> todo{mt.bsdf};
+			for (int guard = 0; !todo.empty() && guard < 4096; ++guard) {
+				const uint32_t g = todo.back(); todo.pop_back();
+				if (g >= s->gnode_count || !isBsdfKind(s->gnodes[g].kind)) continue;
+				kinds |= 1u << (s->gnodes[g].kind & 15u);
+				todo.push_back(s->gnodes[g].a); todo.push_back(s->gnodes[g].b); todo.push_back(s->gnodes[g].c);
+			}
+			const bool emits = mt.emission[0] > 0.0f || mt.emission[1] > 0.0f || mt.emission[2] > 0.0f;
+			return kinds | (out.materials[m].pad[0] ? 1u << 16 : 0u) | (emits ? 1u << 17 : 0u) | (sphere ? 1u << 18 : 0u);
+		};
+		std::vector<uint32_t> sig(out.instances.size(), 0xFFFFFFu);
+		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {
+			const crh_instance &in = s->instances[out.instances[k].orig];
+			if (in.kind == CRH_INSTANCE_SPHERE || in.kind == CRH_INSTANCE_SPHERE_VOLUME) {
+				sig[k] = sigOfMaterial(s->spheres[in.object].material, true);
+			} else {
+				uint32_t &ms = sigOfMesh[in.object];
+				if (ms == 0xFFFFFFFFu) {
+					const crh_mesh &mesh = s->meshes[in.object];
+					ms = 0xFFFFFFu;
+					for (uint64_t pi = 0; pi < mesh.poly_count && mesh.poly_base + pi < s->poly_count; ++pi) {
+						const uint32_t one = sigOfMaterial(mesh.material_base + CRH_POLY_MATERIAL(s->polys[mesh.poly_base + pi]), false);
+						if (pi == 0) ms = one;
+						else if (one != ms) { ms = 0xFFFFFEu; break; }          /* mixed */
+					}
+				}
+				sig[k] = ms;
+			}
+		}
+		std::vector<std::pair<uint32_t, uint32_t>> freq;             /* (count, signature) */
+		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {
+			auto it = std::find_if(freq.begin(), freq.end(), [&](const std::pair<uint32_t, uint32_t> &f) { return f.second == sig[k]; });
+			if (it == freq.end()) freq.push_back({1u, sig[k]}); else ++it->first;
+		}
+		std::stable_sort(freq.begin(), freq.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first > b.first; });
+		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {
+			uint32_t cls = CRH_DINST_CLASSES - 1u;
+			for (uint32_t f = 0; f < freq.size() && f < CRH_DINST_CLASSES - 1u; ++f) if (freq[f].second == sig[k]) { cls = f; break; }
+			out.instances[k].kind |= cls << CRH_DINST_CLASS_SHIFT;
+		}
+		out.shade_classes = (uint32_t)std::min<size_t>(freq.size(), CRH_DINST_CLASSES);
+		if (getenv("CRH_DEBUG_CLASSES")) for (auto &f : freq) fprintf(stderr, "shade class signature 0x%x: %u instances\n", f.second, f.first);
 	}
 };
 

@@ -264,10 +264,12 @@ int crh_context_destroy(crh_ctx *ctx);
 #define CRH_OPT_WAVES_PER_SIMD 4  /* register budget variant of the path-tracing kernel: 4 (<=128 VGPRs, default) or 1 */
 #define CRH_OPT_UNIT_ITEMS    6   /* paths per work unit (pixel block x passes) the block shape aims for (default 2048) */
 #define CRH_OPT_SCHED_WEIGHTS 7   /* wave scheduler, four 12-bit fields: node | tri<<12 | ctrl<<24 step weights, finished+idle lanes that trigger a swap step <<36 (default 70,160,120,16) */
-#define CRH_OPT_SCHED_RUNS   11   /* wave scheduler: paths a wave keeps in flight before it waits for idle lanes to generate more (0..192, default 192)
+#define CRH_OPT_SCHED_RUNS   11   /* wave scheduler: paths a wave keeps in flight before it waits for idle lanes to generate more (0..192, default 160)
                                    * | n<<12: a node / triangle run continues while n/8 of its lanes still want that step (default 4)
                                    * | m<<16: inside a node run, triangles are tested as soon as m lanes wait for them (default 12; 65 = never)
-                                   * | k<<24: likewise instance entries / sphere tests (control steps), as soon as k lanes wait (default 12; 65 = never) */
+                                   * | k<<24: likewise instance entries / sphere tests (control steps), as soon as k lanes wait (default 12; 65 = never)
+                                   * | s<<32: surface hits are shaded in batches of one shade class (instances whose hits run the same shading code);
+                                   *          a batch starts once s hits of one class wait (1..128, default 64; 0 = keep), or 128 hits in all */
 #define CRH_OPT_UNITS_PER_WAVE 8  /* shrink the pixel blocks until every wave gets at least this many work units (default 8) */
 #define CRH_OPT_SAMPLER       9   /* which sampler seeds a (pixel, pass): CRH_SAMPLER_RANDOM = renderThread (sampler.c:41-44, default),
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */

@@ -120,6 +120,27 @@ def test_sampler_key_wraps_at_4k_2048spp(pkg, ctx, oracle):
     assert not img[mask].any()
 
 
+def test_shade_class_batches_change_nothing(pkg, ctx, manifest, golden_blob, golden_ref):
+    """Scenes with four or more shade classes (instances whose hits run the same surface-shader code path) shade their hits in batches
+    of few classes; which hits share a batch is pure scheduling. hdr.json at 320x180 (six classes) and the node zoo (dozens of graphs, the
+    programs + volumes kernel variant): every batch threshold gives the reference's frame bit for bit."""
+    for name in ("cfg2_hdr_small", "nodezoo"):
+        m = manifest[name]
+        w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+        ref = golden_ref(name)
+        if "built_blob" in m:
+            ctx.upload(resize_camera(pkg.api.Scene(built_blob(m["built_blob"])), w, h))
+        else:
+            ctx.upload(pkg.api.Scene(golden_blob(m.get("blob", name))))
+        fb = ctx.framebuffer(w, h)
+        for shade_min in (48, 1, 17, 64, 128):
+            ctx.set_sched(70, 160, 120, 16, shade_min=shade_min)
+            ctx.clear(fb, w, h)
+            ctx.render_region(fb, w, h, s, b)
+            assert np.array_equal(ctx.download(fb, w, h), ref), (name, shade_min)
+    ctx.set_sched(70, 160, 120, 16)
+
+
 def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_blob):
     """Tile lists, region splits, pass splits and every block/chunk shape give the same frame bit for bit
     (a pixel's passes are folded in order whatever the schedule)."""

@@ -5,7 +5,7 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one full frame: every rank renders ITS share of the frame (N = 1: the reference's ordered 64x64 tile list;
+One step = one full frame: every rank renders ITS share of the frame (N = 1: the whole frame as one region;
 N > 1: every N-th 4-row strip, which balances the ranks where dealing out tiles does not — c-ray_amd/render.py) for
 all 256 passes in one dispatch of the persistent kernel, then the float framebuffers are summed onto rank 0 with one
 RCCL reduce (non-owned pixels are exactly 0, so the sum is a gather). The frame is a fixed job, so N > 1 is STRONG scaling.
@@ -262,7 +262,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD["what"].format(W=W, H=H, SPP=SPP, B=B),
                        "rays_per_step": int(total_rays / a.steps), "paths_per_step": int(total_paths / a.steps),
-                       "parallelism": ("1 rank: the reference's 64x64 tile list in one dispatch" if world == 1 else
+                       "parallelism": ("1 rank: the whole frame in one dispatch" if world == 1 else
                                        f"4-row strips interleaved over {world} ranks + one RCCL reduce of the float framebuffer")},
             "roofline": {"bound": "hbm", "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_scene / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -1450,13 +1450,25 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	int area = 1;
 	while (area < 256 && (int64_t)area * P->pass_count < unitItems) area *= 2;
 	while (area > 1 && pixels / area < (uint64_t)c->unitsPerWave * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
-	int bw = 1, bh = 1;
-	while (bw * bh < area) { if (bw <= bh) bw *= 2; else bh *= 2; }
+	int capW = 1, capH = 1;                   /* no block wider / taller than the widest / tallest tile (power of two below it): a 16x16 block clipped
+	                                           * to a 4-row strip would generate three quarters of its items as padding */
 	for (uint32_t t = 0; t < tile_count; ++t) {
 		const crh_tile &r = tiles[t];
 		if (r.x0 < 0 || r.y0 < 0 || r.x1 > P->image_width || r.y1 > P->image_height || r.x0 > r.x1 || r.y0 > r.y1)
 			return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
+		while (capW * 2 <= r.x1 - r.x0) capW *= 2;
+		while (capH * 2 <= r.y1 - r.y0) capH *= 2;
 	}
+	auto shapeOf = [capW, capH](int a, int &w, int &h) {
+		w = 1; h = 1;
+		while (w * h < a) {
+			const bool canW = w * 2 <= capW, canH = h * 2 <= capH;
+			if (!canW && !canH) break;
+			if ((w <= h && canW) || !canH) w *= 2; else h *= 2;
+		}
+	};
+	int bw = 1, bh = 1;
+	shapeOf(area, bw, bh);
 	/* Tapered units: the work queue is consumed in list order, so the tail of the list decides how far apart the waves
 	 * finish. The last tailPercent of the pixels (whole tiles from the end of the list, the boundary tile split by rows)
 	 * are cut into blocks of a quarter of the area. */
@@ -1480,7 +1492,6 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		}
 		return t;
 	};
-	auto shapeOf = [](int a, int &w, int &h) { w = 1; h = 1; while (w * h < a) { if (w <= h) w *= 2; else h *= 2; } };
 	uint32_t firstSmall = (uint32_t)work.size(), firstTiny = (uint32_t)work.size();
 	int sbw = bw, sbh = bh, tbw = bw, tbh = bh;
 	if (area >= 2 && c->tailPercent > 0) {

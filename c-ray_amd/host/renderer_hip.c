@@ -10,8 +10,8 @@
  *
  * What changes is who consumes the tile queue: instead of N pthread workers running the pixel x pass loop
  * (renderer.c:258-327) there is ONE host thread per GPU. Each flattens nothing itself — the scene is
- * flattened once (flatten.c) — owns a crh_ctx (libcray_hip.so) and renders ITS share of the frame — one GPU: the reference's tile
- * list (tile.c:66-241) in its order; several: every G-th 4-row strip — with ONE crh_render_tiles() dispatch per 512 passes (the
+ * flattened once (flatten.c) — owns a crh_ctx (libcray_hip.so) and renders ITS share of the frame — one GPU: the whole frame as one
+ * region; several: every G-th 4-row strip — with ONE crh_render_tiles() dispatch per 512 passes (the
  * persistent kernel balances the work units inside a dispatch itself; a drain per tile batch would idle the GPU). Then
  * the per-GPU float framebuffers (disjoint pixels, zero elsewhere) are summed onto GPU 0 with
  * RCCL over xGMI (crh_frames_reduce), downloaded into state.renderBuffer, and converted to the 8-bit sRGB
@@ -71,18 +71,18 @@ struct gpuWorker {
  * frame is cut only along the pass axis, and only when it is long enough that the preview window / abort key should get a turn */
 #define PASSES_PER_DISPATCH 512
 
-/* The share of GPU g of G: G == 1 -> the reference's own tile list in its order (tile.c:66-241); G > 1 -> every G-th 4-row strip
+/* The share of GPU g of G: G == 1 -> the whole frame; G > 1 -> every G-th 4-row strip
  * (static shares must be balanced, and dealing out the tile list is not: DESIGN.md section 6). Returns the tile count. */
 static uint32_t gpuShare(const struct renderer *r, int g, int G, crh_tile **out) {
 	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
 	if (G == 1) {
-		crh_tile *t = calloc((size_t)(r->state.tileCount > 0 ? r->state.tileCount : 1), sizeof(*t));
-		for (int i = 0; i < r->state.tileCount; ++i) {
-			const struct renderTile *rt = &r->state.renderTiles[i];
-			t[i] = (crh_tile){rt->begin.x, rt->begin.y, rt->end.x, rt->end.y};
-		}
+		/* the whole frame as one region: inside a dispatch the library hands out the pixel blocks bottom-up, row by row. The order of the
+		 * reference's tile list (tile.c:119-241) is a preview preference, not part of the result — and measured on one GPU it costs 2 %
+		 * (fromMiddle) to 10 % (topToBottom: the expensive bottom of a frame ends up in the small blocks of the dispatch's tail) */
+		crh_tile *t = calloc(1, sizeof(*t));
+		t[0] = (crh_tile){0, 0, W, H};
 		*out = t;
-		return (uint32_t)r->state.tileCount;
+		return 1;
 	}
 	crh_tile *t = calloc((size_t)crh_strip_share_max(H, G), sizeof(*t));
 	*out = t;

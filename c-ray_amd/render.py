@@ -2,7 +2,7 @@
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm). Every rank holds a
 replica of the flattened scene, takes its share of the frame — every world-th 4-row strip (owned_tiles below; one
-rank: the reference's own ordered tile list, tile.c:66-117 via tiles.py) — and renders it with ONE crh_render_tiles dispatch into a zeroed float
+rank: the whole frame as one region) — and renders it with ONE crh_render_tiles dispatch into a zeroed float
 framebuffer; a single reduce(SUM) to rank 0 then assembles the frame — pixels a rank does not own are
 exactly 0.0f, so the sum is a gather and the result is bit-identical to the 1-GPU frame.
 PyTorch is used for device memory, the stream and the collective only; all rendering is behind the C-ABI.
@@ -16,13 +16,14 @@ STRIP_ROWS = 4
 def owned_tiles(width, height, tile_w, tile_h, order, rank, world):
     """This rank's share of the frame, as a tile list for crh_render_tiles.
 
-    One rank: the reference's ordered tile list (tile.c:66-241). Several ranks: horizontal strips of STRIP_ROWS pixel
-    rows, strip i owned by rank i mod world. Dealing out the reference's tiles instead (tile i -> rank i mod world) looks
+    One rank: the whole frame as ONE region (the library hands its pixel blocks out bottom-up; the reference's tile orders,
+    tile.c:119-241, are a preview preference and cost 2-10 % as work orders: tools/probe_tile_order.py). Several ranks: horizontal
+    strips of STRIP_ROWS pixel rows, strip i owned by rank i mod world. Dealing out the reference's tiles instead (tile i -> rank i mod world) looks
     natural but is badly balanced for the orders that start in the middle: on the bench frame two ranks get 236 M and
     346 M rays (45 / 70 ms), eight ranks 9.8 ... 20.4 ms; 4-row strips give 59.2 / 59.2 ms and 16.9 ... 17.6 ms
     (tools/probe_rank_share.py). Any disjoint cover reproduces the frame bit for bit: a pixel's passes fold on its owner."""
     if world <= 1:
-        return tiles_mod.quantize_image(width, height, tile_w, tile_h, order)
+        return [(0, 0, width, height)]
     strips = [(0, y, width, min(y + STRIP_ROWS, height)) for y in range(0, height, STRIP_ROWS)]
     return strips[rank::world]
 

@@ -142,6 +142,15 @@ int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, c
 	return CRH_OK;
 }
 
+/* The scene compiler's shade classes (scheduling hint of the device kernel): out[orig instance index] = class, returns the number of classes. */
+int emu_shade_classes(const crh_scene_desc *scene, uint32_t *out, uint64_t n) {
+	CompiledScene c;
+	int rc = compile_scene(scene, c, g_err);
+	if (rc != CRH_OK) return rc;
+	for (const DInstance &d : c.instances) if (d.orig < n) out[d.orig] = CRH_DINST_CLASS(d.kind);
+	return (int)c.shade_classes;
+}
+
 }  // extern "C"
 
 /* debug: the most expensive single path (by node tests) in a region: out = {x, y, pass, node_tests, tri_tests, rays} */

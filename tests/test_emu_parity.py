@@ -119,3 +119,23 @@ def test_scene_compiler_rejects_malformed_scenes(emu, oracle, golden_blob):
     old = d.instances[0].kind; d.instances[0].kind = 4; check(abi.ERR_UNSUPPORTED); d.instances[0].kind = old      # 2 / 3 are the volume kinds
     old = d.materials[0].bsdf; d.materials[0].bsdf = abi.NODE_NONE; check(abi.ERR_INVALID); d.materials[0].bsdf = old
     check(0)
+
+
+def test_shade_classes_follow_the_shading_code_path(emu, oracle):
+    """Scene compiler: instances get a shade class by what their hits branch on — sphere or mesh, the bsdf kinds in the material graph,
+    uv use, emission. hdr.json: the three metal spheres share a class, the four glass spheres another, the three lights a third, the plastic
+    sphere, the textured ground mesh and the plastic mesh one each (six); a one-material soup has a single class (the kernel then skips
+    the per-class bookkeeping, as it does below four classes)."""
+    scene = oracle.OracleScene(built_blob("cfg2_hdr"))
+    n = int(scene.desc.instance_count)
+    cls = (C.c_uint32 * n)()
+    emu.emu_shade_classes.argtypes = [C.POINTER(oracle.abi.SceneDesc), C.POINTER(C.c_uint32), C.c_uint64]
+    count = emu.emu_shade_classes(scene.ptr, cls, n)
+    assert count == 6 and max(cls) == 5
+    cls = list(cls)
+    # input/hdr.json order: spheres metal, plastic, metal, glass x4, metal, emissive x3, then the two meshes
+    assert cls[0] == cls[2] == cls[7] and cls[3] == cls[4] == cls[5] == cls[6] and cls[8] == cls[9] == cls[10]
+    assert len({cls[0], cls[1], cls[3], cls[8], cls[11], cls[12]}) == 6
+    soup = oracle.OracleScene(built_blob("soup_1m"))
+    one = (C.c_uint32 * int(soup.desc.instance_count))()
+    assert emu.emu_shade_classes(soup.ptr, one, len(one)) == 1 and list(one) == [0]

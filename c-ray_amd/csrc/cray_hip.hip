@@ -210,12 +210,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
 	/* hits are shaded in batches of few shade classes (ST_SHADE) when the scene has many of them: with two or three classes a mixed batch
-	 * runs little extra code and the bookkeeping costs more than it saves (measured: statues -1 %, venus -3 %; hdr.json, six classes: +3 %) */
-	const bool sorted = S.shade_classes >= 4u;
-	/* the instances' shade classes: an LDS table when the scene has at most 256 instances (a retiring walk looks its class up) */
+	 * runs little extra code and the bookkeeping costs more than it saves (measured: statues -1 %, venus -3 %; hdr.json, six classes: +3 %).
+	 * The instances' classes sit in an LDS table (a retiring walk looks its class up): scenes with more than 256 instances do not sort. */
 	__shared__ uint8_t s_cls[256];
-	const bool clsInLds = S.instance_count <= 256u;
-	if (sorted && clsInLds) {
+	const bool sorted = S.shade_classes >= 4u && S.instance_count <= 256u;
+	if (sorted) {
 		for (uint32_t i = threadIdx.x; i < S.instance_count; i += CRH_BLOCK) s_cls[i] = (uint8_t)CRH_DINST_CLASS(S.instances[i].kind);
 		__syncthreads();
 	}
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
 							if (finHit) {
 								q[5].x = asF32((uint32_t)w.hit.inst);
-								if (sorted) cls = clsInLds ? (uint32_t)((volatile __attribute__((address_space(3))) uint8_t *)s_cls)[w.hit.inst] : CRH_DINST_CLASS(S.instances[w.hit.inst].kind);
+								if (sorted) cls = (uint32_t)((volatile __attribute__((address_space(3))) uint8_t *)s_cls)[w.hit.inst];
 								hits[(uint32_t)hitsQ + laneRank(hm)] = (uint16_t)(myPath | (cls << 8));
 							} else {
 								ids[CRH_IDS_MISSES + (uint32_t)missQn + laneRank(mm)] = (uint8_t)myPath;

@@ -1494,7 +1494,10 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	uint32_t firstSmall = (uint32_t)work.size(), firstTiny = (uint32_t)work.size();
 	int sbw = bw, sbh = bh, tbw = bw, tbh = bh;
 	if (area >= 2 && c->tailPercent > 0) {
-		const int smallArea = std::max(area / 4, 1), tinyArea = std::max(area / 16, 1);
+		/* a quarter / a sixteenth of the block — but never fewer than 512 / 256 paths per unit (few passes per dispatch): a unit that cannot
+		 * even fill the wave's path table is all ramp and drain */
+		auto pixelsFor = [&](int paths) { int a = 1; while ((int64_t)a * P->pass_count < paths && a < area) a *= 2; return a; };
+		const int smallArea = std::max(std::max(area / 4, 1), std::min(pixelsFor(512), area)), tinyArea = std::max(std::max(area / 16, 1), std::min(pixelsFor(256), area));
 		shapeOf(smallArea, sbw, sbh);
 		firstSmall = cutTail(pixels * (uint64_t)c->tailPercent / 100);
 		firstTiny = (uint32_t)work.size();

@@ -10,7 +10,7 @@ ctx = api.Context(0); ctx.set_option(abi.OPT_COUNTER_LEVEL, 1); ctx.set_option(a
 for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 256, 8), ("cfg4_statues", 3840, 2160, 8, 30), ("soup_1m", 2560, 1440, 16, 8), ("cfg3_venus", 1920, 1080, 32, 32)):
     ctx.upload(api.Scene(os.path.join(BUILT, name + ".blob")))
     fb = ctx.framebuffer(w, h)
-    for tail, tail2 in ((16, 4), (8, 2), (12, 3), (24, 6), (30, 4), (30, 8), (40, 10), (50, 12), (0, 0)):
+    for tail, tail2 in [tuple(int(v) for v in t.split("/")) for t in (os.environ.get("TAILS") or "16/4,8/2,12/3,24/6,30/4,30/8,40/10,50/12,0/0").split(",")]:
         ctx.set_option(abi.OPT_TAIL_PERCENT, tail | ((tail2 + 1) << 8))
         best = None
         for rep in range(3):

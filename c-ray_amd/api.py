@@ -70,6 +70,8 @@ def library():
         "crh_blob_save": (C.c_int, [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.BlobPrefs)]),
         "crh_blob_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(abi.SceneDesc)), C.POINTER(abi.BlobPrefs)]),
         "crh_blob_free": (None, [C.POINTER(abi.SceneDesc)]),
+        "crh_debug_plan_units": (C.c_int, [C.POINTER(abi.RenderParams), C.POINTER(abi.Tile), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -86,6 +88,18 @@ def _check(rc, where):
 
 def device_count():
     return library().crh_device_count()
+
+
+def plan_units(width, height, samples, tiles, cu_count=256, first_pass=0, pass_count=None):
+    """crh_debug_plan_units (no device needed): the work units of one dispatch in hand-out order, as an int32 array [n, 6] of
+    x0, y0, x1, y1, block area, taper level — and the pass chunk."""
+    p = abi.RenderParams(0, 0, 0, 0, width, height, first_pass, samples - first_pass if pass_count is None else pass_count, samples, 1)
+    arr = (abi.Tile * len(tiles))(*[abi.Tile(*t) for t in tiles])
+    n, chunk = C.c_uint64(0), C.c_int32(0)
+    _check(library().crh_debug_plan_units(C.byref(p), arr, len(tiles), cu_count, None, 0, C.byref(n), C.byref(chunk)), "crh_debug_plan_units")
+    units = np.zeros((n.value, 6), np.int32)
+    _check(library().crh_debug_plan_units(C.byref(p), arr, len(tiles), cu_count, units.ctypes.data, n.value, C.byref(n), C.byref(chunk)), "crh_debug_plan_units")
+    return units, chunk.value
 
 
 class Scene:

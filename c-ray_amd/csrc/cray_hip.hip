@@ -1429,32 +1429,35 @@ int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int hei
 	return CRH_OK;
 }
 
-int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, float *dev_fb) {
-	if (!c || !P || !dev_fb || (!tiles && tile_count)) return fail(CRH_ERR_INVALID, "crh_render_tiles: NULL argument");
-	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_render_tiles: no scene uploaded");
-	if (P->image_width <= 0 || P->image_height <= 0 || P->pass_count < 0 || P->first_pass < 0 || P->max_passes < P->first_pass + P->pass_count)
-		return fail(CRH_ERR_INVALID, "crh_render_tiles: bad render parameters");
-	int rc = setDevice(c);
-	if (rc) return rc;
-	(void)resolveTimes(c, false);
+/* ---- work plan of one dispatch (host only, no device needed: crh_debug_plan_units runs it for the CPU tests) ------------------------- */
+struct PlanKnobs { int unitItems, unitsPerWave, tailPercent, tail2Percent, passChunk, cuCount, blocksPerCU; bool wg; };
+struct WorkPlan {
+	std::vector<crh_tile> work;            /* the caller's tiles, the tail ones split by rows */
+	std::vector<uint32_t> start;           /* start[t] = first unit of work[t]; start[work.size()] = total */
+	uint64_t total = 0;
+	int bw = 1, bh = 1, sbw = 1, sbh = 1, tbw = 1, tbh = 1;      /* block shapes: regular, from firstSmall on, from firstTiny on */
+	uint32_t firstSmall = 0, firstTiny = 0;
+	int area = 1, chunk = 1;
+	uint32_t grid = 0;
+};
+static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, const PlanKnobs &K, WorkPlan &W, std::string &err) {
 	/* Block shape: one work unit (a block for all passes of the dispatch) should hold about unitItems paths, so
 	 * that every wave gets many units (load balance) whatever the sample count: 16x16 pixels at 4 spp ... 2x2 at
 	 * 256 spp, 1x1 beyond. Smaller blocks also keep the 64 lanes of a wave on fewer pixels (coherent walks). */
 	uint64_t pixels = 0;
 	for (uint32_t t = 0; t < tile_count; ++t) pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * std::max(0, tiles[t].y1 - tiles[t].y0);
 	/* the workgroup kernel's unit is worked on by four waves: four times the paths, a quarter of the consumers */
-	const bool wg = c->kernel == CRH_KERNEL_WG;
-	const int unitItems = wg ? c->unitItems * 4 : c->unitItems;
-	const uint64_t wavesMax = (uint64_t)c->cuCount * c->blocksPerCU * (wg ? 1 : CRH_BLOCK / 64);
+	const int unitItems = K.wg ? K.unitItems * 4 : K.unitItems;
+	const uint64_t wavesMax = (uint64_t)K.cuCount * K.blocksPerCU * (K.wg ? 1 : CRH_BLOCK / 64);
 	int area = 1;
 	while (area < 256 && (int64_t)area * P->pass_count < unitItems) area *= 2;
-	while (area > 1 && pixels / area < (uint64_t)c->unitsPerWave * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
+	while (area > 1 && pixels / area < (uint64_t)K.unitsPerWave * wavesMax) area /= 2;       /* few pixels (or few passes): keep every wave fed */
 	int capW = 1, capH = 1;                   /* no block wider / taller than the widest / tallest tile (power of two below it): a 16x16 block clipped
 	                                           * to a 4-row strip would generate three quarters of its items as padding */
 	for (uint32_t t = 0; t < tile_count; ++t) {
 		const crh_tile &r = tiles[t];
 		if (r.x0 < 0 || r.y0 < 0 || r.x1 > P->image_width || r.y1 > P->image_height || r.x0 > r.x1 || r.y0 > r.y1)
-			return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
+			{ err = "crh_render_tiles: tile outside the image"; return CRH_ERR_INVALID; }
 		while (capW * 2 <= r.x1 - r.x0) capW *= 2;
 		while (capH * 2 <= r.y1 - r.y0) capH *= 2;
 	}
@@ -1466,12 +1469,14 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 			if ((w <= h && canW) || !canH) w *= 2; else h *= 2;
 		}
 	};
-	int bw = 1, bh = 1;
+	int &bw = W.bw, &bh = W.bh;
+	bw = 1; bh = 1;
 	shapeOf(area, bw, bh);
 	/* Tapered units: the work queue is consumed in list order, so the tail of the list decides how far apart the waves
 	 * finish. The last tailPercent of the pixels (whole tiles from the end of the list, the boundary tile split by rows)
 	 * are cut into blocks of a quarter of the area. */
-	std::vector<crh_tile> work(tiles, tiles + tile_count);
+	std::vector<crh_tile> &work = W.work;
+	work.assign(tiles, tiles + tile_count);
 	/* index of the first tile of the tail that holds the last `want` pixels (the boundary tile is split by rows) */
 	auto cutTail = [&work](uint64_t want) -> uint32_t {
 		uint64_t got = 0;
@@ -1491,39 +1496,100 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		}
 		return t;
 	};
-	uint32_t firstSmall = (uint32_t)work.size(), firstTiny = (uint32_t)work.size();
-	int sbw = bw, sbh = bh, tbw = bw, tbh = bh;
-	if (area >= 2 && c->tailPercent > 0) {
+	uint32_t &firstSmall = W.firstSmall, &firstTiny = W.firstTiny;
+	firstSmall = firstTiny = (uint32_t)work.size();
+	int &sbw = W.sbw, &sbh = W.sbh, &tbw = W.tbw, &tbh = W.tbh;
+	sbw = bw; sbh = bh; tbw = bw; tbh = bh;
+	if (area >= 2 && K.tailPercent > 0) {
 		/* a quarter / a sixteenth of the block — but never fewer than 512 / 256 paths per unit (few passes per dispatch): a unit that cannot
 		 * even fill the wave's path table is all ramp and drain */
 		auto pixelsFor = [&](int paths) { int a = 1; while ((int64_t)a * P->pass_count < paths && a < area) a *= 2; return a; };
 		const int smallArea = std::max(std::max(area / 4, 1), std::min(pixelsFor(512), area)), tinyArea = std::max(std::max(area / 16, 1), std::min(pixelsFor(256), area));
 		shapeOf(smallArea, sbw, sbh);
-		firstSmall = cutTail(pixels * (uint64_t)c->tailPercent / 100);
+		firstSmall = cutTail(pixels * (uint64_t)K.tailPercent / 100);
 		firstTiny = (uint32_t)work.size();
 		tbw = sbw; tbh = sbh;
-		if (tinyArea < smallArea && c->tail2Percent > 0 && c->tail2Percent < c->tailPercent) {
+		if (tinyArea < smallArea && K.tail2Percent > 0 && K.tail2Percent < K.tailPercent) {
 			shapeOf(tinyArea, tbw, tbh);
-			firstTiny = std::max(firstSmall, cutTail(pixels * (uint64_t)c->tail2Percent / 100));
+			firstTiny = std::max(firstSmall, cutTail(pixels * (uint64_t)K.tail2Percent / 100));
 		}
 	}
 	const uint32_t work_count = (uint32_t)work.size();
-	std::vector<uint32_t> start(work_count + 1, 0);
-	uint64_t total = 0;
+	std::vector<uint32_t> &start = W.start;
+	start.assign(work_count + 1, 0);
+	uint64_t &total = W.total;
+	total = 0;
 	for (uint32_t t = 0; t < work_count; ++t) {
 		const crh_tile &r = work[t];
 		const int ubw = t >= firstTiny ? tbw : t >= firstSmall ? sbw : bw, ubh = t >= firstTiny ? tbh : t >= firstSmall ? sbh : bh;
 		start[t] = (uint32_t)total;
 		total += (uint64_t)((r.x1 - r.x0 + ubw - 1) / ubw) * ((r.y1 - r.y0 + ubh - 1) / ubh);
-		if (total > 0xFFFFFFF0ull) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: more than 2^32 pixel blocks in one dispatch");
+		if (total > 0xFFFFFFF0ull) { err = "crh_render_tiles: more than 2^32 pixel blocks in one dispatch"; return CRH_ERR_UNSUPPORTED; }
 	}
 	start[work_count] = (uint32_t)total;
+	W.grid = 0; W.chunk = 1; W.area = area;
 	if (total == 0 || P->pass_count == 0) return CRH_OK;
-
-	const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->cuCount * c->blocksPerCU, wg ? total : (total + 3) / 4);
+	W.grid = (uint32_t)std::min<uint64_t>((uint64_t)K.cuCount * K.blocksPerCU, K.wg ? total : (total + 3) / 4);
 	/* passes per chunk: a chunk (block x passes) should also hold about unitItems paths, so that each lane runs >= 16
 	 * paths between two wave-wide folds */
-	const int chunk = std::min(P->pass_count, std::max(c->passChunk, (unitItems + area - 1) / area));
+	W.chunk = std::min(P->pass_count, std::max(K.passChunk, (unitItems + area - 1) / area));
+	return CRH_OK;
+}
+
+/* The work units crh_render_tiles would hand to the kernel for this dispatch on a GPU with `cu_count` compute units at the default options:
+ * one record of six ints per unit, in hand-out order — pixel rectangle x0, y0, x1, y1 (clipped to its tile), block area in pixels, and
+ * the taper level (0 regular, 1 quarter blocks, 2 sixteenth blocks). Needs no device: the CPU tests check cover, order and unit sizes. */
+int crh_debug_plan_units(const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, uint32_t cu_count, int32_t *units_out, uint64_t max_units,
+						 uint64_t *unit_count_out, int32_t *pass_chunk_out) {
+	if (!P || (!tiles && tile_count) || !unit_count_out || cu_count < 1) return fail(CRH_ERR_INVALID, "crh_debug_plan_units: bad argument");
+	if (P->image_width <= 0 || P->image_height <= 0 || P->pass_count < 0) return fail(CRH_ERR_INVALID, "crh_debug_plan_units: bad render parameters");
+	const crh_ctx defaults{};
+	const PlanKnobs knobs{defaults.unitItems, defaults.unitsPerWave, defaults.tailPercent, defaults.tail2Percent, defaults.passChunk, (int)cu_count, defaults.blocksPerCU, false};
+	WorkPlan W;
+	std::string err;
+	const int rc = planWork(P, tiles, tile_count, knobs, W, err);
+	if (rc != CRH_OK) return fail(rc, err);
+	*unit_count_out = W.total;
+	if (pass_chunk_out) *pass_chunk_out = W.chunk;
+	uint64_t u = 0;
+	for (uint32_t t = 0; t < W.work.size() && units_out; ++t) {          /* the kernel's unit -> block arithmetic (k_pathtrace: "pull a work unit") */
+		const crh_tile &r = W.work[t];
+		const int level = t >= W.firstTiny ? 2 : t >= W.firstSmall ? 1 : 0;
+		const int ubw = level == 2 ? W.tbw : level == 1 ? W.sbw : W.bw, ubh = level == 2 ? W.tbh : level == 1 ? W.sbh : W.bh;
+		const uint32_t nbx = (uint32_t)(r.x1 - r.x0 + ubw - 1) / (uint32_t)ubw;
+		for (uint32_t local = 0; local < W.start[t + 1] - W.start[t]; ++local, ++u) {
+			if (u >= max_units) continue;
+			const int x0 = r.x0 + (int)(local % nbx) * ubw, y0 = r.y0 + (int)(local / nbx) * ubh;
+			int32_t *o = units_out + 6 * u;
+			o[0] = x0; o[1] = y0; o[2] = std::min(x0 + ubw, r.x1); o[3] = std::min(y0 + ubh, r.y1); o[4] = ubw * ubh; o[5] = level;
+		}
+	}
+	return CRH_OK;
+}
+
+int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, float *dev_fb) {
+	if (!c || !P || !dev_fb || (!tiles && tile_count)) return fail(CRH_ERR_INVALID, "crh_render_tiles: NULL argument");
+	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_render_tiles: no scene uploaded");
+	if (P->image_width <= 0 || P->image_height <= 0 || P->pass_count < 0 || P->first_pass < 0 || P->max_passes < P->first_pass + P->pass_count)
+		return fail(CRH_ERR_INVALID, "crh_render_tiles: bad render parameters");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	(void)resolveTimes(c, false);
+	const bool wg = c->kernel == CRH_KERNEL_WG;
+	const PlanKnobs knobs{c->unitItems, c->unitsPerWave, c->tailPercent, c->tail2Percent, c->passChunk, c->cuCount, c->blocksPerCU, wg};
+	WorkPlan plan;
+	{
+		std::string perr;
+		const int prc = planWork(P, tiles, tile_count, knobs, plan, perr);
+		if (prc != CRH_OK) return fail(prc, perr);
+	}
+	if (plan.total == 0 || P->pass_count == 0) return CRH_OK;
+	const std::vector<crh_tile> &work = plan.work;
+	const std::vector<uint32_t> &start = plan.start;
+	const uint32_t work_count = (uint32_t)work.size();
+	const uint64_t total = plan.total;
+	const int bw = plan.bw, bh = plan.bh, sbw = plan.sbw, sbh = plan.sbh, tbw = plan.tbw, tbh = plan.tbh, chunk = plan.chunk;
+	const uint32_t firstSmall = plan.firstSmall, firstTiny = plan.firstTiny, grid = plan.grid;
 	c->lastGrid = grid;
 	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > 8192) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
 	{

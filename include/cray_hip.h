@@ -343,6 +343,11 @@ int crh_kernel_time_ms(crh_ctx *ctx, float *last_ms, double *total_ms, uint64_t 
 enum crh_math_function { CRH_MATH_SINF = 0, CRH_MATH_COSF, CRH_MATH_SINCOSF_SIN, CRH_MATH_SINCOSF_COS, CRH_MATH_LOGF, CRH_MATH_LOG10F,
                          CRH_MATH_ATANF, CRH_MATH_ACOSF, CRH_MATH_ASINF, CRH_MATH_TANF, CRH_MATH_POWF, CRH_MATH_ATAN2F };
 int crh_debug_eval_math(crh_ctx *ctx, int function, const float *x_host, const float *y_host, uint64_t n, float *out_host);
+/* Debug / test entry that needs NO device: the work units crh_render_tiles would hand to the kernel for this dispatch on a GPU with
+ * cu_count compute units, at the default options, in hand-out order. units_out (may be NULL): six ints per unit — the pixel rectangle
+ * x0, y0, x1, y1 (clipped to its tile), the block area in pixels, the taper level (0 regular, 1 quarter blocks, 2 sixteenth blocks). */
+int crh_debug_plan_units(const crh_render_params *params, const crh_tile *tiles, uint32_t tile_count, uint32_t cu_count, int32_t *units_out,
+						 uint64_t max_units, uint64_t *unit_count_out, int32_t *pass_chunk_out);
 
 /* Diagnostic / parity entry: getClosestIsect (pathtrace.c:26-30) for n caller-supplied world-space
  * rays (6 floats each: start xyz, direction xyz). Host in, host out. */

@@ -8,7 +8,7 @@ pkg = load_package(); api = pkg.api; abi = pkg.abi
 name, w, h, spp, b, reps = sys.argv[1], *map(int, sys.argv[2:7])
 ctx = api.Context(0)
 ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
-ctx.upload(api.Scene(os.path.join(BUILT, name + ".blob")))
+ctx.upload(api.Scene(name if name.endswith(".blob") else os.path.join(BUILT, name + ".blob")))
 fb = ctx.framebuffer(w, h)
 for _ in range(reps):
     ctx.clear(fb, w, h); ctx.reset_counters()

@@ -42,6 +42,14 @@ using namespace crh;
 #define CRH_STACK_LDS 23         /* traversal stack entries kept in LDS per lane; with the 13 park slots, the id stacks and cursors: < 40 KB per block, 4 blocks per CU */
 #endif
 
+/* CRH_LOCKSTEP(): marks a place where the lanes of a wave hand data to each other through LDS with no wave collective in between,
+ * relying on what the hardware guarantees anyway — a wave executes in lockstep and its LDS operations in program order. It expands to
+ * nothing here; the CPU emulation of these kernels (tests/emu/hipemu, test infrastructure), whose lanes run one after the other from
+ * collective to collective, makes it a rendezvous of the wave. */
+#ifndef CRH_LOCKSTEP
+#define CRH_LOCKSTEP() do { } while (0)
+#endif
+
 /* ---- error plumbing ---------------------------------------------------------------------------- */
 static thread_local std::string t_err;
 static int fail(int code, const std::string &msg) { t_err = msg; return code; }
@@ -288,6 +296,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 				const int nE = 64 - nN - nT - nC - nF;                        /* idle lanes */
 				const int raysQ = wq[WQ_RAYS], hitsQ = wq[WQ_HITS], missQn = wq[WQ_MISSES], freeQ = wq[WQ_FREE];
 				const uint32_t nextItem = (uint32_t)wq[WQ_NEXT_ITEM];
+				CRH_LOCKSTEP();               /* every lane has read the fill levels before lane 0 updates them at the end of the step */
 				const bool canGen = nextItem < nItems && freeQ >= 64;
 				const int walkers = nN + nT + nC;
 				enum { ST_NODE, ST_TRI, ST_CTRL, ST_SWAP, ST_GEN, ST_SHADE, ST_MISS, ST_END };
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 								if (take[p]) hits[(uint32_t)(hitsQ - n) + tr[p]] = (uint16_t)e[p];
 								if (keep[p]) hits[kr[p]] = (uint16_t)e[p];
 							}
+							CRH_LOCKSTEP();        /* the batch below reads entries other lanes have just written */
 						}
 						/* the per-class counts after this batch */
 #pragma unroll

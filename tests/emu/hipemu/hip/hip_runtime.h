@@ -1,0 +1,185 @@
+/*
+ * hipemu — a HIP-on-CPU shim, TEST INFRASTRUCTURE ONLY (tests/emu/): enough of <hip/hip_runtime.h> to compile
+ * c-ray_amd/csrc/cray_hip.hip — the product's kernels AND its C-ABI host code, unmodified — with g++ for x86-64 and to run
+ * the kernels as what they are: SPMD programs of 64-lane waves that talk through ballots, shuffles, LDS and atomics.
+ *
+ * Why: the CPU-only test tier already pins the LANE code (tests/emu/emu.cpp compiles pt_device.h for the host); what it could not
+ * reach is the WAVE machine around it — k_pathtrace's scheduler, id stacks, path table, work queue, staging and fold, and the
+ * host side of crh_render_tiles (work plan -> queue -> launch). With this shim the very same source runs on the CPU, so kernel
+ * orchestration is checked bit for bit against the oracle without a GPU (tests/test_kernel_emu.py), and scheduler changes can be
+ * developed and counted (steps per kind, lanes per step) before they cost GPU minutes.
+ *
+ * How: every lane is a fiber (a few lines of x86-64 context switch, no ucontext system calls); a lane runs until it reaches a
+ * wave collective (__ballot, __shfl_xor, readfirstlane), a block barrier (__syncthreads), s_sleep, or the end of the kernel; when
+ * all live lanes of a wave wait at the same collective it is resolved and they continue. Lanes that have left the kernel count as
+ * inactive, as on the hardware. Collectives inside divergent control flow that only part of a wave reaches are NOT modelled (the
+ * kernels have none; the runtime aborts if lanes wait at different call sites). The waves of a block take turns one collective
+ * at a time, blocks are spread over OS threads, `__shared__` is `static thread_local` (a block lives on one OS thread).
+ * Kernel launches are synchronous, streams and events are bookkeeping, hipMalloc is the host heap.
+ *
+ * Never linked into libcray_hip.so, never used by bench.py or the product: the product has no CPU path.
+ */
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <functional>
+
+/* ---- language ------------------------------------------------------------------------------------------------------------------ */
+#define __global__
+#define __device__
+#define __host__
+#define __constant__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#ifndef __clang__
+#define __builtin_assume(x) ((void)0)
+#endif
+
+struct hipemu_uint3 { unsigned x, y, z; };
+struct dim3 {
+	unsigned x, y, z;
+	dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hipemu {
+
+enum Wait { W_RUN = 0, W_BALLOT, W_SHFL_XOR, W_FIRSTLANE, W_LOCKSTEP, W_BARRIER, W_SLEEP, W_DONE };
+
+struct Lane {
+	void *sp;                       /* saved stack pointer while switched out */
+	int state;                      /* enum Wait */
+	const void *site;               /* call site of the collective the lane waits at */
+	uint64_t arg, arg2, res;
+	hipemu_uint3 tIdx, bIdx, bDim, gDim;
+};
+
+extern thread_local Lane *t_lane;   /* the lane that is running on this OS thread */
+uint64_t collective(int kind, uint64_t arg, uint64_t arg2, const void *site);
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+
+/* statistics of the launches so far (all threads): collectives resolved, lane switches */
+struct Stats { uint64_t launches, blocks, collectives, switches; };
+Stats stats();
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::t_lane->tIdx)
+#define blockIdx (hipemu::t_lane->bIdx)
+#define blockDim (hipemu::t_lane->bDim)
+#define gridDim (hipemu::t_lane->gDim)
+
+/* ---- wave / block intrinsics ------------------------------------------------------------------------------------------------------ */
+/* one address per textual call site: lanes of a wave must wait at the SAME collective */
+#define HIPEMU_SITE ([]() -> const void * { static const char tag = 0; return &tag; }())
+#define __ballot(pred) hipemu::collective(hipemu::W_BALLOT, (pred) ? 1u : 0u, 0, HIPEMU_SITE)
+static __forceinline__ int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static __forceinline__ int __popc(unsigned v) { return __builtin_popcount(v); }
+template <class T>
+static __forceinline__ T hipemu_shfl_xor(T v, int laneMask, const void *site) {
+	static_assert(sizeof(T) <= 8, "shuffle of at most 64 bits");
+	uint64_t a = 0;
+	memcpy(&a, &v, sizeof(T));
+	const uint64_t r = hipemu::collective(hipemu::W_SHFL_XOR, a, (uint64_t)laneMask, site);
+	T out;
+	memcpy(&out, &r, sizeof(T));
+	return out;
+}
+#define __shfl_xor(v, laneMask) hipemu_shfl_xor((v), (laneMask), HIPEMU_SITE)
+template <class T>
+static __forceinline__ T hipemu_readfirstlane(T v, const void *site) {
+	uint64_t a = 0;
+	memcpy(&a, &v, sizeof(T));
+	const uint64_t r = hipemu::collective(hipemu::W_FIRSTLANE, a, 0, site);
+	T out;
+	memcpy(&out, &r, sizeof(T));
+	return out;
+}
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane((v), HIPEMU_SITE)
+static __forceinline__ unsigned hipemu_lane() { return (hipemu::t_lane->tIdx.x + hipemu::t_lane->tIdx.y * hipemu::t_lane->bDim.x) & 63u; }
+/* mbcnt: the number of set mask bits below this lane (+ base) */
+static __forceinline__ unsigned hipemu_mbcnt_lo(unsigned mask, unsigned base) {
+	const unsigned l = hipemu_lane();
+	return base + (unsigned)__builtin_popcount(l >= 32u ? mask : (mask & ((1u << l) - 1u)));
+}
+static __forceinline__ unsigned hipemu_mbcnt_hi(unsigned mask, unsigned base) {
+	const unsigned l = hipemu_lane();
+	return base + (l > 32u ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32u)) - 1u)) : 0u);
+}
+#define __builtin_amdgcn_mbcnt_lo(m, b) hipemu_mbcnt_lo(m, b)
+#define __builtin_amdgcn_mbcnt_hi(m, b) hipemu_mbcnt_hi(m, b)
+/* cray_hip.hip's marker for "the lanes exchange data through LDS here, relying on lockstep": a rendezvous of the wave */
+#define CRH_LOCKSTEP() ((void)hipemu::collective(hipemu::W_LOCKSTEP, 0, 0, HIPEMU_SITE))
+#define __syncthreads() ((void)hipemu::collective(hipemu::W_BARRIER, 0, 0, HIPEMU_SITE))
+static __forceinline__ void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static __forceinline__ void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_sleep(n) ((void)hipemu::collective(hipemu::W_SLEEP, 0, 0, nullptr))
+static __forceinline__ unsigned long long wall_clock64() {       /* 100 MHz ticks, like s_memrealtime */
+	return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
+
+/* device-side min / max (HIP declares them at global scope) */
+template <class T> static __forceinline__ T min(T a, T b) { return b < a ? b : a; }
+template <class T> static __forceinline__ T max(T a, T b) { return a < b ? b : a; }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+
+/* ---- atomics (blocks run on several OS threads) ---------------------------------------------------------------------------------------- */
+static __forceinline__ unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static __forceinline__ int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static __forceinline__ unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static __forceinline__ unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static __forceinline__ int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static __forceinline__ unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
+static __forceinline__ int atomicCAS(int *p, int cmp, int v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
+static __forceinline__ unsigned atomicExch(unsigned *p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+static __forceinline__ int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+/* the kernels address LDS words through volatile pointers */
+static __forceinline__ int atomicCAS(volatile int *p, int cmp, int v) { return atomicCAS((int *)p, cmp, v); }
+static __forceinline__ int atomicAdd(volatile int *p, int v) { return atomicAdd((int *)p, v); }
+static __forceinline__ int atomicExch(volatile int *p, int v) { return atomicExch((int *)p, v); }
+static __forceinline__ unsigned atomicOr(volatile unsigned *p, unsigned v) { return atomicOr((unsigned *)p, v); }
+
+/* ---- runtime API (the subset cray_hip.hip uses) ------------------------------------------------------------------------------------------ */
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidDevice = 101 } hipError_t;
+typedef struct hipemu_stream *hipStream_t;
+typedef struct hipemu_event *hipEvent_t;
+typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; };
+#define hipStreamNonBlocking 1u
+#define hipHostMallocDefault 0u
+#define hipEventDisableTiming 2u
+
+const char *hipGetErrorString(hipError_t e);
+hipError_t hipGetLastError(void);
+hipError_t hipGetDeviceCount(int *n);
+hipError_t hipSetDevice(int device);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device);
+hipError_t hipMalloc(void **p, size_t bytes);
+template <class T> static inline hipError_t hipMalloc(T **p, size_t bytes) { return hipMalloc((void **)p, bytes); }
+hipError_t hipFree(void *p);
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void *p);
+hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t hipMemset(void *dst, int value, size_t bytes);
+hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t s);
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipEventCreate(hipEvent_t *e);
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+	hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

@@ -648,10 +648,12 @@ __device__ __forceinline__ bool wgLock(int *lockWord, wg_int *ctl, uint32_t lane
 			if (++spins > (1u << 24) || ctl[CT_ABORT]) { ctl[CT_ABORT] = 1; atomicOr(errFlag, 1u); break; }
 		}
 	}
+	CRH_LOCKSTEP();          /* the other lanes wait for lane 0's spin */
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	return ctl[CT_ABORT] == 0;
 }
 __device__ __forceinline__ void wgUnlock(int *lockWord, uint32_t lane) {
+	CRH_LOCKSTEP();          /* every lane is through the critical section before lane 0 opens the lock */
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          /* this wave's id / counter writes are in LDS before the lock opens */
 	if (lane == 0) __hip_atomic_store(lockWord, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 				const int nH = ctl[CT_HITS], nM = ctl[CT_MISSES], nR = ctl[CT_RAYS];
 				const uint32_t nextItem = (uint32_t)ctl[CT_NEXT];
 				const int nFree = ctl[CT_FREE];
+				CRH_LOCKSTEP();               /* one consistent reading of the control words for the whole wave */
 				const bool canGen = nextItem < nItems && nFree >= 64;
 				enum { JB_SHADE, JB_MISS, JB_GEN, JB_WALK, JB_WAIT };
 				int job = JB_WAIT;
@@ -761,6 +764,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 					const int n = min(hq, 64);
 					uint32_t id = 0;
 					if ((int)lane < n) id = idsA[NP - hq + (int)lane];
+					CRH_LOCKSTEP();
 					if (lane == 0) ctl[CT_HITS] = hq - n;
 					wgUnlock(lockWord, lane);
 					if (n == 0) continue;
@@ -790,6 +794,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 					const int rq = ctl[CT_RAYS], fq = ctl[CT_FREE];
 					if (cont) idsA[rq + (int)laneRank(cm)] = (uint16_t)id;
 					if (done) idsB[NP - 1 - fq - (int)laneRank(dm)] = (uint16_t)id;
+					CRH_LOCKSTEP();
 					if (lane == 0) { ctl[CT_RAYS] = rq + (int)__popcll(cm); ctl[CT_FREE] = fq + (int)__popcll(dm); }
 					wgUnlock(lockWord, lane);
 					idlePolls = 0;
@@ -801,6 +806,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 					const int n = min(mq, 64);
 					uint32_t id = 0;
 					if ((int)lane < n) id = idsB[mq - n + (int)lane];
+					CRH_LOCKSTEP();
 					if (lane == 0) ctl[CT_MISSES] = mq - n;
 					wgUnlock(lockWord, lane);
 					if (n == 0) continue;
@@ -822,6 +828,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 					if (!wgLock(lockWord, ctl, lane, errFlag)) break;
 					const int fq = ctl[CT_FREE];
 					if ((int)lane < n) idsB[NP - 1 - fq - (int)lane] = (uint16_t)id;
+					CRH_LOCKSTEP();
 					if (lane == 0) ctl[CT_FREE] = fq + n;
 					wgUnlock(lockWord, lane);
 					idlePolls = 0;
@@ -839,6 +846,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 					const int n = (int)__popcll(vm);
 					uint32_t id = 0;
 					if (valid) id = idsB[NP - fq + (int)laneRank(vm)];
+					CRH_LOCKSTEP();
 					if (lane == 0 && ok) { ctl[CT_FREE] = fq - n; ctl[CT_NEXT] = (int)(it0 + 64u); }
 					wgUnlock(lockWord, lane);
 					if (!ok) continue;
@@ -853,6 +861,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 						if (!wgLock(lockWord, ctl, lane, errFlag)) break;
 						const int rq = ctl[CT_RAYS];
 						if (valid) idsA[rq + (int)laneRank(vm)] = (uint16_t)id;
+						CRH_LOCKSTEP();
 						if (lane == 0) ctl[CT_RAYS] = rq + n;
 						wgUnlock(lockWord, lane);
 					}
@@ -902,6 +911,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 							const int take = draining ? 0 : min(rq, (int)__popcll(em));
 							const bool got = idle && (int)er < take;
 							if (got) myPath = idsA[rq - take + (int)er];
+							CRH_LOCKSTEP();
 							if (lane == 0) { ctl[CT_HITS] = hq2; ctl[CT_MISSES] = mq2; ctl[CT_RAYS] = rq - take; ctl[CT_DRAINERS] = drainers; }
 							wgUnlock(lockWord, lane);
 							if (got) {

@@ -1,0 +1,88 @@
+"""CPU tier: the kernels of libcray_hip.so themselves — not a restatement of them — run on the CPU and are held to the GPU tier's bar.
+
+tests/emu/libcray_hip_emu.so is c-ray_amd/csrc/cray_hip.hip (k_pathtrace, k_pathtrace_wg, k_trace_rays, k_fold_black, k_to_srgb8 AND the
+C-ABI host code around them: work planning, queues, launches, counters) compiled unmodified against a HIP-on-CPU shim
+(tests/emu/hipemu: every lane a fiber, 64-lane waves that meet at ballots / shuffles / readfirstlane, blocks with __syncthreads, LDS as
+block-local statics, atomics as atomics). The tests below start the GPU tier's own test functions (`-m gpu`) in a child pytest whose
+api.py loads that library (CRH_LIB) — same tests, same source, same C-ABI, no GPU: frames must equal the reference's float buffers bit
+for bit, ray records the oracle's, every dispatch decomposition / scheduler option / kernel form the same frame.
+
+What this tier adds to tests/test_emu_parity.py (which pins the LANE code): the wave machine — scheduler, id stacks, path table, shade
+class batches, work queue, tapered units, staging and the in-order fold, the workgroup kernel's lock protocol — and the host side of
+crh_render_tiles. What it cannot see: anything that depends on the hardware's timing, register allocation or memory model (the GPU tier
+keeps that), and the GPU BVH builder (DPP scans; not part of the emulation).
+
+TEST INFRASTRUCTURE: the emulation library is never loaded by the product, by bench.py or by the GPU tier.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(REPO, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libcray_hip_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libcray_hip_emu.so"])
+    return EMU_LIB
+
+
+def run_gpu_tier_on_emulation(emu_lib, files, select, expect_passed):
+    """Run the selected `-m gpu` tests in a child pytest against the emulation library; every one of them must pass."""
+    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2")
+    cmd = [sys.executable, "-m", "pytest", *[os.path.join(REPO, "tests", f) for f in files], "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=1700)
+    tail = (r.stdout[-2500:] + "\n" + r.stderr[-1500:])
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) == expect_passed, f"expected {expect_passed} tests to run on the emulation:\n{tail}"
+    assert "skipped" not in r.stdout.splitlines()[-1], tail
+
+
+def test_the_shim_itself(tmp_path):
+    """Known answers for the emulation runtime: ballots with exited lanes, shuffles, ranks, barrier, atomics, a spin lock, the rendezvous."""
+    exe = str(tmp_path / "hipemu_selftest")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(EMU_DIR, "hipemu"), "-x", "c++",
+                           os.path.join(EMU_DIR, "hipemu_selftest.cpp"), os.path.join(EMU_DIR, "hipemu", "hipemu.cpp"), "-o", exe])
+    for threads in ("1", "4"):
+        r = subprocess.run([exe], env=dict(os.environ, HIPEMU_THREADS=threads), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_emulation_library_is_the_product_source(emu_lib):
+    """The emulation builds the product's own file (no copy of the kernels under tests/) and exports the whole C-ABI."""
+    src = open(os.path.join(EMU_DIR, "kernel_emu.cpp")).read()
+    assert '#include "../../c-ray_amd/csrc/cray_hip.hip"' in src
+    assert "__global__" not in src, "kernel code belongs to c-ray_amd/csrc, not to the emulation harness"
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", emu_lib], text=True)
+    header = open(os.path.join(REPO, "include", "cray_hip.h")).read()
+    declared = set(re.findall(r"\b(crh_[a-z0-9_]+)\s*\(", header))
+    exported = set(re.findall(r" T (crh_[a-z0-9_]+)", syms))
+    assert declared - exported == set(), sorted(declared - exported)
+
+
+def test_k_trace_rays_on_emulation(emu_lib):
+    run_gpu_tier_on_emulation(emu_lib, ["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6)
+
+
+def test_k_pathtrace_frames_on_emulation(emu_lib):
+    """The wave machine renders the six scene fixtures: the reference's float buffer, bit for bit."""
+    run_gpu_tier_on_emulation(emu_lib, ["test_gpu_parity.py"], "test_image_parity_vs_reference", 6)
+
+
+def test_schedules_decompositions_and_edge_cases_on_emulation(emu_lib):
+    """Shade-class batches, tiles / pass chunks / unit sizes / taper levels, the Halton sampler, empty / ragged / single-pixel dispatches,
+    bounces <= 0 (k_fold_black), degenerate rays, k_to_srgb8, the error paths of the C-ABI."""
+    run_gpu_tier_on_emulation(emu_lib, ["test_gpu_parity.py"],
+                              "shade_class_batches or dispatch_decompositions or interactive_mode or edge_cases or zero_component or srgb8 or error_paths", 7)
+
+
+def test_node_programs_volumes_and_the_workgroup_kernel_on_emulation(emu_lib):
+    """The rare-features instantiations (node programs, volumes: sampler draws inside the walk) and k_pathtrace_wg with its LDS lock."""
+    run_gpu_tier_on_emulation(emu_lib, ["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"],
+                              "test_gpu_node_zoo or test_gpu_volumes or workgroup_kernel", 4)

@@ -592,6 +592,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	}
 }
 
+#ifdef CRH_EXP_ROLLING_UNITS          /* experimental kernel form (not in the default library): see the header */
+#define CRH_KERNEL_ROLL 2
+#include "pathtrace_roll.h"
+#endif
+
 /* ================================================================================================================================
  * k_pathtrace_wg — the WORKGROUP-cooperative form of the machine above (CRH_OPT_KERNEL = CRH_KERNEL_WG).
  *
@@ -1160,6 +1165,32 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
 #define CRH_LAUNCH_WG(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_wg<LEVEL, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 													  c->dCounters, c->dStage, chunk, c->schedWg, c->dQueues, c->dOvf, c->dErr)
+#ifdef CRH_EXP_ROLLING_UNITS
+#define CRH_LAUNCH_ROLL(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_roll<LEVEL, 4, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
+														  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf)
+	if (c->kernel == CRH_KERNEL_ROLL) {
+#ifdef CRH_DEV_ONLY_BENCH_VARIANT
+#if defined(CRH_DEV_ONLY_LEVEL2)              /* the counting instantiation (tools/emu_sched_stats.py) */
+		CRH_LAUNCH_ROLL(2, true, 0);
+#elif defined(CRH_DEV_ONLY_PROG)
+		CRH_LAUNCH_ROLL(1, true, 0);
+#else
+		CRH_LAUNCH_ROLL(1, false, 0);
+#endif
+#else
+		const bool halton = c->sampler == CRH_SAMPLER_HALTON;
+		if (c->counterLevel >= 2) {
+			if (c->hasPrograms) { if (halton) CRH_LAUNCH_ROLL(2, true, 1); else CRH_LAUNCH_ROLL(2, true, 0); }
+			else { if (halton) CRH_LAUNCH_ROLL(2, false, 1); else CRH_LAUNCH_ROLL(2, false, 0); }
+		} else {
+			if (c->hasPrograms) { if (halton) CRH_LAUNCH_ROLL(1, true, 1); else CRH_LAUNCH_ROLL(1, true, 0); }
+			else { if (halton) CRH_LAUNCH_ROLL(1, false, 1); else CRH_LAUNCH_ROLL(1, false, 0); }
+		}
+#endif
+		return hipGetLastError();
+	}
+#undef CRH_LAUNCH_ROLL
+#endif
 #ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/kernel_regs.py): one instantiation compiles in seconds */
 #ifdef CRH_DEV_ONLY_PROG
 	if (wg) CRH_LAUNCH_WG(1, true, 0); else CRH_LAUNCH(1, 4, true, 0);
@@ -1344,6 +1375,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			if (value < 1 || value > 4096) return fail(CRH_ERR_INVALID, "pass chunk must be 1..4096");
 			c->passChunk = (int)value; return CRH_OK;
 		case CRH_OPT_KERNEL:
+#ifdef CRH_EXP_ROLLING_UNITS
+			if (value == CRH_KERNEL_ROLL) { c->kernel = (int)value; return CRH_OK; }
+#endif
 			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_WAVE or CRH_KERNEL_WG");
 			c->kernel = (int)value; return CRH_OK;
 		case CRH_OPT_SCHED_WG: {       /* linger | drainAt << 8 | maxDrainers << 20 | partialMin << 24 | walkMin << 32 | fillTo << 40 */
@@ -1613,7 +1647,10 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	c->lastGrid = grid;
 	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > 8192) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
 	{
-		const size_t need = (size_t)grid * (wg ? 1 : CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
+		size_t need = (size_t)grid * (wg ? 1 : CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
+#ifdef CRH_EXP_ROLLING_UNITS
+		if (c->kernel == CRH_KERNEL_ROLL) need *= CRH_ROLL_SLOTS;      /* one sample slab per open job */
+#endif
 		if (need > c->stageFloats) {
 			HIP_TRY(hipStreamSynchronize(c->stream));
 			if (c->dStage) HIP_TRY(hipFree(c->dStage));

@@ -1,0 +1,516 @@
+/*
+ * pathtrace_roll.h — k_pathtrace_roll: the wave machine of k_pathtrace (cray_hip.hip) with ROLLING work units.
+ * EXPERIMENTAL: compiled only with -DCRH_EXP_ROLLING_UNITS (CRH_OPT_KERNEL = CRH_KERNEL_ROLL); the default library does not contain it.
+ *
+ * Why. k_pathtrace works a unit (a pixel block x a chunk of passes) to its last path before it pulls the next one: every unit ramps the
+ * wave's path table up and drains it again, and while it drains the walk steps run with ever fewer lanes. The kernel emulation
+ * (tests/emu, tools/emu_sched_stats.py) prices that exactly: on hdr.json the default 2048-path units take 1.049 M node steps at 38.4
+ * lanes per step where 32768-path units take 0.912 M at 44.2 — ramp and drain are 13 % of all node steps, 10 % of the modelled time —
+ * but bigger units are slower on the GPU (r02_probe_unit_size.log: their sample slabs and their coarser tail cost more than they save).
+ * Rolling units take the drain away without growing the unit: a wave keeps up to CRH_ROLL_SLOTS jobs open (a ring). When the items of
+ * the job it generates from run out, it pulls the next job into the next free slot and keeps the path table full from there, while the
+ * last paths of the older jobs finish; a job is folded into the frame when its last sample is staged (in job order, so a pixel's chunks
+ * still fold in pass order), which frees its slot. Only the last jobs of a wave drain.
+ *
+ * What stays: every step of a path — and so every result — is the one k_pathtrace runs (same lane code, same id stacks, same scheduler
+ * rules); the frame is the same bit for bit (tests/test_kernel_emu.py on the CPU, tests/test_gpu_parity.py on the GPU).
+ * Job state lives in LDS next to the stack fill levels (wave-uniform: lane 0 writes, every lane reads); the hit stack is 136 entries
+ * instead of 192 (it never holds more than 64 waiting + 64 retired hits), which pays for it: the LDS footprint stays below 40 KB.
+ */
+#pragma once
+
+#define CRH_ROLL_HITS_MAX 136u
+#define CRH_ROLL_IDS_MISSES (CRH_IDS_HITS + 2u * CRH_ROLL_HITS_MAX)
+#define CRH_ROLL_IDS_BYTES (CRH_ROLL_IDS_MISSES + 128u)
+#ifndef CRH_ROLL_SLOTS
+#define CRH_ROLL_SLOTS 4u                      /* jobs a wave keeps open (a ring: opened and folded in order); 2..4 */
+#endif
+#ifndef CRH_ROLL_FIFO
+#define CRH_ROLL_FIFO 0                        /* 1: rays are walked oldest first (measured in the emulation: no fewer steps — the last paths of a job are late
+                                                * because they are long, not because they wait under newer rays) */
+#endif
+#define CRH_ROLL_SLOT_SHIFT 30u                /* item word of a path record: slot of its job << 30 | item index inside the job */
+#define CRH_ROLL_ITEM_MASK 0x3FFFFFFFu
+
+template <int LEVEL, int WPS, bool PROG, int SAMP>
+__global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
+																 unsigned long long *counters,
+																 float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll) {
+	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
+	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
+	/* wave-uniform words: stack fill levels, shade-class counts, the ring of job slots */
+	enum { RQ_RAYS, RQ_HITS, RQ_MISSES, RQ_FREE, RQ_CLS_LO, RQ_CLS_HI,
+	       RQ_GENLEFT,   /* items not yet generated of the youngest open job (0: none open, or all generated) */
+	       RQ_FLAGS,     /* bit 0: the oldest open job is complete (all items generated, every sample staged) -> fold it;
+	                      * bit 1: a slot is free and the work queue is not known to be empty -> the next job can be opened.
+	                      * Both words are derived from the ones below by lane 0 whenever those change (refreshJobWords), so that the
+	                      * scheduler reads two words per round instead of the slots */
+	       RQ_HEAD,      /* the open jobs are the slots head, head + 1, ... (mod CRH_ROLL_SLOTS): head folds first, ... */
+	       RQ_OPEN,      /* ... this many of them; ... */
+	       RQ_GEN,       /* ... items are generated from the youngest: slot (head + open - 1) mod CRH_ROLL_SLOTS */
+	       RQ_DRY,       /* the work queue is empty */
+	       RQ_SLOT0 };
+	enum { SJ_X0, SJ_Y0, SJ_WH /* w | h << 16 */, SJ_BWBH /* bw | bh << 16 */, SJ_PASS0, SJ_PASSN, SJ_NEXT, SJ_OUT, SJ_WORDS };     /* SJ_OUT: paths generated, sample not yet staged */
+	enum { NS = (int)CRH_ROLL_SLOTS, RQ_WORDS = RQ_SLOT0 + NS * SJ_WORDS };
+	static_assert(NS >= 2 && NS <= 4, "2..4 job slots (two bits of the item word)");
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_ROLL_IDS_BYTES + RQ_WORDS * 4) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+	const DScene S = globalize(Sarg);
+	CRH_EM_POW_TABLES_INIT();
+	const unsigned long long tStart = wall_clock64();
+	uint32_t unitsDone = 0;
+	LdsStack stk;
+	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
+	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
+	CountersT<LEVEL, PROG> cnt;
+	memset(&cnt, 0, sizeof(cnt));
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
+	__shared__ uint8_t s_cls[256];
+	const bool sorted = S.shade_classes >= 4u && S.instance_count <= 256u;
+	if (sorted) {
+		for (uint32_t i = threadIdx.x; i < S.instance_count; i += CRH_BLOCK) s_cls[i] = (uint8_t)CRH_DINST_CLASS(S.instances[i].kind);
+		__syncthreads();
+	}
+	stk.ovf = (glb_u32 *)ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_OVF_WORDS_PER_WAVE;
+	const size_t slabFloats = (size_t)Q.bw * Q.bh * chunk * 3;           /* one job's samples; a wave owns one slab per slot */
+	float *const myStage = stage + (size_t)wave * (size_t)NS * slabFloats;
+	const int passEnd = P.first_pass + P.pass_count;
+	f4 *const ptab = (f4 *)(queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS);
+	__shared__ int s_rq[(CRH_BLOCK / 64) * RQ_WORDS];
+	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_ROLL_IDS_BYTES];
+	typedef volatile __attribute__((address_space(3))) int lds_int;
+	typedef volatile __attribute__((address_space(3))) uint8_t lds_u8;
+	typedef volatile __attribute__((address_space(3))) uint16_t lds_u16;
+	lds_int *const wq = (lds_int *)&s_rq[(threadIdx.x >> 6) * RQ_WORDS];
+	lds_u8 *const ids = (lds_u8 *)&s_ids[(threadIdx.x >> 6) * CRH_ROLL_IDS_BYTES];
+	lds_u16 *const hits = (lds_u16 *)&s_ids[(threadIdx.x >> 6) * CRH_ROLL_IDS_BYTES + CRH_IDS_HITS];
+	auto loadJob = [&](int s) {
+		lds_int *j = wq + RQ_SLOT0 + s * SJ_WORDS;
+		BlockJob J;
+		const int wh = j[SJ_WH], bwbh = j[SJ_BWBH];
+		J.x0 = j[SJ_X0]; J.y0 = j[SJ_Y0]; J.w = wh & 0xFFFF; J.h = wh >> 16; J.bw = bwbh & 0xFFFF; J.bh = bwbh >> 16; J.passBegin = j[SJ_PASS0]; J.passCount = j[SJ_PASSN];
+		return J;
+	};
+	/* lane 0, after it changed a job's words: the two words the scheduler reads every round */
+	auto refreshJobWords = [&]() {
+		const int head = wq[RQ_HEAD], open = wq[RQ_OPEN];
+		int left = 0, flags = 0;
+		if (open > 0) {
+			lds_int *gj = wq + RQ_SLOT0 + wq[RQ_GEN] * SJ_WORDS, *oj = wq + RQ_SLOT0 + head * SJ_WORDS;
+			const int gb = gj[SJ_BWBH], ob = oj[SJ_BWBH];
+			left = (gb & 0xFFFF) * (gb >> 16) * gj[SJ_PASSN] - gj[SJ_NEXT];
+			if (left < 0) left = 0;
+			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0) flags |= 1;
+		}
+		if (!wq[RQ_DRY] && open < NS) flags |= 2;
+		wq[RQ_GENLEFT] = left; wq[RQ_FLAGS] = flags;
+	};
+
+	if (lane == 0) {
+		wq[RQ_RAYS] = 0; wq[RQ_HITS] = 0; wq[RQ_MISSES] = 0; wq[RQ_FREE] = (int)CRH_PATHS; wq[RQ_CLS_LO] = 0; wq[RQ_CLS_HI] = 0;
+		wq[RQ_HEAD] = 0; wq[RQ_OPEN] = 0; wq[RQ_GEN] = 0; wq[RQ_DRY] = 0;
+		for (int i = 0; i < NS * SJ_WORDS; ++i) wq[RQ_SLOT0 + i] = 0;
+		refreshJobWords();
+	}
+	for (uint32_t i = lane; i < CRH_PATHS; i += 64u) ids[i] = (uint8_t)i;              /* all slots free */
+	__threadfence_block();
+	Walk w;
+	memset(&w, 0, sizeof(w));
+	w.phase = PH_IDLE;
+	uint32_t myPath = 0;
+	uint32_t guard = 0;                 /* experimental kernel: a wave that spins without finishing gives up (incomplete frame, never a hung GPU) */
+	for (;;) {
+		if (++guard > 60000000u) break;
+		const uint32_t ph = w.phase;
+		TablePort<SAMP> port{ptab + myPath * CRH_PATH_F4};
+		const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
+		const int nF = __popcll(__ballot(ph == PH_SHADE));
+		const int nE = 64 - nN - nT - nC - nF;
+		const int raysQ = wq[RQ_RAYS], hitsQ = wq[RQ_HITS], missQn = wq[RQ_MISSES], freeQ = wq[RQ_FREE];
+		const int itemsLeft = wq[RQ_GENLEFT], jobFlags = wq[RQ_FLAGS];
+		CRH_LOCKSTEP();               /* every lane has read the wave's words before lane 0 updates them at the end of the step */
+		const bool genLeft = itemsLeft > 0;
+		const bool canGen = genLeft && freeQ >= 64;
+		/* the next job can be opened when the job being generated has no items left and a slot is free */
+		const bool canOpen = !genLeft && (jobFlags & 2);
+		const bool foldReady = (jobFlags & 1) != 0;
+		const bool wantGen = raysQ < 64 && (((int)CRH_PATHS - freeQ) < K.fillTo || (nE + nF > 0 && raysQ < nE + nF));
+		const int walkers = nN + nT + nC;
+		enum { ST_NODE, ST_TRI, ST_CTRL, ST_SWAP, ST_GEN, ST_SHADE, ST_MISS, ST_OPEN, ST_FOLD, ST_END };
+		int pick;
+		if (foldReady) pick = ST_FOLD;
+		else if (hitsQ >= 64) pick = ST_SHADE;
+		else if (missQn >= 64) pick = ST_MISS;
+		else if (nF + nE >= K.swapMin && (nF > 0 || (nE > 0 && raysQ > 0))) pick = ST_SWAP;
+		else if (wantGen && canGen) pick = ST_GEN;
+		else if (wantGen && canOpen && freeQ >= 64) pick = ST_OPEN;
+		else if (walkers > 0) {
+			int best = nN * K.wNode;
+			pick = ST_NODE;
+			if (nT * K.wTri > best) { best = nT * K.wTri; pick = ST_TRI; }
+			if (nC * K.wCtrl > best) { best = nC * K.wCtrl; pick = ST_CTRL; }
+		}
+		else if (nF > 0 || (nE > 0 && raysQ > 0)) pick = ST_SWAP;
+		else if (hitsQ > 0) pick = ST_SHADE;
+		else if (canGen) pick = ST_GEN;
+		else if (missQn > 0) pick = ST_MISS;
+		else if (canOpen) pick = ST_OPEN;
+		else pick = ST_END;               /* nothing in flight, nothing queued, no job open, the work queue empty */
+		if (pick == ST_END) break;
+		uint32_t tk = 0;
+		if constexpr (LEVEL >= 2) tk = CRH_TICK();
+		switch (pick) {
+			case ST_NODE: {
+				int now = nN;
+				do {
+					if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
+					if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
+					if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) {
+						if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
+					}
+					if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
+						if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
+					}
+					now = __popcll(__ballot(w.phase == PH_NODE));
+				} while (now * 8 >= nN * K.runNum);
+				break;
+			}
+			case ST_TRI: {
+				int now = nT;
+				do {
+					if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
+					if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_tri += 1; cnt.u_tri += (uint32_t)now; } }
+					now = __popcll(__ballot(w.phase == PH_TRI));
+				} while (now * 8 >= nT * K.runNum);
+				break;
+			}
+			case ST_CTRL:
+				if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
+				if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port); }
+				break;
+			case ST_SWAP: {
+				const bool fin = (ph == PH_SHADE);
+				const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
+				const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
+				uint32_t cls = 0;
+				if (fin) {
+					f4 *q = ptab + myPath * CRH_PATH_F4;
+					q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
+					if (finHit) {
+						q[5].x = asF32((uint32_t)w.hit.inst);
+						if (sorted) cls = (uint32_t)((volatile __attribute__((address_space(3))) uint8_t *)s_cls)[w.hit.inst];
+						hits[(uint32_t)hitsQ + laneRank(hm)] = (uint16_t)(myPath | (cls << 8));
+					} else {
+						ids[CRH_ROLL_IDS_MISSES + (uint32_t)missQn + laneRank(mm)] = (uint8_t)myPath;
+					}
+					w.phase = PH_IDLE;
+				}
+				if (sorted && hm) {
+					uint32_t addLo = 0, addHi = 0;
+#pragma unroll
+					for (uint32_t b = 0; b < 8u; ++b) {
+						const uint32_t nb = (uint32_t)__popcll(__ballot(finHit && cls == b));
+						if (b < 4u) addLo += nb << (8u * b); else addHi += nb << (8u * (b - 4u));
+					}
+					if (lane == 0) { wq[RQ_CLS_LO] = wq[RQ_CLS_LO] + (int)addLo; wq[RQ_CLS_HI] = wq[RQ_CLS_HI] + (int)addHi; }
+				}
+				const bool idle = (w.phase == PH_IDLE);
+				const unsigned long long em = __ballot(idle);
+				const uint32_t er = laneRank(em);
+				const int take = min(raysQ, (int)__popcll(em));
+#if CRH_ROLL_FIFO
+				/* oldest rays first (k_pathtrace pops the newest): the last paths of an older job must not wait under the rays of the
+				 * job being generated, or its fold — and with it its slot — is held up for that job's whole length. The remaining ids move
+				 * down to close the gap: every entry is read, then written (LDS operations of a wave execute in program order). */
+				uint32_t myRay = 0;
+				if (idle && (int)er < take) myRay = ids[CRH_IDS_RAYS + er];
+				{
+					uint32_t mv[4];
+#pragma unroll
+					for (int k = 0; k < 4; ++k) { const uint32_t i = (uint32_t)take + (uint32_t)k * 64u + lane; mv[k] = (int)i < raysQ ? (uint32_t)ids[CRH_IDS_RAYS + i] : 0u; }
+					CRH_LOCKSTEP();
+#pragma unroll
+					for (int k = 0; k < 4; ++k) { const uint32_t i = (uint32_t)take + (uint32_t)k * 64u + lane; if ((int)i < raysQ) ids[CRH_IDS_RAYS + i - (uint32_t)take] = (uint8_t)mv[k]; }
+				}
+				if (idle && (int)er < take) {
+					myPath = myRay;
+#else
+				if (idle && (int)er < take) {
+					myPath = ids[CRH_IDS_RAYS + (uint32_t)(raysQ - take) + er];
+#endif
+					const f4 *q = ptab + myPath * CRH_PATH_F4;
+					const f4 q0 = q[0], q1 = q[1];
+					{ TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port2); }
+				}
+				if (lane == 0) { wq[RQ_HITS] = hitsQ + (int)__popcll(hm); wq[RQ_MISSES] = missQn + (int)__popcll(mm); wq[RQ_RAYS] = raysQ - take; }
+				__threadfence_block();
+				break;
+			}
+			case ST_OPEN: {          /* the next job: the following chunk of the youngest job's unit, or a new unit from the queue */
+				const int o = wq[RQ_HEAD], open = wq[RQ_OPEN];
+				const int s = (o + open) % NS;
+				BlockJob J;
+				bool have = false;
+				if (open > 0) {
+					J = loadJob(wq[RQ_GEN]);
+					if (J.passBegin + J.passCount < passEnd) { J.passBegin += J.passCount; J.passCount = min(chunk, passEnd - J.passBegin); have = true; }
+				}
+				if (!have) {
+					uint32_t unit = 0;
+					if (lane == 0) unit = atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
+					unit = __builtin_amdgcn_readfirstlane(unit);
+					if (unit < Q.total) {
+						++unitsDone;
+						uint32_t lo = 0, hi = Q.ntiles;
+						while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
+						const crh_tile t = asGlobal(Q.tiles)[lo];
+						const uint32_t local = unit - asGlobal(Q.start)[lo];
+						const int ubw = lo >= Q.firstTiny ? Q.tbw : lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstTiny ? Q.tbh : lo >= Q.firstSmall ? Q.sbh : Q.bh;
+						const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + ubw - 1) / (uint32_t)ubw;
+						J.bw = ubw; J.bh = ubh;
+						J.x0 = t.x0 + (int)(local % nbx) * ubw;
+						J.y0 = t.y0 + (int)(local / nbx) * ubh;
+						J.w = min(ubw, t.x1 - J.x0);
+						J.h = min(ubh, t.y1 - J.y0);
+						J.passBegin = P.first_pass;
+						J.passCount = min(chunk, passEnd - P.first_pass);
+						have = true;
+					}
+				}
+				CRH_LOCKSTEP();          /* every lane has read the ring's words */
+				if (lane == 0) {
+					if (have) {
+						lds_int *j = wq + RQ_SLOT0 + s * SJ_WORDS;
+						j[SJ_X0] = J.x0; j[SJ_Y0] = J.y0; j[SJ_WH] = J.w | (J.h << 16); j[SJ_BWBH] = J.bw | (J.bh << 16); j[SJ_PASS0] = J.passBegin; j[SJ_PASSN] = J.passCount;
+						j[SJ_NEXT] = 0; j[SJ_OUT] = 0;
+						wq[RQ_OPEN] = open + 1; wq[RQ_GEN] = s;
+					} else {
+						wq[RQ_DRY] = 1;
+					}
+					refreshJobWords();
+				}
+				__threadfence_block();
+				break;
+			}
+			case ST_GEN: {
+				const int g = wq[RQ_GEN];
+				const BlockJob J = loadJob(g);
+				const uint32_t genNext = (uint32_t)wq[RQ_SLOT0 + g * SJ_WORDS + SJ_NEXT], genItems = genNext + (uint32_t)itemsLeft;
+				const uint32_t item = genNext + lane;
+				int x = 0, y = 0, pass = 0;
+				const bool valid = item < genItems && decodeItem(J, item, x, y, pass);         /* (the ballot below: every lane has read the job's words) */
+				const unsigned long long vm = __ballot(valid);
+				const int n = (int)__popcll(vm);
+				if (valid) {
+					const uint32_t rk = laneRank(vm);
+					const uint32_t id = ids[CRH_IDS_FREE_END - (uint32_t)freeQ + rk];
+					v3 ro, rd;
+					PathRecT<RngT<SAMP>> r;
+					beginPath(S, P, x, y, pass, ro, rd, r, cnt);
+					putPathRay(ptab + id * CRH_PATH_F4, ro, rd, r, item | ((uint32_t)g << CRH_ROLL_SLOT_SHIFT));
+					ids[CRH_IDS_RAYS + (uint32_t)raysQ + rk] = (uint8_t)id;
+				}
+				if (lane == 0) {
+					wq[RQ_RAYS] = raysQ + n; wq[RQ_FREE] = freeQ - n;
+					lds_int *j = wq + RQ_SLOT0 + g * SJ_WORDS;
+					j[SJ_NEXT] = (int)(genNext + 64u); j[SJ_OUT] = j[SJ_OUT] + n;
+					refreshJobWords();
+				}
+				__threadfence_block();
+				break;
+			}
+			case ST_MISS: {
+				const int n = min(missQn, 64);
+				int mySlot = -1;
+				if ((int)lane < n) {
+					const uint32_t id = ids[CRH_ROLL_IDS_MISSES + (uint32_t)(missQn - n) + lane];
+					const f4 *q = ptab + id * CRH_PATH_F4;
+					const f4 q1 = q[1], q2 = q[2], q3 = q[3];
+					v3 ro{0.0f, 0.0f, 0.0f}, rd{q1.x, q1.y, q1.z};
+					PathRecT<RngT<SAMP>> r;
+					r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
+					r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
+					r.rng.state = 0; r.depth = 0;
+					const uint32_t item = asU32(q1.w);
+					mySlot = (int)(item >> CRH_ROLL_SLOT_SHIFT);
+					TravHit h;
+					h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
+					(void)shadeCore(S, P, ro, rd, h, r, cnt);
+					float *so = myStage + (size_t)mySlot * slabFloats + (size_t)(item & CRH_ROLL_ITEM_MASK) * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+					ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - lane] = (uint8_t)id;
+				}
+				int fin[NS];
+#pragma unroll
+				for (int s = 0; s < NS; ++s) fin[s] = (int)__popcll(__ballot(mySlot == s));
+				if (lane == 0) {
+					wq[RQ_MISSES] = missQn - n; wq[RQ_FREE] = freeQ + n;
+#pragma unroll
+					for (int s = 0; s < NS; ++s) if (fin[s]) wq[RQ_SLOT0 + s * SJ_WORDS + SJ_OUT] = wq[RQ_SLOT0 + s * SJ_WORDS + SJ_OUT] - fin[s];
+					refreshJobWords();
+				}
+				__threadfence_block();
+				break;
+			}
+			case ST_FOLD: {          /* the older job is complete: its samples go into the frame in pass order; its slot is free again */
+				const int o = wq[RQ_HEAD], open = wq[RQ_OPEN];
+				const BlockJob J = loadJob(o);
+				__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
+				const float *slab = myStage + (size_t)o * slabFloats;
+				for (uint32_t pix = lane; pix < (uint32_t)(J.bw * J.bh); pix += 64u) foldBlockPixel(P, J, pix, slab, fb);
+				__threadfence_block();                 /* ... and read before a later job overwrites them */
+				CRH_LOCKSTEP();          /* every lane has read the ring's words */
+				if (lane == 0) { wq[RQ_HEAD] = (o + 1) % NS; wq[RQ_OPEN] = open - 1; refreshJobWords(); }
+				__threadfence_block();
+				break;
+			}
+			default: {   /* ST_SHADE */
+				uint32_t clsLo = 0, clsHi = 0;
+				int n = min(hitsQ, 64);
+				if (sorted) {
+				clsLo = (uint32_t)__builtin_amdgcn_readfirstlane(wq[RQ_CLS_LO]); clsHi = (uint32_t)__builtin_amdgcn_readfirstlane(wq[RQ_CLS_HI]);
+				int c8[8];
+#pragma unroll
+				for (int b = 0; b < 8; ++b) c8[b] = (int)(((b < 4 ? clsLo : clsHi) >> (8 * (b & 3))) & 255u);
+				uint32_t fullMask = 0;
+				int partCls = -1, partN = 0;
+				n = 0;
+#pragma unroll
+				for (int it = 0; it < 8; ++it) {
+					int bc = 0, bb = -1;
+#pragma unroll
+					for (int b = 0; b < 8; ++b) if (!((fullMask >> b) & 1u) && c8[b] > bc) { bc = c8[b]; bb = b; }
+					if (bb < 0 || n >= K.shadeMin || partCls >= 0) break;
+					if (n + bc <= 64) { fullMask |= 1u << bb; n += bc; }
+					else { partCls = bb; partN = 64 - n; n = 64; }
+				}
+				if (n < hitsQ) {
+					uint32_t e[3];
+					bool take[3], keep[3];
+					uint32_t tr[3], kr[3];
+					int tBase = 0, kBase = 0, pBase = 0;
+#pragma unroll
+					for (int p = 0; p < 3; ++p) {
+						const uint32_t i = (uint32_t)p * 64u + lane;
+						const bool valid = (int)i < hitsQ;
+						e[p] = valid ? (uint32_t)hits[i] : 0u;
+						const uint32_t ec = e[p] >> 8;
+						const bool part = valid && (int)ec == partCls;
+						const unsigned long long pm = __ballot(part);
+						take[p] = valid && (((fullMask >> ec) & 1u) || (part && pBase + (int)laneRank(pm) < partN));
+						pBase += (int)__popcll(pm);
+						const unsigned long long tm = __ballot(take[p]);
+						tr[p] = (uint32_t)tBase + laneRank(tm);
+						keep[p] = valid && !take[p];
+						const unsigned long long km = __ballot(keep[p]);
+						kr[p] = (uint32_t)kBase + laneRank(km);
+						tBase += (int)__popcll(tm);
+						kBase += (int)__popcll(km);
+					}
+#pragma unroll
+					for (int p = 0; p < 3; ++p) {
+						if (take[p]) hits[(uint32_t)(hitsQ - n) + tr[p]] = (uint16_t)e[p];
+						if (keep[p]) hits[kr[p]] = (uint16_t)e[p];
+					}
+					CRH_LOCKSTEP();        /* the batch below reads entries other lanes have just written */
+				}
+#pragma unroll
+				for (int b = 0; b < 8; ++b) {
+					const uint32_t gone = ((fullMask >> b) & 1u) ? (uint32_t)c8[b] : (b == partCls ? (uint32_t)partN : 0u);
+					if (b < 4) clsLo -= gone << (8 * b); else clsHi -= gone << (8 * (b - 4));
+				}
+				}
+				if constexpr (LEVEL >= 2) { if (lane == 0) cnt.u_shade += (uint32_t)n; }
+				bool cont = false, done = false;
+				int mySlot = -1;
+				uint32_t id = 0;
+				if ((int)lane < n) {
+					id = (uint32_t)hits[(uint32_t)(hitsQ - n) + lane] & 255u;
+					f4 *q = ptab + id * CRH_PATH_F4;
+					const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+					v3 ro{q0.x, q0.y, q0.z}, rd{q1.x, q1.y, q1.z};
+					PathRecT<RngT<SAMP>> r;
+					r.wr = q2.x; r.wg = q2.y; r.wb = q2.z;
+					r.fr = q3.x; r.fg = q3.y; r.fb = q3.z;
+					r.rng.state = (uint64_t)asU32(q2.w) | ((uint64_t)asU32(q3.w) << 32);
+					r.depth = (int)asU32(q0.w);
+					const uint32_t item = asU32(q1.w);
+					TravHit h;
+					h.t = q4.x; h.u = q4.y; h.v = q4.z;
+					h.slot = (int32_t)asU32(q4.w); h.inst = (int32_t)asU32(q[5].x);
+					__builtin_assume(h.inst >= 0);
+					cont = shadeCore(S, P, ro, rd, h, r, cnt);
+					done = !cont;
+					if (cont) putPathRay(q, ro, rd, r, item);
+					else {
+						mySlot = (int)(item >> CRH_ROLL_SLOT_SHIFT);
+						float *so = myStage + (size_t)mySlot * slabFloats + (size_t)(item & CRH_ROLL_ITEM_MASK) * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+					}
+				}
+				const unsigned long long cm = __ballot(cont), dm = __ballot(done);
+				int fin[NS];
+#pragma unroll
+				for (int s = 0; s < NS; ++s) fin[s] = (int)__popcll(__ballot(mySlot == s));
+				if (cont) ids[CRH_IDS_RAYS + (uint32_t)raysQ + laneRank(cm)] = (uint8_t)id;
+				if (done) ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - laneRank(dm)] = (uint8_t)id;
+				if (lane == 0) {
+					const int nd = (int)__popcll(dm);
+					wq[RQ_HITS] = hitsQ - n; wq[RQ_RAYS] = raysQ + (int)__popcll(cm); wq[RQ_FREE] = freeQ + nd;
+					wq[RQ_CLS_LO] = (int)clsLo; wq[RQ_CLS_HI] = (int)clsHi;
+#pragma unroll
+					for (int s = 0; s < NS; ++s) if (fin[s]) wq[RQ_SLOT0 + s * SJ_WORDS + SJ_OUT] = wq[RQ_SLOT0 + s * SJ_WORDS + SJ_OUT] - fin[s];
+					if (nd) refreshJobWords();
+				}
+				__threadfence_block();
+				break;
+			}
+		}
+		if constexpr (LEVEL >= 2) {
+			if (lane == 0) {
+				const uint32_t dt = CRH_TICK() - tk;
+				cnt.w_round += 1;
+				if (pick == ST_NODE) { cnt.t_trav += dt; }
+				else if (pick == ST_TRI) { cnt.t_setup += dt; }
+				else if (pick == ST_CTRL) { cnt.w_ctrl += 1; cnt.w_setup += dt; cnt.u_ctrl += (uint32_t)nC; }
+				else if (pick == ST_SWAP) { cnt.n_swap += 1; cnt.t_swap += dt; cnt.u_swap += (uint32_t)(nF + min(nE + nF, raysQ)); }
+				else if (pick == ST_GEN || pick == ST_MISS || pick == ST_OPEN || pick == ST_FOLD) { cnt.n_gen += 1; cnt.t_gen += dt; }
+				else { cnt.w_shade += 1; cnt.t_shade += dt; }
+			}
+		}
+	}
+	if (waveStats && lane == 0) {
+		waveStats[2 * wave] = wall_clock64() - tStart;
+		waveStats[2 * wave + 1] = unitsDone;
+	}
+	const bool lead = (lane == 0);
+	uint32_t v;
+	v = waveSum(cnt.paths); if (lead && v) atomicAdd(&counters[0], (unsigned long long)v);
+	v = waveSum(cnt.rays); if (lead && v) atomicAdd(&counters[1], (unsigned long long)v);
+	if constexpr (LEVEL >= 2) {
+		v = waveSum(cnt.node_tests); if (lead && v) atomicAdd(&counters[2], (unsigned long long)v);
+		v = waveSum(cnt.tri_tests); if (lead && v) atomicAdd(&counters[3], (unsigned long long)v);
+		v = waveSum(cnt.inst_visits); if (lead && v) atomicAdd(&counters[4], (unsigned long long)v);
+		v = waveSum(cnt.inst_hits); if (lead && v) atomicAdd(&counters[5], (unsigned long long)v);
+		v = waveSum(cnt.sphere_tests); if (lead && v) atomicAdd(&counters[6], (unsigned long long)v);
+		v = waveSum(cnt.tex_fetches); if (lead && v) atomicAdd(&counters[7], (unsigned long long)v);
+		if (lead) {
+			atomicAdd(&counters[8], (unsigned long long)cnt.t_setup);
+			atomicAdd(&counters[9], (unsigned long long)cnt.t_trav);
+			atomicAdd(&counters[10], (unsigned long long)cnt.t_shade);
+		}
+		v = waveSum(cnt.w_node); if (lead && v) atomicAdd(&counters[11], (unsigned long long)v);
+		v = waveSum(cnt.w_tri); if (lead && v) atomicAdd(&counters[12], (unsigned long long)v);
+		v = waveSum(cnt.w_ctrl); if (lead && v) atomicAdd(&counters[13], (unsigned long long)v);
+		v = waveSum(cnt.w_round); if (lead && v) atomicAdd(&counters[14], (unsigned long long)v);
+		v = waveSum(cnt.w_shade); if (lead && v) atomicAdd(&counters[15], (unsigned long long)v);
+		v = waveSum(cnt.w_setup); if (lead && v) atomicAdd(&counters[16], (unsigned long long)v);
+		v = waveSum(cnt.u_node); if (lead && v) atomicAdd(&counters[17], (unsigned long long)v);
+		v = waveSum(cnt.u_shade); if (lead && v) atomicAdd(&counters[18], (unsigned long long)v);
+		v = waveSum(cnt.t_swap); if (lead && v) atomicAdd(&counters[19], (unsigned long long)v);
+		v = waveSum(cnt.t_gen); if (lead && v) atomicAdd(&counters[20], (unsigned long long)v);
+		v = waveSum(cnt.n_swap); if (lead && v) atomicAdd(&counters[21], (unsigned long long)v);
+		v = waveSum(cnt.n_gen); if (lead && v) atomicAdd(&counters[22], (unsigned long long)v);
+		v = waveSum(cnt.u_swap); if (lead && v) atomicAdd(&counters[23], (unsigned long long)v);
+		v = waveSum(cnt.u_tri); if (lead && v) atomicAdd(&counters[24], (unsigned long long)v);
+		v = waveSum(cnt.u_ctrl); if (lead && v) atomicAdd(&counters[25], (unsigned long long)v);
+	}
+}

@@ -18,8 +18,15 @@ if os.environ.get("AB_CHILD"):
     if os.environ.get("AB_SCHED"):                 # "fill_to,shade_min" (NAME.env of a build)
         f, sm = (int(v) for v in os.environ["AB_SCHED"].split(","))
         ctx.set_sched(70, 160, 120, 16, fill_to=f, shade_min=sm)
+    if os.environ.get("AB_KERNEL"):                # CRH_OPT_KERNEL of a build with an experimental kernel form (NAME.env)
+        ctx.set_option(abi.OPT_KERNEL, int(os.environ["AB_KERNEL"]))
+    if os.environ.get("AB_UNIT_ITEMS"):
+        ctx.set_option(abi.OPT_UNIT_ITEMS, int(os.environ["AB_UNIT_ITEMS"]))
     res = {}
-    for name, w, h, spp, b, reps in (CASES[:3] if quick else CASES):
+    cases = CASES[:3] if quick else CASES
+    if os.environ.get("AB_CASES"):                 # e.g. AB_CASES=cfg2_hdr,soup_1m
+        cases = [c for c in CASES if c[0] in os.environ["AB_CASES"].split(",")]
+    for name, w, h, spp, b, reps in cases:
         path = os.path.join(BUILT, name + ".blob")
         if not os.path.exists(path):
             continue
@@ -49,7 +56,7 @@ for lib in libs:
     if os.path.exists(lib[:-3] + ".env"):           # NAME.env: extra environment of that build (e.g. CRH_BLOCKS_PER_CU=3)
         env.update(l.strip().split("=", 1) for l in open(lib[:-3] + ".env") if "=" in l)
     try:
-        r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=240)
+        r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=int(os.environ.get("AB_TIMEOUT", "240")))
     except subprocess.TimeoutExpired:
         print(tag, "TIMEOUT", flush=True)
         continue

@@ -86,3 +86,17 @@ def test_node_programs_volumes_and_the_workgroup_kernel_on_emulation(emu_lib):
     """The rare-features instantiations (node programs, volumes: sampler draws inside the walk) and k_pathtrace_wg with its LDS lock."""
     run_gpu_tier_on_emulation(emu_lib, ["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"],
                               "test_gpu_node_zoo or test_gpu_volumes or workgroup_kernel", 4)
+
+
+def test_rolling_units_kernel_on_emulation(emu_lib):
+    """k_pathtrace_roll (experimental kernel form, csrc/pathtrace_roll.h, compiled into the emulation library only): a ring of open
+    jobs per wave instead of one unit at a time. Same frames, bit for bit, and the same ray counts — with the default units and with
+    units so small that every slot of the ring is in use."""
+    import json
+    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2")
+    names = ["cfg1_scene", "refraction", "volumes", "nodezoo", "glowmetal"]
+    r = subprocess.run([sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "2", *names], env=env, cwd=REPO, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [g["name"] for g in got] == names
+    assert all(g["equal"] for g in got), got

@@ -48,7 +48,7 @@ struct dim3 {
 
 namespace hipemu {
 
-enum Wait { W_RUN = 0, W_BALLOT, W_SHFL_XOR, W_FIRSTLANE, W_LOCKSTEP, W_BARRIER, W_SLEEP, W_DONE };
+enum Wait { W_RUN = 0, W_BALLOT, W_SHFL_XOR, W_FIRSTLANE, W_LOCKSTEP, W_QUAD_PERM, W_BARRIER, W_SLEEP, W_DONE };
 
 struct Lane {
 	void *sp;                       /* saved stack pointer while switched out */
@@ -99,6 +99,12 @@ static __forceinline__ T hipemu_readfirstlane(T v, const void *site) {
 	memcpy(&out, &r, sizeof(T));
 	return out;
 }
+/* DPP quad_perm (dpp_ctrl 0x00..0xFF: two bits per lane of the quad select the source lane; bound_ctrl: exited lanes read as 0) */
+static __forceinline__ int hipemu_mov_dpp(int v, int ctrl, const void *site) {
+	if (ctrl < 0 || ctrl > 0xFF) abort();          /* only quad permutes are modelled */
+	return (int)(uint32_t)hipemu::collective(hipemu::W_QUAD_PERM, (uint32_t)v, (uint64_t)ctrl, site);
+}
+#define __builtin_amdgcn_mov_dpp(v, ctrl, rowMask, bankMask, boundCtrl) hipemu_mov_dpp((v), (ctrl), HIPEMU_SITE)
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane((v), HIPEMU_SITE)
 static __forceinline__ unsigned hipemu_lane() { return (hipemu::t_lane->tIdx.x + hipemu::t_lane->tIdx.y * hipemu::t_lane->bDim.x) & 63u; }
 /* mbcnt: the number of set mask bits below this lane (+ base) */

@@ -119,6 +119,12 @@ void resolve(Lane *lanes, unsigned n, int kind) {
 		for (unsigned i = 0; i < n; ++i) lanes[i].res = v;
 	} else if (kind == W_LOCKSTEP) {
 		/* a rendezvous only */
+	} else if (kind == W_QUAD_PERM) {
+		for (unsigned i = 0; i < n; ++i) {
+			if (lanes[i].state == W_DONE) continue;
+			const unsigned j = (i & ~3u) | (unsigned)((lanes[i].arg2 >> (2u * (i & 3u))) & 3u);
+			lanes[i].res = (j < n && lanes[j].state != W_DONE) ? lanes[j].arg : 0u;
+		}
 	} else {           /* W_SHFL_XOR */
 		for (unsigned i = 0; i < n; ++i) {
 			if (lanes[i].state == W_DONE) continue;
@@ -150,7 +156,7 @@ bool turn(Worker &w, Lane *lanes, unsigned n) {
 		const int s = lanes[i].state;
 		if (s == W_DONE) continue;
 		++live;
-		if (s == W_BALLOT || s == W_SHFL_XOR || s == W_FIRSTLANE || s == W_LOCKSTEP) {
+		if (s == W_BALLOT || s == W_SHFL_XOR || s == W_FIRSTLANE || s == W_LOCKSTEP || s == W_QUAD_PERM) {
 			if (kind < 0) kind = s;
 			if (s == kind) ++atKind;
 		}

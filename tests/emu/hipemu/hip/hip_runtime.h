@@ -48,7 +48,7 @@ struct dim3 {
 
 namespace hipemu {
 
-enum Wait { W_RUN = 0, W_BALLOT, W_SHFL_XOR, W_FIRSTLANE, W_LOCKSTEP, W_QUAD_PERM, W_BARRIER, W_SLEEP, W_DONE };
+enum Wait { W_RUN = 0, W_BALLOT, W_SHFL_XOR, W_FIRSTLANE, W_LOCKSTEP, W_QUAD_PERM, W_READ_LANE, W_BARRIER, W_SLEEP, W_DONE };
 
 struct Lane {
 	void *sp;                       /* saved stack pointer while switched out */
@@ -89,7 +89,42 @@ static __forceinline__ T hipemu_shfl_xor(T v, int laneMask, const void *site) {
 	memcpy(&out, &r, sizeof(T));
 	return out;
 }
-#define __shfl_xor(v, laneMask) hipemu_shfl_xor((v), (laneMask), HIPEMU_SITE)
+/* the general data movement between lanes: every lane offers a value and names the lane whose value it wants (its own lane: keeps its own;
+ * an exited lane: gets its own). __shfl / __shfl_up / __shfl_xor with a width and the DPP row modes are this with the source computed here. */
+template <class T>
+static __forceinline__ T hipemu_read_lane(T v, unsigned srcLane, const void *site) {
+	static_assert(sizeof(T) <= 8, "lane exchange of at most 64 bits");
+	uint64_t a = 0;
+	memcpy(&a, &v, sizeof(T));
+	const uint64_t r = hipemu::collective(hipemu::W_READ_LANE, a, (uint64_t)srcLane, site);
+	T out;
+	memcpy(&out, &r, sizeof(T));
+	return out;
+}
+static __forceinline__ unsigned hipemu_lane_id();
+template <class T> static __forceinline__ T hipemu_shfl(T v, int src, int width, const void *site) {
+	const unsigned l = hipemu_lane_id(), w = (unsigned)width;
+	return hipemu_read_lane(v, (l & ~(w - 1u)) | ((unsigned)src & (w - 1u)), site);
+}
+template <class T> static __forceinline__ T hipemu_shfl_up(T v, unsigned delta, int width, const void *site) {
+	const unsigned l = hipemu_lane_id(), w = (unsigned)width, in = l & (w - 1u);
+	return hipemu_read_lane(v, in >= delta ? l - delta : l, site);
+}
+template <class T> static __forceinline__ T hipemu_shfl_xor_w(T v, int mask, int width, const void *site) {
+	const unsigned l = hipemu_lane_id(), w = (unsigned)width, src = l ^ (unsigned)mask;
+	return hipemu_read_lane(v, (src & ~(w - 1u)) == (l & ~(w - 1u)) ? src : l, site);
+}
+/* (two- and three-argument forms) */
+#define HIPEMU_PICK(_1, _2, _3, NAME, ...) NAME
+#define hipemu_shfl2(v, s) hipemu_shfl((v), (s), 64, HIPEMU_SITE)
+#define hipemu_shfl3(v, s, w) hipemu_shfl((v), (s), (w), HIPEMU_SITE)
+#define __shfl(...) HIPEMU_PICK(__VA_ARGS__, hipemu_shfl3, hipemu_shfl2, )(__VA_ARGS__)
+#define hipemu_shfl_up2(v, d) hipemu_shfl_up((v), (d), 64, HIPEMU_SITE)
+#define hipemu_shfl_up3(v, d, w) hipemu_shfl_up((v), (d), (w), HIPEMU_SITE)
+#define __shfl_up(...) HIPEMU_PICK(__VA_ARGS__, hipemu_shfl_up3, hipemu_shfl_up2, )(__VA_ARGS__)
+#define hipemu_shfl_xor2(v, m) hipemu_shfl_xor((v), (m), HIPEMU_SITE)
+#define hipemu_shfl_xor3(v, m, w) hipemu_shfl_xor_w((v), (m), (w), HIPEMU_SITE)
+#define __shfl_xor(...) HIPEMU_PICK(__VA_ARGS__, hipemu_shfl_xor3, hipemu_shfl_xor2, )(__VA_ARGS__)
 template <class T>
 static __forceinline__ T hipemu_readfirstlane(T v, const void *site) {
 	uint64_t a = 0;
@@ -106,6 +141,23 @@ static __forceinline__ int hipemu_mov_dpp(int v, int ctrl, const void *site) {
 }
 #define __builtin_amdgcn_mov_dpp(v, ctrl, rowMask, bankMask, boundCtrl) hipemu_mov_dpp((v), (ctrl), HIPEMU_SITE)
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane((v), HIPEMU_SITE)
+static __forceinline__ unsigned hipemu_lane_id() { return (hipemu::t_lane->tIdx.x + hipemu::t_lane->tIdx.y * hipemu::t_lane->bDim.x) & 63u; }
+/* DPP row modes (update_dpp): row_shr:N (0x110 + N) and row_bcast15 (0x142), with a row mask; lanes without a valid source, or in a row
+ * the mask leaves out, keep `old` (bound_ctrl = false) */
+static __forceinline__ int hipemu_update_dpp(int old, int src, int ctrl, int rowMask, int bankMask, bool boundCtrl, const void *site) {
+	if (bankMask != 0xF || boundCtrl) abort();
+	const unsigned l = hipemu_lane_id(), row = l >> 4, inRow = l & 15u;
+	unsigned from = l;
+	bool valid = false;
+	if (ctrl > 0x110 && ctrl <= 0x11F) { const unsigned n = (unsigned)ctrl - 0x110u; valid = inRow >= n; from = l - n; }
+	else if (ctrl == 0x142) { valid = row > 0u; from = (row - 1u) * 16u + 15u; }             /* row_bcast15: lane 15 of the row before */
+	else abort();
+	const int got = hipemu_read_lane(src, valid ? from : l, site);
+	return (valid && ((rowMask >> row) & 1)) ? got : old;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rowMask, bankMask, boundCtrl) hipemu_update_dpp((old), (src), (ctrl), (rowMask), (bankMask), (boundCtrl), HIPEMU_SITE)
+static __forceinline__ float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static __forceinline__ int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 static __forceinline__ unsigned hipemu_lane() { return (hipemu::t_lane->tIdx.x + hipemu::t_lane->tIdx.y * hipemu::t_lane->bDim.x) & 63u; }
 /* mbcnt: the number of set mask bits below this lane (+ base) */
 static __forceinline__ unsigned hipemu_mbcnt_lo(unsigned mask, unsigned base) {
@@ -140,6 +192,14 @@ template <class T> static __forceinline__ T max(T a, T b) { return a < b ? b : a
 static __forceinline__ unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static __forceinline__ T hipemu_atomic_min(T *p, T v) { T cur = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return cur; }
+template <class T> static __forceinline__ T hipemu_atomic_max(T *p, T v) { T cur = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return cur; }
+static __forceinline__ unsigned long long atomicMin(unsigned long long *p, unsigned long long v) { return hipemu_atomic_min(p, v); }
+static __forceinline__ unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { return hipemu_atomic_max(p, v); }
+static __forceinline__ unsigned atomicMin(unsigned *p, unsigned v) { return hipemu_atomic_min(p, v); }
+static __forceinline__ unsigned atomicMax(unsigned *p, unsigned v) { return hipemu_atomic_max(p, v); }
+static __forceinline__ int atomicMin(int *p, int v) { return hipemu_atomic_min(p, v); }
+static __forceinline__ int atomicMax(int *p, int v) { return hipemu_atomic_max(p, v); }
 static __forceinline__ unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }

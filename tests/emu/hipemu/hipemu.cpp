@@ -119,6 +119,12 @@ void resolve(Lane *lanes, unsigned n, int kind) {
 		for (unsigned i = 0; i < n; ++i) lanes[i].res = v;
 	} else if (kind == W_LOCKSTEP) {
 		/* a rendezvous only */
+	} else if (kind == W_READ_LANE) {
+		for (unsigned i = 0; i < n; ++i) {
+			if (lanes[i].state == W_DONE) continue;
+			const unsigned j = (unsigned)lanes[i].arg2;
+			lanes[i].res = (j < n && lanes[j].state != W_DONE) ? lanes[j].arg : lanes[i].arg;
+		}
 	} else if (kind == W_QUAD_PERM) {
 		for (unsigned i = 0; i < n; ++i) {
 			if (lanes[i].state == W_DONE) continue;
@@ -156,7 +162,7 @@ bool turn(Worker &w, Lane *lanes, unsigned n) {
 		const int s = lanes[i].state;
 		if (s == W_DONE) continue;
 		++live;
-		if (s == W_BALLOT || s == W_SHFL_XOR || s == W_FIRSTLANE || s == W_LOCKSTEP || s == W_QUAD_PERM) {
+		if (s == W_BALLOT || s == W_SHFL_XOR || s == W_FIRSTLANE || s == W_LOCKSTEP || s == W_QUAD_PERM || s == W_READ_LANE) {
 			if (kind < 0) kind = s;
 			if (s == kind) ++atKind;
 		}

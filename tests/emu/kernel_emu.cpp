@@ -3,15 +3,11 @@
  * file, unmodified) compiled for the host against the HIP-on-CPU shim in hipemu/. TEST INFRASTRUCTURE ONLY: the CPU-only test tier
  * runs the wave machine of k_pathtrace — scheduler, id stacks, path table, work queue, staging, fold — and the host side of
  * crh_render_tiles through the very C-ABI the GPU tests use, and compares the frames with the oracle bit for bit
- * (tests/test_kernel_emu.py). Never loaded by the product, bench.py or the GPU tests.
+ * (tests/test_kernel_emu.py). The GPU BVH builder is bvh_emu.cpp. Never loaded by the product, bench.py or the GPU tests.
  */
 #include "../../c-ray_amd/csrc/cray_hip.hip"
 
 extern "C" {
-/* the GPU BVH builder (csrc/bvh_build.hip: DPP scans, cross-lane permutes) is not part of this emulation */
-int crh_bvh_build_triangles(crh_ctx *, const crh_poly *, uint32_t, const float *, uint64_t, crh_bvh_node *, int32_t *, uint32_t *, crh_bvh_build_stats *) {
-	return fail(CRH_ERR_UNSUPPORTED, "crh_bvh_build_triangles: not part of the CPU emulation of the path-tracing kernels");
-}
 /* emulation bookkeeping: {kernel launches, blocks, wave collectives resolved, lane switches} */
 void crh_emu_stats(uint64_t out[4]) {
 	const hipemu::Stats s = hipemu::stats();

@@ -1,7 +1,8 @@
 """CPU tier: the kernels of libcray_hip.so themselves — not a restatement of them — run on the CPU and are held to the GPU tier's bar.
 
 tests/emu/libcray_hip_emu.so is c-ray_amd/csrc/cray_hip.hip (k_pathtrace, k_pathtrace_wg, k_trace_rays, k_fold_black, k_to_srgb8 AND the
-C-ABI host code around them: work planning, queues, launches, counters) compiled unmodified against a HIP-on-CPU shim
+C-ABI host code around them: work planning, queues, launches, counters) and csrc/bvh_build.hip (the GPU BVH builder) compiled unmodified
+against a HIP-on-CPU shim
 (tests/emu/hipemu: every lane a fiber, 64-lane waves that meet at ballots / shuffles / readfirstlane, blocks with __syncthreads, LDS as
 block-local statics, atomics as atomics). The tests below start the GPU tier's own test functions (`-m gpu`) in a child pytest whose
 api.py loads that library (CRH_LIB) — same tests, same source, same C-ABI, no GPU: frames must equal the reference's float buffers bit
@@ -10,7 +11,7 @@ for bit, ray records the oracle's, every dispatch decomposition / scheduler opti
 What this tier adds to tests/test_emu_parity.py (which pins the LANE code): the wave machine — scheduler, id stacks, path table, shade
 class batches, work queue, tapered units, staging and the in-order fold, the workgroup kernel's lock protocol — and the host side of
 crh_render_tiles. What it cannot see: anything that depends on the hardware's timing, register allocation or memory model (the GPU tier
-keeps that), and the GPU BVH builder (DPP scans; not part of the emulation).
+keeps that).
 
 TEST INFRASTRUCTURE: the emulation library is never loaded by the product, by bench.py or by the GPU tier.
 """
@@ -86,6 +87,14 @@ def test_node_programs_volumes_and_the_workgroup_kernel_on_emulation(emu_lib):
     """The rare-features instantiations (node programs, volumes: sampler draws inside the walk) and k_pathtrace_wg with its LDS lock."""
     run_gpu_tier_on_emulation(emu_lib, ["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"],
                               "test_gpu_node_zoo or test_gpu_volumes or workgroup_kernel", 4)
+
+
+def test_gpu_bvh_builder_on_emulation(emu_lib):
+    """csrc/bvh_build.hip on the shim (level-synchronous binning with LDS / global 64-bit atomics, the SAH sweeps as DPP row scans, one
+    wave per small subtree): the reference's tree — node numbering, bounds bit patterns, primitive order — for the six scene fixtures and
+    the degenerate inputs. (The 524 288-triangle stand-in and the 1 M soup pass too, in three minutes: run the GPU tier's file with
+    CRH_LIB set to see it.)"""
+    run_gpu_tier_on_emulation(emu_lib, ["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 7)
 
 
 def test_rolling_units_kernel_on_emulation(emu_lib):

@@ -82,6 +82,7 @@ void prepare(Worker &w, unsigned i) {
 	if (i >= w.stacks.size()) {
 		void *m = mmap(nullptr, kStackBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
 		if (m == MAP_FAILED) die("cannot map a lane stack");
+		(void)mprotect(m, 4096, PROT_NONE);          /* guard page: a lane that outgrows its stack faults instead of writing into its neighbour's */
 		w.stacks.push_back((char *)m);
 	}
 	uintptr_t top = ((uintptr_t)w.stacks[i] + kStackBytes) & ~(uintptr_t)15;

@@ -109,3 +109,23 @@ def test_rolling_units_kernel_on_emulation(emu_lib):
     got = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert [g["name"] for g in got] == names
     assert all(g["equal"] for g in got), got
+
+
+# The scheduler's step counters on a 2-CU device (HIPEMU_CUS=2 fixes the work plan): node / triangle / control / retire+refill / generate /
+# shade steps, lanes served by node and shade steps, scheduling rounds. A unit's schedule depends only on the unit, so these are exact and
+# the same on every machine and thread count — and on the GPU (cfg2 at 64 spp, all counters equal). They change only
+# when the scheduler, the work plan or a walk's step sequence changes: whoever does that on purpose updates them here (and looks at the
+# lanes per step they imply); anything else that moves them is a performance regression caught without a GPU.
+PINNED_STEPS = {
+    "fence": {"w_node": 75197, "u_node": 2334213, "w_tri": 8527, "w_ctrl": 5469, "n_swap": 28818, "n_gen": 1501, "w_shade": 6221, "u_shade": 297282, "w_round": 67183},
+    "cfg1_scene": {"w_node": 306342, "u_node": 11322917, "w_tri": 13082, "w_ctrl": 13884, "n_swap": 45068, "n_gen": 4941, "w_shade": 16125, "u_shade": 932071, "w_round": 134341},
+}
+
+
+def test_scheduler_step_counts_are_pinned(emu_lib):
+    import json
+    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2")
+    r = subprocess.run([sys.executable, os.path.join(EMU_DIR, "sched_counts.py"), *PINNED_STEPS], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = {j["name"]: {k: v for k, v in j.items() if k != "name"} for j in (json.loads(l) for l in r.stdout.splitlines() if l.startswith("{"))}
+    assert got == PINNED_STEPS, got

@@ -95,14 +95,18 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	auto refreshJobWords = [&]() {
 		const int head = wq[RQ_HEAD], open = wq[RQ_OPEN];
 		int left = 0, flags = 0;
+		bool moreChunks = false;             /* the youngest job's unit has passes left: the next job is its following chunk, whatever the queue holds */
 		if (open > 0) {
 			lds_int *gj = wq + RQ_SLOT0 + wq[RQ_GEN] * SJ_WORDS, *oj = wq + RQ_SLOT0 + head * SJ_WORDS;
 			const int gb = gj[SJ_BWBH], ob = oj[SJ_BWBH];
 			left = (gb & 0xFFFF) * (gb >> 16) * gj[SJ_PASSN] - gj[SJ_NEXT];
 			if (left < 0) left = 0;
-			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0) flags |= 1;
+			moreChunks = gj[SJ_PASS0] + gj[SJ_PASSN] < passEnd;
+			/* a job that is the only open one AND not its unit's last chunk stays open until the following chunk has been opened from it
+			 * (ST_OPEN reads the unit from the youngest job): folded earlier, the unit's remaining passes would never be generated */
+			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0 && (open > 1 || !moreChunks)) flags |= 1;
 		}
-		if (!wq[RQ_DRY] && open < NS) flags |= 2;
+		if (open < NS && (!wq[RQ_DRY] || moreChunks)) flags |= 2;
 		wq[RQ_GENLEFT] = left; wq[RQ_FLAGS] = flags;
 	};
 

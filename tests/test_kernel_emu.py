@@ -129,3 +129,11 @@ def test_scheduler_step_counts_are_pinned(emu_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = {j["name"]: {k: v for k, v in j.items() if k != "name"} for j in (json.loads(l) for l in r.stdout.splitlines() if l.startswith("{"))}
     assert got == PINNED_STEPS, got
+
+
+def test_schedule_fuzz_on_emulation(emu_lib):
+    """tools/emu_fuzz.py, twelve seeded cases: random work plans, scheduler parameters, kernel forms (wave / workgroup / rolling units),
+    device sizes, tile covers and pass splits — every one must give the reference's frame bit for bit and its ray count."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:12"], cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.stdout.count('"ok": true') == 12, r.stdout[-3000:]

@@ -63,8 +63,11 @@ def algorithmic_bytes(cnt, path_state=True):
 
 
 def kernel_source_md5():
-    """Fingerprint of the DEVICE code in the built library (the .hip_fatbin section of libcray_hip.so): PMC figures in profiles/ are
-    quoted only while they describe the kernels that are running — host-side edits do not invalidate them, any kernel edit does."""
+    """Fingerprint of the DEVICE code of the path-tracing kernels in the built library: the gfx950 code object of csrc/cray_hip.hip inside
+    the .hip_fatbin section of libcray_hip.so (the section bundles one code object per translation unit; the GPU BVH builder's is the other
+    one). PMC figures in profiles/ are quoted only while they describe the kernels that are running — host-side edits and edits to the BVH
+    builder do not invalidate them, any edit that changes the path-tracing code object does. (Until r02e the whole section was hashed:
+    e0fb1a6f... is the same device code as d699817a... under this definition.)"""
     import hashlib
     import struct
     path = os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so")
@@ -78,12 +81,36 @@ def kernel_source_md5():
         name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
         return name, off, size
     _, stroff, strsize = sec(shstrndx)
+    fat = None
     for i in range(shnum):
         name, off, size = sec(i)
         end = data.index(b"\0", stroff + name)
         if data[stroff + name:end] == b".hip_fatbin":
-            return hashlib.md5(data[off:off + size]).hexdigest()
-    return hashlib.md5(data).hexdigest()
+            fat = data[off:off + size]
+            break
+    if fat is None:
+        return hashlib.md5(data).hexdigest()
+    magic, objects, pos = b"__CLANG_OFFLOAD_BUNDLE__", [], 0
+    while True:                                    # one offload bundle per translation unit: {magic, n, n x (offset, size, triple)}
+        p = fat.find(magic, pos)
+        if p < 0:
+            break
+        n, = struct.unpack_from("<Q", fat, p + 24)
+        q = p + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from("<QQQ", fat, q)
+            triple = fat[q + 24:q + 24 + ts]
+            q += 24 + ts
+            obj = fat[p + o:p + o + sz]
+            if b"gfx" in triple and b"k_pathtrace" in obj:
+                objects.append(obj)
+        pos = p + len(magic)
+    if not objects:
+        return hashlib.md5(fat).hexdigest()
+    h = hashlib.md5()
+    for obj in objects:
+        h.update(obj)
+    return h.hexdigest()
 
 
 def measured_profile(workload_key):

@@ -453,7 +453,7 @@ struct SmallRoot { float bounds[6]; uint32_t begin, end, depth, forceLeaf; uint3
  * pairs are appended in allocation order, inner nodes point at LOCAL indices. Roots that are leaves by rule (depth limit,
  * fewer than two primitives, or a large node whose split left nothing on the left: forceLeaf) are emitted directly. */
 __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t nRoots, int32_t *prims, const float *boxes, const float *centers,
-											  crh_bvh_node *local, uint32_t *localCount, unsigned long long *prof) {
+											  crh_bvh_node *local, uint32_t *localCount, unsigned long long *prof, uint32_t *overflow) {
 	/* the index range is kept as SLOT numbers (= position at load time): boxes[] / centers[] are in position order (k_swap moves them
 	 * with the indices), so slot s of this subtree has its data at base + s — 18 KB of contiguous, cache-resident records per subtree.
 	 * (Keeping those records in LDS instead was measured: 30 KB per wave leaves 5 waves per CU, and the build got slower.) */
@@ -496,6 +496,7 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 	}
 	__syncthreads();
 	uint32_t sp = 1, used = 1;
+	const uint32_t cap = 2u * total - 1u;                     /* this subtree's share of the node array (the reference's bound, bvh.c:271) */
 	unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     /* CRH_BVH_TRACE: wall-clock ticks per part (lane 0 of every wave) */
 	unsigned long long pc = prof ? wall_clock64() : 0ull;
 #define CRH_PROF(i) do { if (prof) { const unsigned long long now_ = wall_clock64(); pt[i] += now_ - pc; pc = now_; } } while (0)
@@ -530,6 +531,11 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 			__syncthreads();
 			CRH_PROF(3);
 			leaf = s_dec.leaf != 0;
+			/* The reference splits a node whose primitives ALL land on the left (bvh.c:220 asks only beginRight > begin): clusters of more
+			 * than 16 coincident primitives become chains of (everything | nothing) splits, and with enough of them the tree has more than
+			 * 2 n - 1 nodes — the reference overflows its heap array there. Here the subtree stops (memory stays intact) and the build
+			 * reports that no reference tree exists. */
+			if (!leaf && used + 2u > cap) { leaf = true; if (lane == 0) atomicOr(overflow, 1u); }
 		}
 		if (leaf) {
 			if (lane == 0) { out[j.node].first = base + first; out[j.node].count_leaf = (n & 0x3FFFFFFFu) | (1u << 30); }
@@ -774,11 +780,18 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	BVH_TRY(hipMemcpyAsync(dRoots.p, smallRoots.data(), nRoots * sizeof(SmallRoot), hipMemcpyHostToDevice, st));
 	DevBuf<unsigned long long> dProf;
 	if (trace) { BVH_TRY(dProf.alloc(8)); BVH_TRY(hipMemsetAsync(dProf.p, 0, 8 * sizeof(unsigned long long), st)); }
-	hipLaunchKernelGGL(k_small, dim3(nRoots), dim3(64), 0, st, dRoots.p, nRoots, dPrims.p, dBoxes.p, dCenters.p, dLocal.p, dLocalCount.p, trace ? dProf.p : nullptr);
+	DevBuf<uint32_t> dOverflow;
+	BVH_TRY(dOverflow.alloc(1)); BVH_TRY(hipMemsetAsync(dOverflow.p, 0, sizeof(uint32_t), st));
+	hipLaunchKernelGGL(k_small, dim3(nRoots), dim3(64), 0, st, dRoots.p, nRoots, dPrims.p, dBoxes.p, dCenters.p, dLocal.p, dLocalCount.p, trace ? dProf.p : nullptr, dOverflow.p);
 	BVH_TRY(hipGetLastError());
 	std::vector<uint32_t> localCount(nRoots);
+	uint32_t overflowed = 0;
 	BVH_TRY(hipMemcpyAsync(localCount.data(), dLocalCount.p, nRoots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipMemcpyAsync(&overflowed, dOverflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	BVH_TRY(hipStreamSynchronize(st));
+	static const char *const kNoReferenceTree = "crh_bvh_build_triangles: degenerate mesh — the reference's builder needs more than the 2 n - 1 nodes it allocates "
+		"(bvh.c:271; clusters of more than 16 coincident primitives are split into (all | none) down to the depth limit): no reference tree exists";
+	if (overflowed) return crh_internal_fail(CRH_ERR_UNSUPPORTED, kNoReferenceTree);
 	if (trace) {
 		const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh small phase: %u subtrees %.3f ms\n", nRoots, std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn;
 		unsigned long long hp[8];
@@ -810,6 +823,7 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 		}
 	}
 	const uint32_t nodeCount = next;
+	if ((size_t)nodeCount > 2 * (size_t)N - 1) return crh_internal_fail(CRH_ERR_UNSUPPORTED, kNoReferenceTree);      /* the same, with the chains in the upper tree */
 	BVH_TRY(hipMemcpyAsync(dRootId.p, rootId.data(), nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 	BVH_TRY(hipMemcpyAsync(dFirstId.p, firstId.data(), nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_emit, dim3(std::min<uint32_t>(nRoots, 65535u)), dim3(256), 0, st, dRoots.p, nRoots, dLocalCount.p, dRootId.p, dFirstId.p, dLocal.p, dNodes.p);

@@ -292,7 +292,10 @@ int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out24);   /* debug: 24 values 
  * tree: nodes_out[0 .. *node_count_out) equal its struct bvhNode array (bounds bit for bit, child / first-prim indices,
  * leaf flags and leaf sizes; inner nodes carry primCount 0 where the reference leaves heap garbage) and
  * prim_indices_out[0 .. poly_count) equals bvh->primIndices. Host pointers in and out; polys[i].v[] index `vertices`
- * (3 floats each). nodes_out needs room for 2 * poly_count - 1 nodes. poly_count == 0 gives the empty BVH (node count 0). */
+ * (3 floats each). nodes_out needs room for 2 * poly_count - 1 nodes. poly_count == 0 gives the empty BVH (node count 0).
+ * CRH_ERR_UNSUPPORTED: the mesh is one on which the reference itself writes past the 2 n - 1 nodes it allocates (bvh.c:271; clusters of
+ * more than 16 coincident primitives are split into (all | none) down to the depth limit, bvh.c:220) — no reference tree exists; the
+ * context stays usable. */
 typedef struct crh_bvh_build_stats {
 	double   upload_ms, build_ms, download_ms;   /* host->device copies; every kernel + the host's level bookkeeping; results back */
 	uint32_t levels, upper_nodes, subtrees, pad;  /* level-synchronous passes; nodes kept by the host; subtrees built by one wave each */

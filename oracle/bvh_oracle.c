@@ -68,7 +68,8 @@ void orc_bvh_triangle_bounds(const crh_poly *polys, const float *vertices, uint3
 
 typedef struct { uint32_t node, first, last, depth; } job;
 
-/* boxes6: {min xyz, max xyz} per primitive; nodes: capacity 2*count-1; prims: capacity count. Returns 0 / -1. */
+/* boxes6: {min xyz, max xyz} per primitive; nodes: capacity 2*count-1; prims: capacity count. Returns 0, -1 (no memory) or -2 (the reference's
+ * own node array would overflow on this input: no reference result exists). */
 int orc_bvh_build(const float *boxes6, const float *centers3, uint32_t count, crh_bvh_node *nodes, int32_t *prims, uint32_t *node_count) {
 	if (count < 1) { *node_count = 0; return 0; }                                           /* bvh.c:250-256 */
 	box3 root;
@@ -157,6 +158,10 @@ int orc_bvh_build(const float *boxes6, const float *centers3, uint32_t count, cr
 			--r; ++l;
 		}
 		if (l <= j.first) { LEAF(); continue; }                                             /* bvh.c:239-241 */
+		/* The reference allocates 2 * count - 1 nodes (bvh.c:271: "binary tree property") and then splits nodes whose primitives all land on
+		 * the left (bvh.c:220 only asks beginRight > begin): more than 16 coincident primitives give a chain of (everything | nothing)
+		 * splits down to the depth limit, and enough such clusters overflow its heap array. There is no reference result then. */
+		if ((size_t)used + 2 > 2 * (size_t)count - 1) { free(bins); free(stack); return -2; }
 		const uint32_t kids = used;                                                         /* bvh.c:221-223 */
 		used += 2;
 		box3 lb, rb;                                                                        /* bvh.c:226-233 */

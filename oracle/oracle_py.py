@@ -144,6 +144,8 @@ def bvh_build_triangles(polys_ptr, vertices_ptr, count):
     prims = np.zeros(max(count, 1), np.int32)
     n = C.c_uint32(0)
     rc = lib().orc_bvh_build(boxes.ctypes.data, centers.ctypes.data, count, nodes.ctypes.data, prims.ctypes.data, C.byref(n))
+    if rc == -2:
+        raise OverflowError("orc_bvh_build: the reference's builder overflows its 2 * count - 1 node array on this input (bvh.c:271)")
     if rc != 0:
         raise MemoryError("orc_bvh_build")
     return nodes[:n.value], prims[:count]

@@ -114,3 +114,32 @@ def test_gpu_builder_degenerate_inputs(pkg, oracle):
     nodes, prims, st = ctx.bvh_build_triangles(polys.ctypes.data, count, verts.ctypes.data, len(verts))
     assert_same_bvh(nodes, prims, ref_nodes, ref_prims, ("outlier line", st))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_builder_refuses_a_mesh_the_reference_overflows_on(pkg, oracle):
+    """bvh.c:271 allocates 2 n - 1 nodes, and bvh.c:220 splits a node whose primitives all land on the left: clusters of more than 16
+    coincident primitives become chains of (all | none) splits down to the depth limit, and enough of them need more nodes than that — the
+    reference writes past its heap array (found by tools/emu_fuzz_bvh.py). No reference tree exists; the builder must say so
+    (CRH_ERR_UNSUPPORTED) with its memory intact, and build the next mesh correctly."""
+    rng = np.random.default_rng(18)
+    count = 9000
+    c = np.round(rng.uniform(-1, 1, (count, 3)) * 4) / 4.0                 # 729 distinct centres, zero-size triangles
+    verts = np.repeat(c, 3, axis=0).astype(np.float32)
+    polys = np.zeros((count, 10), np.int32)
+    polys[:, 0] = np.arange(count) * 3; polys[:, 1] = polys[:, 0] + 1; polys[:, 2] = polys[:, 0] + 2; polys[:, 3:9] = -1
+    with pytest.raises(OverflowError):
+        oracle.bvh_build_triangles(polys.ctypes.data, verts.ctypes.data, count)
+    ctx = pkg.api.Context(0)
+    try:
+        with pytest.raises(pkg.api.CrhError) as e:
+            ctx.bvh_build_triangles(polys.ctypes.data, count, verts.ctypes.data, len(verts))
+        assert e.value.code == pkg.abi.ERR_UNSUPPORTED and "2 n - 1" in str(e.value)
+        good = count // 3                                                    # the same context builds a sane mesh afterwards
+        verts2 = rng.uniform(-1, 1, (good * 3, 3)).astype(np.float32)
+        polys2 = np.ascontiguousarray(polys[:good])
+        ref_nodes, ref_prims = oracle.bvh_build_triangles(polys2.ctypes.data, verts2.ctypes.data, good)
+        nodes, prims, st = ctx.bvh_build_triangles(polys2.ctypes.data, good, verts2.ctypes.data, len(verts2))
+        assert_same_bvh(nodes, prims, ref_nodes, ref_prims, ("after a refused mesh", st))
+    finally:
+        ctx.close()

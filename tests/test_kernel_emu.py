@@ -94,7 +94,16 @@ def test_gpu_bvh_builder_on_emulation(emu_lib):
     wave per small subtree): the reference's tree — node numbering, bounds bit patterns, primitive order — for the six scene fixtures and
     the degenerate inputs. (The 524 288-triangle stand-in and the 1 M soup pass too, in three minutes: run the GPU tier's file with
     CRH_LIB set to see it.)"""
-    run_gpu_tier_on_emulation(emu_lib, ["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 7)
+    run_gpu_tier_on_emulation(emu_lib, ["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8)
+
+
+def test_bvh_builder_fuzz_on_emulation(emu_lib):
+    """tools/emu_fuzz_bvh.py, 24 seeded meshes that are awkward for a parallel builder (grid-aligned coordinates: every tie rule decides;
+    duplicates; clusters with outliers; flat and needle extents; sizes around the phase boundaries): the reference's tree, or — where the
+    reference's own node array overflows — a refusal."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:24"], cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.stdout.count('"ok": true') == 24 and '"refused": true' in r.stdout, r.stdout[-3000:]
 
 
 def test_rolling_units_kernel_on_emulation(emu_lib):

@@ -33,16 +33,62 @@ def emu_lib():
     return EMU_LIB
 
 
-def run_gpu_tier_on_emulation(emu_lib, files, select, expect_passed):
-    """Run the selected `-m gpu` tests in a child pytest against the emulation library; every one of them must pass."""
-    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2")
-    cmd = [sys.executable, "-m", "pytest", *[os.path.join(REPO, "tests", f) for f in files], "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select]
-    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=1700)
-    tail = (r.stdout[-2500:] + "\n" + r.stderr[-1500:])
-    assert r.returncode == 0, tail
-    m = re.search(r"(\d+) passed", r.stdout)
+GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of tests that must run and pass)
+    "trace_rays": (["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6),
+    "frames": (["test_gpu_parity.py"], "test_image_parity_vs_reference", 6),
+    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or interactive_mode or edge_cases or zero_component or srgb8 or error_paths", 7),
+    "rare_and_wg": (["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"], "test_gpu_node_zoo or test_gpu_volumes", 3),          # (test_gpu_volumes renders with both kernel forms;
+    # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
+    "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
+}
+ROLL_FIXTURES = ["cfg1_scene", "refraction", "volumes", "nodezoo", "glowmetal"]
+
+
+@pytest.fixture(scope="module")
+def children(emu_lib):
+    """Every child process of this module, started at once (they are independent; each runs the emulation on two OS threads): the module
+    takes as long as its slowest child instead of the sum."""
+    import tempfile
+    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2", HIPEMU_THREADS="3")
+    procs = {}
+
+    def start(name, cmd):
+        out = tempfile.TemporaryFile(mode="w+")
+        procs[name] = (subprocess.Popen(cmd, env=env, cwd=REPO, stdout=out, stderr=subprocess.STDOUT, text=True), out)
+
+    for name, (files, select, _) in GPU_TIER_JOBS.items():
+        start(name, [sys.executable, "-m", "pytest", *[os.path.join(REPO, "tests", f) for f in files], "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select])
+    start("roll", [sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "2", *ROLL_FIXTURES])
+    start("steps", [sys.executable, os.path.join(EMU_DIR, "sched_counts.py"), *PINNED_STEPS])
+    start("fuzz", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:9"])
+    start("fuzz_bvh", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:19"])
+
+    def finish(name, timeout=1700):
+        proc, out = procs[name]
+        try:
+            proc.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            raise
+        out.seek(0)
+        return proc.returncode, out.read()
+
+    yield finish
+    for proc, out in procs.values():
+        if proc.poll() is None:
+            proc.kill()
+        out.close()
+
+
+def run_gpu_tier_on_emulation(children, job):
+    """The selected `-m gpu` tests, run by a child pytest against the emulation library: every one of them must have run and passed."""
+    rc, text = children(job)
+    expect_passed = GPU_TIER_JOBS[job][2]
+    tail = text[-4000:]
+    assert rc == 0, tail
+    m = re.search(r"(\d+) passed", text)
     assert m and int(m.group(1)) == expect_passed, f"expected {expect_passed} tests to run on the emulation:\n{tail}"
-    assert "skipped" not in r.stdout.splitlines()[-1], tail
+    assert "skipped" not in text.strip().splitlines()[-1], tail
 
 
 def test_the_shim_itself(tmp_path):
@@ -67,56 +113,53 @@ def test_emulation_library_is_the_product_source(emu_lib):
     assert declared - exported == set(), sorted(declared - exported)
 
 
-def test_k_trace_rays_on_emulation(emu_lib):
-    run_gpu_tier_on_emulation(emu_lib, ["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6)
+def test_k_trace_rays_on_emulation(children):
+    run_gpu_tier_on_emulation(children, "trace_rays")
 
 
-def test_k_pathtrace_frames_on_emulation(emu_lib):
+def test_k_pathtrace_frames_on_emulation(children):
     """The wave machine renders the six scene fixtures: the reference's float buffer, bit for bit."""
-    run_gpu_tier_on_emulation(emu_lib, ["test_gpu_parity.py"], "test_image_parity_vs_reference", 6)
+    run_gpu_tier_on_emulation(children, "frames")
 
 
-def test_schedules_decompositions_and_edge_cases_on_emulation(emu_lib):
+def test_schedules_decompositions_and_edge_cases_on_emulation(children):
     """Shade-class batches, tiles / pass chunks / unit sizes / taper levels, the Halton sampler, empty / ragged / single-pixel dispatches,
     bounces <= 0 (k_fold_black), degenerate rays, k_to_srgb8, the error paths of the C-ABI."""
-    run_gpu_tier_on_emulation(emu_lib, ["test_gpu_parity.py"],
-                              "shade_class_batches or dispatch_decompositions or interactive_mode or edge_cases or zero_component or srgb8 or error_paths", 7)
+    run_gpu_tier_on_emulation(children, "schedules")
 
 
-def test_node_programs_volumes_and_the_workgroup_kernel_on_emulation(emu_lib):
-    """The rare-features instantiations (node programs, volumes: sampler draws inside the walk) and k_pathtrace_wg with its LDS lock."""
-    run_gpu_tier_on_emulation(emu_lib, ["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"],
-                              "test_gpu_node_zoo or test_gpu_volumes or workgroup_kernel", 4)
+def test_node_programs_volumes_and_the_workgroup_kernel_on_emulation(children):
+    """The rare-features instantiations (node programs; volumes: sampler draws inside the walk) and, on the volumes fixture, k_pathtrace_wg
+    with its LDS lock."""
+    run_gpu_tier_on_emulation(children, "rare_and_wg")
 
 
-def test_gpu_bvh_builder_on_emulation(emu_lib):
+def test_gpu_bvh_builder_on_emulation(children):
     """csrc/bvh_build.hip on the shim (level-synchronous binning with LDS / global 64-bit atomics, the SAH sweeps as DPP row scans, one
     wave per small subtree): the reference's tree — node numbering, bounds bit patterns, primitive order — for the six scene fixtures and
     the degenerate inputs. (The 524 288-triangle stand-in and the 1 M soup pass too, in three minutes: run the GPU tier's file with
     CRH_LIB set to see it.)"""
-    run_gpu_tier_on_emulation(emu_lib, ["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8)
+    run_gpu_tier_on_emulation(children, "bvh")
 
 
-def test_bvh_builder_fuzz_on_emulation(emu_lib):
-    """tools/emu_fuzz_bvh.py, 24 seeded meshes that are awkward for a parallel builder (grid-aligned coordinates: every tie rule decides;
+def test_bvh_builder_fuzz_on_emulation(children):
+    """tools/emu_fuzz_bvh.py, 19 seeded meshes that are awkward for a parallel builder (grid-aligned coordinates: every tie rule decides;
     duplicates; clusters with outliers; flat and needle extents; sizes around the phase boundaries): the reference's tree, or — where the
     reference's own node array overflows — a refusal."""
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:24"], cwd=REPO, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
-    assert r.stdout.count('"ok": true') == 24 and '"refused": true' in r.stdout, r.stdout[-3000:]
+    rc, text = children("fuzz_bvh")
+    assert rc == 0, text[-4000:]
+    assert text.count('"ok": true') == 19 and '"refused": true' in text, text[-4000:]
 
 
-def test_rolling_units_kernel_on_emulation(emu_lib):
+def test_rolling_units_kernel_on_emulation(children):
     """k_pathtrace_roll (experimental kernel form, csrc/pathtrace_roll.h, compiled into the emulation library only): a ring of open
     jobs per wave instead of one unit at a time. Same frames, bit for bit, and the same ray counts — with the default units and with
     units so small that every slot of the ring is in use."""
     import json
-    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2")
-    names = ["cfg1_scene", "refraction", "volumes", "nodezoo", "glowmetal"]
-    r = subprocess.run([sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "2", *names], env=env, cwd=REPO, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    got = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert [g["name"] for g in got] == names
+    rc, text = children("roll")
+    assert rc == 0, text[-4000:]
+    got = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+    assert [g["name"] for g in got] == ROLL_FIXTURES
     assert all(g["equal"] for g in got), got
 
 
@@ -131,18 +174,17 @@ PINNED_STEPS = {
 }
 
 
-def test_scheduler_step_counts_are_pinned(emu_lib):
+def test_scheduler_step_counts_are_pinned(children):
     import json
-    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2")
-    r = subprocess.run([sys.executable, os.path.join(EMU_DIR, "sched_counts.py"), *PINNED_STEPS], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    got = {j["name"]: {k: v for k, v in j.items() if k != "name"} for j in (json.loads(l) for l in r.stdout.splitlines() if l.startswith("{"))}
+    rc, text = children("steps")
+    assert rc == 0, text[-4000:]
+    got = {j["name"]: {k: v for k, v in j.items() if k != "name"} for j in (json.loads(l) for l in text.splitlines() if l.startswith("{"))}
     assert got == PINNED_STEPS, got
 
 
-def test_schedule_fuzz_on_emulation(emu_lib):
-    """tools/emu_fuzz.py, twelve seeded cases: random work plans, scheduler parameters, kernel forms (wave / workgroup / rolling units),
+def test_schedule_fuzz_on_emulation(children):
+    """tools/emu_fuzz.py, nine seeded cases (three per kernel form): random work plans, scheduler parameters, kernel forms (wave / workgroup / rolling units),
     device sizes, tile covers and pass splits — every one must give the reference's frame bit for bit and its ray count."""
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:12"], cwd=REPO, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
-    assert r.stdout.count('"ok": true') == 12, r.stdout[-3000:]
+    rc, text = children("fuzz")
+    assert rc == 0, text[-4000:]
+    assert text.count('"ok": true') == 9, text[-4000:]

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""emu_fuzz_rays.py — dev / test: k_trace_rays (getClosestIsect for caller rays) on the kernel emulation against the oracle, on ADVERSARIAL rays:
+direction components that are exactly zero or -0 (the slab test's NaN cases), denormal, huge; origins on box faces, on vertices of the scene's
+geometry, far outside, exactly on the camera; axis-aligned rays through box edges. The hit record (instance, polygon, distance, point, normal, uv,
+material) of every ray whose direction components all have finite reciprocals must be the oracle's bit for bit, and no ray may cost more
+node tests than the reference's. Rays with a zero (or denormal) component take the device's exact-slab path: fewer node
+tests, and — rarely — a different record; those are counted and printed.
+
+Where degenerate rays differ (about 1 in 10^5 of these adversarial rays): (a) the origin sits one ulp beside an axis-aligned face and the ray runs
+parallel to it — the reference's NaN slab test lets it into the box, and its triangle test, whose rounding error exceeds that ulp, reports a hit
+the exact slab test has already excluded; (b) a direction so long that d.d or (d.o)^2 overflows fp32 (|d| beyond ~1e18) AND with a zero component. The reference's
+arithmetic is NaN all the way then — its slab test lets the ray into every box and sphere.c:30-47 reports a "hit" at distance NaN (every
+comparison with NaN is false) — while the device's exact test of a zero-component slab culls the box first. Likewise directions whose LARGEST
+component is tiny (1e-30 with a zero beside it): hit distances of 1e32 times denormal components are numerical noise, and the noise the reference
+finds in boxes its NaN slab test should not have let it into is not the noise the device finds. Rays the renderer makes are unit length;
+both cases need a caller of crh_trace_rays who passes such a direction.
+
+    python tools/emu_fuzz_rays.py [--seeds A:B] [--fixtures cfg1_scene,fence,...] [--rays N]
+"""
+import argparse, gzip, json, os, sys, tempfile
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", default="0:6")
+ap.add_argument("--fixtures", default="cfg1_scene,fence,refraction,glowmetal,uvsphere,alphanode")
+ap.add_argument("--rays", type=int, default=20000)
+ap.add_argument("--dump", default="", help="directory for the rays and both hit arrays of failing cases (.npy)")
+a = ap.parse_args()
+lo, hi = (int(v) for v in a.seeds.split(":"))
+fixtures = a.fixtures.split(",")
+os.environ["CRH_LIB"] = os.path.join(REPO, "tests", "emu", "libcray_hip_emu.so")
+os.environ.setdefault("HIPEMU_CUS", "4")
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
+import subprocess
+subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"])
+import numpy as np
+import oracle_py
+from __graft_entry__ import load_package
+pkg = load_package(); api = pkg.api
+ctx = api.Context(0)
+bad = 0
+for seed in range(lo, hi):
+    name = fixtures[seed % len(fixtures)]
+    rng = np.random.default_rng(seed)
+    with tempfile.NamedTemporaryFile(suffix=".blob") as f:
+        f.write(gzip.open(os.path.join(REPO, "tests", "golden", name + ".blob.gz")).read()); f.flush()
+        scene = api.Scene(f.name)
+        oscene = oracle_py.OracleScene(f.name)
+    ctx.upload(scene)
+    d = oscene.desc
+    cam = np.array(list(d.camera.A), dtype=np.float64).reshape(3, 4)
+    verts = np.ctypeslib.as_array(d.vertices, shape=(int(d.vertex_count), 3)).astype(np.float32) if int(d.vertex_count) else np.zeros((1, 3), np.float32)
+    n = a.rays
+    rays = np.zeros((n, 6), np.float32)
+    # origins: camera, far away, on scene vertices, on a coarse grid (box faces of axis-aligned geometry)
+    pick = rng.integers(0, 4, n)
+    rays[:, 0:3] = cam[:, 3]
+    far = pick == 1; rays[far, 0:3] = rng.uniform(-50, 50, (int(far.sum()), 3))
+    onv = pick == 2; rays[onv, 0:3] = verts[rng.integers(0, len(verts), int(onv.sum()))]
+    grid = pick == 3; rays[grid, 0:3] = np.round(rng.uniform(-4, 4, (int(grid.sum()), 3)) * 2) / 2
+    # directions: towards the scene, then components replaced by special values
+    target = verts[rng.integers(0, len(verts), n)] + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+    dirs = target - rays[:, 0:3]
+    dirs[np.abs(dirs).sum(axis=1) == 0] = [0, 0, 1]
+    special = np.array([0.0, -0.0, 1e-42, -1e-42, 1e-30, 1.0, -1.0, 1e9], np.float32)      # (not 3e37: see the note below)
+    for ax in range(3):
+        m = rng.random(n) < 0.25
+        dirs[m, ax] = special[rng.integers(0, len(special), int(m.sum()))]
+    tiny = np.abs(dirs).max(axis=1) < 0.1            # keep one component of ordinary size: see "Known and excluded"
+    dirs[tiny, rng.integers(0, 3, int(tiny.sum()))] = rng.choice([-1.0, 1.0], int(tiny.sum())) * rng.uniform(0.1, 2.0, int(tiny.sum()))
+    rays[:, 3:6] = dirs
+    hg, ho = ctx.trace_rays(rays), oracle_py.trace_rays(oscene, rays)
+    diff = {f: int((hg[f] != ho[f]).any(axis=tuple(range(1, hg[f].ndim))).sum() if hg[f].ndim > 1 else (hg[f] != ho[f]).sum())
+            for f in ("inst", "poly", "distance", "point", "normal", "uv", "material")}
+    # NaN-valued fields compare unequal to themselves: compare bit patterns
+    for f in ("distance", "point", "normal", "uv"):
+        ag, ao = np.ascontiguousarray(hg[f]).view(np.uint32), np.ascontiguousarray(ho[f]).view(np.uint32)
+        diff[f] = int((ag != ao).reshape(n, -1).any(axis=1).sum())
+    more = int((hg["node_tests"] > ho["node_tests"]).sum())
+    # rays with a direction component whose reciprocal is not finite (zero, or a denormal below 2.9e-39) take the device's exact-slab path:
+    # their records may differ from the reference's where its NaN slab test let it into boxes the ray misses (see above); counted, not failed
+    with np.errstate(divide="ignore"):
+        degenerate = ~np.isfinite(1.0 / rays[:, 3:6].astype(np.float32)).all(axis=1)
+    rec_differs = np.zeros(n, bool)
+    for f in ("inst", "poly", "material"):
+        rec_differs |= hg[f] != ho[f]
+    for f in ("distance", "point", "normal", "uv"):
+        rec_differs |= (np.ascontiguousarray(hg[f]).view(np.uint32) != np.ascontiguousarray(ho[f]).view(np.uint32)).reshape(n, -1).any(axis=1)
+    regular_differs = int((rec_differs & ~degenerate).sum())
+    ok = regular_differs == 0 and more == 0
+    bad += 0 if ok else 1
+    if a.dump and not ok:
+        np.save(os.path.join(a.dump, f"rays_{seed}.npy"), rays); np.save(os.path.join(a.dump, f"emu_{seed}.npy"), hg); np.save(os.path.join(a.dump, f"oracle_{seed}.npy"), ho)
+    print(json.dumps({"ok": bool(ok), "seed": seed, "fixture": name, "rays": n, "hits": int((ho["inst"] >= 0).sum()), "degenerate_rays": int(degenerate.sum()), "degenerate_rays_that_differ": int((rec_differs & degenerate).sum()),
+                      "regular_rays_that_differ": regular_differs, "more_node_tests": more,
+                      "fewer_node_tests": int((hg["node_tests"] < ho["node_tests"]).sum())}), flush=True)
+ctx.close()
+sys.exit(1 if bad else 0)

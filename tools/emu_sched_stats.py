@@ -2,8 +2,8 @@
 """emu_sched_stats.py — dev: the wave scheduler's step statistics WITHOUT a GPU, from the kernel emulation (tests/emu/libcray_hip_emu.so:
 cray_hip.hip on the HIP-on-CPU shim). A unit's schedule depends only on the unit (the wave's path table starts empty), so with the GPU's
 CU count (HIPEMU_CUS=256: the same work plan) the counts are the GPU's own, step for step: tools/probe_step_clocks.py on the GPU and this
-script print the same node / tri / ctrl / swap / gen / shade step counts and lanes per step. `model ms` prices the steps with the ns / step
-the GPU measured for that scene (profiles/r02d_probe_step_clocks.log) — a first-order cost model for scheduler changes.
+script print the same node / tri / ctrl / swap / gen / shade step counts and lanes per step. Two cost models are printed from the ns / step the GPU
+measured for that scene (profiles/r02d_probe_step_clocks.log): per step (A) and per lane-step (B); the hardware follows B.
 
     python tools/emu_sched_stats.py SCENE W H SPP BOUNCES [name=value ...]     e.g. cfg2_hdr 320 180 64 8 unit_items=4096 fill_to=192
 """
@@ -50,10 +50,20 @@ print(f"{name} {w}x{h} {spp} spp {b} bounces {opts}: emulated in {secs:.1f} s; r
 rows = (("node", t["w_node"], t["u_node"]), ("tri", t["w_tri"], t["u_tri"]), ("ctrl", t["w_ctrl"], t["u_ctrl"]), ("swap", t["n_swap"], t["u_swap"]),
         ("gen", t["n_gen"], None), ("shade", t["w_shade"], t["u_shade"]))
 ns = GPU_NS.get(name)
-total = 0.0
+LANES = {"cfg2_hdr": dict(node=34.9, tri=19.9, ctrl=13.3, swap=52.5, shade=53.1),        # lanes per step of the runs GPU_NS comes from
+         "cfg3_venus": dict(node=24.0, tri=2.7, ctrl=2.9, swap=22.6, shade=43.8), "soup_1m": dict(node=35.0, tri=5.8, ctrl=29.9, swap=32.2, shade=57.1)}
+per_step = per_lane = 0.0
 for k, n, lanes in rows:
     s = f"  {k:6s} {n:12d} steps"
     if lanes is not None: s += f", {lanes / max(n, 1):5.1f} lanes/step"
-    if ns: total += n * ns[k]; s += f", {n * ns[k] / 1e6:10.1f} wave-ms"
+    if ns:
+        per_step += n * ns[k]
+        per_lane += (lanes * ns[k] / LANES[name][k]) if lanes is not None else n * ns[k]
+        s += f", {n * ns[k] / 1e6:10.1f} wave-ms per step"
     print(s)
-print(f"  rounds {t['w_round']}" + (f"; model: {total / 1e6:.1f} wave-ms = {total / 1e6 / 4096:.2f} ms on 4096 waves, {total / max(rays, 1):.1f} wave-ns per ray" if ns else ""), flush=True)
+print(f"  rounds {t['w_round']}")
+if ns:
+    print(f"  model A (a step costs what the GPU measured per STEP):      {per_step / 1e6:9.1f} wave-ms = {per_step / 1e6 / 4096:.2f} ms on 4096 waves, {per_step / max(rays, 1):.1f} wave-ns per ray")
+    print(f"  model B (a step costs what the GPU measured per LANE-step): {per_lane / 1e6:9.1f} wave-ms = {per_lane / 1e6 / 4096:.2f} ms on 4096 waves, {per_lane / max(rays, 1):.1f} wave-ns per ray")
+    print("  (the MI355X follows B, not A: r02e_roll_step_clocks.log — 17 % fewer node steps at 20 % more lanes took the same time; neither model sees the cache misses\n"
+          "   that a bigger working set adds: r02e_pmc_base_vs_roll.txt)", flush=True)

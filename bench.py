@@ -216,6 +216,8 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if hasattr(api.library(), "crh_emu_stats"):
+        raise SystemExit("bench.py: CRH_LIB names the CPU emulation of the kernels (tests/emu): bench.py measures the MI355X path only")
     if api.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; libcray_hip has no CPU fallback")
     dist = None

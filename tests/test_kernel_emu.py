@@ -49,7 +49,7 @@ def children(emu_lib):
     """Every child process of this module, started at once (they are independent; each runs the emulation on two OS threads): the module
     takes as long as its slowest child instead of the sum."""
     import tempfile
-    env = dict(os.environ, CRH_LIB=emu_lib, HIPEMU_CUS="2", HIPEMU_THREADS="3")
+    env = dict(os.environ, CRH_LIB=emu_lib, CRH_ALLOW_EMULATION="1", HIPEMU_CUS="2", HIPEMU_THREADS="3")
     procs = {}
 
     def start(name, cmd):
@@ -201,3 +201,18 @@ def test_adversarial_rays_on_emulation(children):
     got = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
     assert len(got) == 6 and all(g["ok"] and g["regular_rays_that_differ"] == 0 and g["more_node_tests"] == 0 for g in got), got
     assert sum(g["degenerate_rays_that_differ"] for g in got) <= 6, got          # measured: 1 in 40 000 of the degenerate ones
+
+
+def test_product_entry_points_refuse_the_emulation(emu_lib):
+    """api.py binds to the emulation library only for a caller that says CRH_ALLOW_EMULATION=1; bench.py and smoke() refuse it even then."""
+    env = dict(os.environ, CRH_LIB=emu_lib)
+    env.pop("CRH_ALLOW_EMULATION", None)
+    code = "import sys; sys.path.insert(0, %r); from __graft_entry__ import load_package; load_package().api.library()" % REPO
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "CPU emulation" in r.stderr, r.stderr[-1500:]
+    env["CRH_ALLOW_EMULATION"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0"], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "CPU emulation" in (r.stderr + r.stdout), (r.stdout + r.stderr)[-1500:]
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.smoke()" % REPO], env=env, cwd=REPO,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "CPU emulation" in r.stderr, r.stderr[-1500:]

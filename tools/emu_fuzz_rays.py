@@ -28,6 +28,7 @@ a = ap.parse_args()
 lo, hi = (int(v) for v in a.seeds.split(":"))
 fixtures = a.fixtures.split(",")
 os.environ["CRH_LIB"] = os.path.join(REPO, "tests", "emu", "libcray_hip_emu.so")
+os.environ["CRH_ALLOW_EMULATION"] = "1"
 os.environ.setdefault("HIPEMU_CUS", "4")
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
 import subprocess

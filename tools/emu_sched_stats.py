@@ -10,6 +10,7 @@ measured for that scene (profiles/r02d_probe_step_clocks.log): per step (A) and 
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["CRH_LIB"] = os.path.join(REPO, "tests", "emu", "libcray_hip_emu.so")
+os.environ["CRH_ALLOW_EMULATION"] = "1"
 os.environ.setdefault("HIPEMU_CUS", "256")
 sys.path.insert(0, REPO)
 from __graft_entry__ import load_package, BUILT

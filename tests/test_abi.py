@@ -55,6 +55,18 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle_py" not in text and "libcray_oracle" not in text and "cray_oracle.h" not in text, os.path.join(root, f)
 
 
+def test_default_library_holds_no_experimental_kernel_and_no_emulation(pkg):
+    """The library the product loads is the measured one: the experimental kernel forms (csrc/pathtrace_roll.h, -DCRH_EXP_*) are not compiled
+    into it, it is not the CPU emulation, and the product sources never name the emulation library."""
+    lib = os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so")
+    blob = open(lib, "rb").read()
+    assert b"k_pathtrace_roll" not in blob and b"crh_emu_stats" not in blob and b"hipemu" not in blob
+    for root, _, files in os.walk(os.path.join(REPO, "c-ray_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".cpp", ".hip")):
+                assert "libcray_hip_emu" not in open(os.path.join(root, f), errors="replace").read(), os.path.join(root, f)
+
+
 def test_blob_roundtrip(pkg, golden_blob, tmp_path):
     scene = pkg.api.Scene(golden_blob("fence"))
     out = str(tmp_path / "copy.blob")

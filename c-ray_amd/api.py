@@ -40,7 +40,7 @@ def library():
     except Exception:
         pass
     L = C.CDLL(LIB_PATH)
-    # tests/emu/libcray_hip_emu.so — the kernels compiled for the CPU on a HIP shim — exports the same C-ABI. It is test infrastructure: only
+    # The emulation library of tests/emu — the kernels compiled for the CPU on a HIP shim — exports the same C-ABI. It is test infrastructure: only
     # a caller that says so explicitly (the emulation tier's child processes and the tools/emu_* scripts) may bind to it.
     if hasattr(L, "crh_emu_stats") and os.environ.get("CRH_ALLOW_EMULATION") != "1":
         raise RuntimeError(f"{LIB_PATH} is the CPU emulation of the kernels (test infrastructure): the product has no CPU path "

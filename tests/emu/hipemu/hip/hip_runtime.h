@@ -10,8 +10,9 @@
  * developed and counted (steps per kind, lanes per step) before they cost GPU minutes.
  *
  * How: every lane is a fiber (a few lines of x86-64 context switch, no ucontext system calls); a lane runs until it reaches a
- * wave collective (__ballot, __shfl_xor, readfirstlane), a block barrier (__syncthreads), s_sleep, or the end of the kernel; when
- * all live lanes of a wave wait at the same collective it is resolved and they continue. Lanes that have left the kernel count as
+ * wave collective (__ballot, __shfl / __shfl_up / __shfl_xor, readfirstlane, DPP quad permutes, row shifts and row_bcast15, the
+ * CRH_LOCKSTEP rendezvous), a block barrier (__syncthreads), s_sleep, or the end of the kernel; when all live lanes of a wave wait at
+ * the same collective it is resolved and they continue. Lanes that have left the kernel count as
  * inactive, as on the hardware. Collectives inside divergent control flow that only part of a wave reaches are NOT modelled (the
  * kernels have none; the runtime aborts if lanes wait at different call sites). The waves of a block take turns one collective
  * at a time, blocks are spread over OS threads, `__shared__` is `static thread_local` (a block lives on one OS thread).
@@ -158,14 +159,13 @@ static __forceinline__ int hipemu_update_dpp(int old, int src, int ctrl, int row
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rowMask, bankMask, boundCtrl) hipemu_update_dpp((old), (src), (ctrl), (rowMask), (bankMask), (boundCtrl), HIPEMU_SITE)
 static __forceinline__ float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static __forceinline__ int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
-static __forceinline__ unsigned hipemu_lane() { return (hipemu::t_lane->tIdx.x + hipemu::t_lane->tIdx.y * hipemu::t_lane->bDim.x) & 63u; }
 /* mbcnt: the number of set mask bits below this lane (+ base) */
 static __forceinline__ unsigned hipemu_mbcnt_lo(unsigned mask, unsigned base) {
-	const unsigned l = hipemu_lane();
+	const unsigned l = hipemu_lane_id();
 	return base + (unsigned)__builtin_popcount(l >= 32u ? mask : (mask & ((1u << l) - 1u)));
 }
 static __forceinline__ unsigned hipemu_mbcnt_hi(unsigned mask, unsigned base) {
-	const unsigned l = hipemu_lane();
+	const unsigned l = hipemu_lane_id();
 	return base + (l > 32u ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32u)) - 1u)) : 0u);
 }
 #define __builtin_amdgcn_mbcnt_lo(m, b) hipemu_mbcnt_lo(m, b)

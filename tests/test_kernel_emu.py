@@ -40,6 +40,9 @@ GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of 
     "rare_and_wg": (["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"], "test_gpu_node_zoo or test_gpu_volumes", 3),          # (test_gpu_volumes renders with both kernel forms;
     # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
+    # the reference's own program with renderer.c replaced (c-ray-hip: its main.c, JSON / OBJ loaders, encoders, renderer_hip.c, flatten.c, the GPU
+    # BVH builder behind buildBottomLevelBvh) and its cluster worker, bound to the emulation library with LD_PRELOAD: the drop-in boundary on the CPU
+    "dropin": (["test_gpu_parity.py"], "dropin_binary or cluster_worker", 2),
 }
 ROLL_FIXTURES = ["cfg1_scene", "refraction", "volumes", "nodezoo", "glowmetal"]
 
@@ -49,7 +52,7 @@ def children(emu_lib):
     """Every child process of this module, started at once (they are independent; each runs the emulation on two OS threads): the module
     takes as long as its slowest child instead of the sum."""
     import tempfile
-    env = dict(os.environ, CRH_LIB=emu_lib, CRH_ALLOW_EMULATION="1", HIPEMU_CUS="2", HIPEMU_THREADS="3")
+    env = dict(os.environ, CRH_LIB=emu_lib, CRH_ALLOW_EMULATION="1", CRH_DROPIN_PRELOAD=emu_lib, HIPEMU_CUS="2", HIPEMU_THREADS="3")
     procs = {}
 
     def start(name, cmd):
@@ -216,3 +219,13 @@ def test_product_entry_points_refuse_the_emulation(emu_lib):
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.smoke()" % REPO], env=env, cwd=REPO,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "CPU emulation" in r.stderr, r.stderr[-1500:]
+
+
+def test_dropin_program_and_cluster_worker_on_emulation(children):
+    """SURVEY 8(b) on the CPU: c-ray-hip — the reference's main.c, loaders, encoders and tile / UI code with ONE file replaced — renders
+    config 1 through renderFrame() -> flatten -> C-ABI -> kernels (emulated) -> BMP encoder, normal and --iterative, and its `--worker` serves
+    the reference's wire protocol to a test master: the reference's frame bit for bit, its tiles byte for byte. Needs the drop-in program and
+    the asset overlay (built where /root/reference exists)."""
+    if not (os.path.exists(os.path.join(REPO, "c-ray_amd", "_lib", "c-ray-hip")) and os.path.exists(os.path.join(REPO, "oracle", "_ref", "input", "scene.json"))):
+        pytest.skip("c-ray-hip or the asset overlay is not built (needs /root/reference at build time)")
+    run_gpu_tier_on_emulation(children, "dropin")

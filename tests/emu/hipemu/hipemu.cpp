@@ -270,10 +270,13 @@ const char *hipGetErrorString(hipError_t e) {
 	return "unknown error";
 }
 hipError_t hipGetLastError(void) { return hipSuccess; }
-hipError_t hipGetDeviceCount(int *n) { if (!n) return hipErrorInvalidValue; *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int device) { return device == 0 ? hipSuccess : hipErrorInvalidDevice; }
+/* HIPEMU_DEVICES=<n>: that many identical "devices" (all of them this CPU and this heap): lets a host that drives several GPUs from several
+ * threads — renderer_hip.c — run its partition and gather logic */
+static int deviceCount() { const char *e = getenv("HIPEMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : (n > 16 ? 16 : n); }
+hipError_t hipGetDeviceCount(int *n) { if (!n) return hipErrorInvalidValue; *n = deviceCount(); return hipSuccess; }
+hipError_t hipSetDevice(int device) { return device >= 0 && device < deviceCount() ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device) {
-	if (!prop || device != 0) return hipErrorInvalidValue;
+	if (!prop || device < 0 || device >= deviceCount()) return hipErrorInvalidValue;
 	memset(prop, 0, sizeof(*prop));
 	snprintf(prop->name, sizeof(prop->name), "hipemu (CPU emulation, tests only)");
 	const char *e = getenv("HIPEMU_CUS");

@@ -30,10 +30,11 @@ def ctx(pkg):
 
 def dropin_preload():
     """Extra environment of the c-ray-hip child processes. Empty on a GPU box. The CPU tier (tests/test_kernel_emu.py) runs these tests
-    against the kernel emulation and names that library here, so that the reference's program binds to it instead of libcray_hip.so."""
+    against the kernel emulation: CRH_DROPIN_LIBDIR names a directory whose libcray_hip.so IS the emulation library, and the program's
+    loader finds it there before its RUNPATH."""
     import os
-    lib = os.environ.get("CRH_DROPIN_PRELOAD")
-    return {"LD_PRELOAD": lib} if lib else {}
+    libdir = os.environ.get("CRH_DROPIN_LIBDIR")
+    return {"LD_LIBRARY_PATH": libdir + ":" + os.environ.get("LD_LIBRARY_PATH", "")} if libdir else {}
 
 
 def gpu_render(pkg, ctx, blob, w, h, s, b, **kw):

@@ -41,7 +41,7 @@ GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of 
     # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
     # the reference's own program with renderer.c replaced (c-ray-hip: its main.c, JSON / OBJ loaders, encoders, renderer_hip.c, flatten.c, the GPU
-    # BVH builder behind buildBottomLevelBvh) and its cluster worker, bound to the emulation library with LD_PRELOAD: the drop-in boundary on the CPU
+    # BVH builder behind buildBottomLevelBvh) and its cluster worker, bound to the emulation library (LD_LIBRARY_PATH -> tests/emu/_dropin_libs): the drop-in boundary on the CPU
     "dropin": (["test_gpu_parity.py"], "dropin_binary or cluster_worker", 2),
 }
 ROLL_FIXTURES = ["cfg1_scene", "refraction", "volumes", "nodezoo", "glowmetal"]
@@ -52,7 +52,7 @@ def children(emu_lib):
     """Every child process of this module, started at once (they are independent; each runs the emulation on two OS threads): the module
     takes as long as its slowest child instead of the sum."""
     import tempfile
-    env = dict(os.environ, CRH_LIB=emu_lib, CRH_ALLOW_EMULATION="1", CRH_DROPIN_PRELOAD=emu_lib, HIPEMU_CUS="2", HIPEMU_THREADS="3")
+    env = dict(os.environ, CRH_LIB=emu_lib, CRH_ALLOW_EMULATION="1", CRH_DROPIN_LIBDIR=os.path.join(EMU_DIR, "_dropin_libs"), HIPEMU_CUS="2", HIPEMU_THREADS="3")
     procs = {}
 
     def start(name, cmd):
@@ -229,3 +229,32 @@ def test_dropin_program_and_cluster_worker_on_emulation(children):
     if not (os.path.exists(os.path.join(REPO, "c-ray_amd", "_lib", "c-ray-hip")) and os.path.exists(os.path.join(REPO, "oracle", "_ref", "input", "scene.json"))):
         pytest.skip("c-ray-hip or the asset overlay is not built (needs /root/reference at build time)")
     run_gpu_tier_on_emulation(children, "dropin")
+
+
+def test_dropin_program_on_several_emulated_gpus(emu_lib, manifest, golden_ref, tmp_path):
+    """renderer_hip.c with more than one GPU, which no single-GPU box can run: HIPEMU_DEVICES emulated devices, one dispatch thread each,
+    4-row strips dealt to them (host/share.h), the float framebuffers summed onto GPU 0 through the RCCL entry points (a stand-in library:
+    tests/emu/fake_rccl.c), downloaded, resolved — and, with --iterative, the per-chunk gather of every GPU's strips on the host. The frame
+    is the reference's, bit for bit, whatever the number of GPUs."""
+    import json
+    import numpy as np
+    exe = os.path.join(REPO, "c-ray_amd", "_lib", "c-ray-hip")
+    overlay = os.path.join(REPO, "oracle", "_ref", "input")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(overlay, "scene.json"))):
+        pytest.skip("c-ray-hip or the asset overlay is not built (needs /root/reference at build time)")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import refrun
+    libdir = os.path.join(EMU_DIR, "_dropin_libs")
+    for mode, key, gpu_counts in (((), "cfg1_scene", (2, 5)), (("--iterative",), "cfg1_scene_iterative", (3,))):
+        m = manifest[key]
+        w, h = manifest["cfg1_scene"]["width"], manifest["cfg1_scene"]["height"]
+        scene = refrun.rewrite_scene("scene.json", w, h, m["samples"], m["bounces"], out_dir=str(tmp_path))
+        for gpus in gpu_counts:
+            dump = str(tmp_path / f"hip_{key}_{gpus}.f32")
+            env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES=str(gpus), HIPEMU_DEVICES=str(gpus), HIPEMU_CUS="2", HIPEMU_THREADS="4",
+                       LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+            proc = subprocess.run([exe, *mode], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+            out = proc.stdout.decode(errors="replace")
+            assert proc.returncode == 0 and f"on {gpus} GPUs" in out, out[-2000:]
+            img = np.fromfile(dump, dtype=np.float32).reshape(h, w, 3)
+            assert np.array_equal(img.view(np.uint32), golden_ref(key).view(np.uint32)), (key, gpus)

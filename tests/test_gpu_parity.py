@@ -28,7 +28,7 @@ def ctx(pkg):
     c.close()
 
 
-def dropin_preload():
+def dropin_env():
     """Extra environment of the c-ray-hip child processes. Empty on a GPU box. The CPU tier (tests/test_kernel_emu.py) runs these tests
     against the kernel emulation: CRH_DROPIN_LIBDIR names a directory whose libcray_hip.so IS the emulation library, and the program's
     loader finds it there before its RUNPATH."""
@@ -416,7 +416,7 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
     scene = refrun.rewrite_scene("scene.json", w, h, s, b, out_dir=str(tmp_path))
     dump = str(tmp_path / "hip.f32")
-    env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES="1", **dropin_preload())
+    env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES="1", **dropin_env())
     proc = subprocess.run([exe], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE,
                           stderr=subprocess.STDOUT, timeout=600)
     assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-2000:]
@@ -596,7 +596,7 @@ def test_cluster_worker_renders_its_tiles_on_the_gpu(pkg, oracle, manifest, gold
     tiles = pkg.tiles.quantize_image(w, h, 32, 32, pkg.tiles.ORDER_FROM_MIDDLE)
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    worker = subprocess.Popen([gpu_worker, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1", **dropin_preload()),
+    worker = subprocess.Popen([gpu_worker, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1", **dropin_env()),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     got = {}
     try:

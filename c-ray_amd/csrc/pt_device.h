@@ -747,7 +747,9 @@ CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
  * two slab parameters because invDir carries the sign the octant was taken from), so v_min / v_max / v_max3 /
  * v_min3 give the same boolean and the same tEntry (up to the sign of zero, which no comparison sees).
  *
- * Slow path, two deliberate, result-preserving differences ("degenerate rays"):
+ * Slow path, two deliberate differences ("degenerate rays"; result-preserving except where the reference's extra visits find a
+ * hit its own rounding error allows — an origin one ulp beside an axis-aligned face, the ray parallel to it: 5 of 190 750 adversarial
+ * zero / denormal-component rays in tools/emu_fuzz_rays.py, none of the rendered fixtures and configurations):
  *  - a direction component that is zero (or so small that 1/d > 1e30): the reference computes
  *    fma(bound, inf, -start*inf) = inf - inf = NaN whenever bound and start have the same sign, and its
  *    NaN-ordered selects then drop that slab AND the x slab, so the walk visits every node and triangle of the

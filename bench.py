@@ -148,12 +148,18 @@ def dropin_timing(workload):
         if proc.returncode != 0 or not os.path.exists(stats):
             return {"failed": proc.stdout.decode(errors="replace")[-300:]}
         st = json.load(open(stats))
-    return {"program": "c-ray_amd/_lib/c-ray-hip < hdr.json (1 GPU)", "mrays": round(st["rays"] / st["render_ms"] / 1e3, 1), "render_ms": st["render_ms"],
-            "kernel_ms": st.get("kernel_ms"), "launch_host_ms": st.get("launch_host_ms"),
-            "context_upload_ms": st["context_upload_ms"], "flatten_ms": st["flatten_ms"], "reduce_download_ms": st["reduce_download_ms"],
-            "resolve_srgb_ms": st["resolve_srgb_ms"], "process_wall_s": round(wall, 2), "rays": st["rays"],
-            "note": "render_ms = first dispatch to last synchronize inside renderFrame(); context_upload_ms = HIP context creation + layout compile + copies "
-                    "(one-off per process); process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
+    phase = st.get("render_phase_ms", st["render_ms"])
+    return {"program": "c-ray_amd/_lib/c-ray-hip < hdr.json (1 GPU)",
+            "render_phase_ms": phase, "mrays": round(st["rays"] / phase / 1e3, 1),
+            "render_ms": st["render_ms"], "kernel_ms": st.get("kernel_ms"), "dispatches": st.get("dispatches"), "launch_host_ms": st.get("launch_host_ms"),
+            "resolve_srgb_ms": st["resolve_srgb_ms"], "download_ms": st.get("download_ms"), "gather_ms": st.get("gather_ms"),
+            "frame_ms": st.get("frame_ms"), "setup_ms": st.get("setup_ms"), "flatten_ms": st["flatten_ms"], "context_ms": st.get("context_ms"),
+            "upload_ms": st.get("upload_ms"), "process_wall_s": round(wall, 2), "rays": st["rays"],
+            "phase_vs_kernel": round(phase / st["kernel_ms"], 4) if st.get("kernel_ms") else None,
+            "note": "render_phase_ms = SURVEY 8(d)'s phase: the timer of src/c-ray.c:279-281 around renderFrame() (frame_ms) minus the set-up (setup_ms: everything "
+                    "before the GPU was ready to dispatch — context + code objects + per-wave buffers, which run beside the flattener, then the scene upload); it holds "
+                    "the dispatch (render_ms; kernel_ms = its GPU time), the 8-bit conversion on the device + its download (resolve_srgb_ms), the float "
+                    "buffer's download and the host in between; mrays = rays / render_phase_ms. process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
 
 
 def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
@@ -292,7 +298,11 @@ def main():
             "config": {"workload": WORKLOAD["what"].format(W=W, H=H, SPP=SPP, B=B),
                        "rays_per_step": int(total_rays / a.steps), "paths_per_step": int(total_paths / a.steps),
                        "parallelism": ("1 rank: the whole frame in one dispatch" if world == 1 else
-                                       f"4-row strips interleaved over {world} ranks + one RCCL reduce of the float framebuffer")},
+                                       f"4-row strips interleaved over {world} ranks; rank 0 gathers the owned strips (1/{world} of the float framebuffer per rank, "
+                                       "RCCL send / receive over xGMI; render.py: StripGather — bit-identical to the one-reduce form)"),
+                       "baseline_config": {"cfg2": "configs[1] (the 1-GPU headline; at N > 1 a STRONG-scaling run of the same 88 ms frame)", "cfg3": "configs[2]",
+                                           "cfg4": "configs[3] (the scene BASELINE.json quotes the 1/2/4/8-GPU curve on: --workload cfg4)",
+                                           "soup": "configs[4] at 1 M triangles", "soup10m": "configs[4]"}.get(a.workload)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_scene / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_pathtrace", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
@@ -315,8 +325,8 @@ def main():
             except Exception:
                 pass
             out["dropin"] = dropin_timing(WORKLOAD)
-            if isinstance(out["dropin"].get("render_ms"), (int, float)):
-                out["dropin"]["vs_bench_ms_per_step"] = round(out["dropin"]["render_ms"] / ms_per_step, 3)
+            if isinstance(out["dropin"].get("render_phase_ms"), (int, float)):
+                out["dropin"]["vs_bench_ms_per_step"] = round(out["dropin"]["render_phase_ms"] / ms_per_step, 3)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -65,6 +65,9 @@ def library():
         "crh_render_tiles": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.POINTER(abi.Tile), C.c_uint32, C.c_void_p]),
         "crh_synchronize": (C.c_int, [ctx]),
         "crh_frames_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+        "crh_frames_gather": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+        "crh_frames_prepare": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+        "crh_context_prepare": (C.c_int, [ctx]),
         "crh_counters_get": (C.c_int, [ctx, C.POINTER(abi.Counters)]),
         "crh_counters_reset": (C.c_int, [ctx]),
         "crh_kernel_time_ms": (C.c_int, [ctx, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -175,7 +178,12 @@ class Context:
                 "t_swap", "t_gen", "n_swap", "n_gen", "u_swap", "u_tri", "u_ctrl")
         return {k: int(v) for k, v in zip(keys, buf)}
 
-    def set_sched(self, node, tri, ctrl, swap_min, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=64):
+    def prepare(self):
+        """crh_context_prepare: per-wave buffers + code objects before the scene is there (optional)."""
+        _check(self.L.crh_context_prepare(self.h), "crh_context_prepare")
+
+    def set_sched(self, node, tri, ctrl, swap_min, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=0):
+        """shade_min = 0 keeps the library's tuned value (include/cray_hip.h: CRH_OPT_SCHED_RUNS)."""
         self.set_option(abi.OPT_SCHED_WEIGHTS, node | (tri << 12) | (ctrl << 24) | (swap_min << 36))
         self.set_option(abi.OPT_SCHED_RUNS, fill_to | (run_num << 12) | (tri_in_run << 16) | (ctrl_in_run << 24) | (shade_min << 32))
 

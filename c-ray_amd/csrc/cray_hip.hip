@@ -1075,6 +1075,12 @@ struct crh_ctx {
 	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
 	size_t ovfWords = 0;
 	unsigned int *dErr = nullptr;            /* workgroup kernel: watchdog flag */
+	std::vector<int> preloaded;              /* kernel instantiations whose code object is loaded (variantKey) */
+	float *dGather = nullptr;                /* crh_frames_gather: this GPU's strips packed (senders) / every sender's slab (GPU 0) */
+	size_t gatherFloats = 0;
+	uint8_t *dSrgb = nullptr;                /* crh_framebuffer_to_srgb8: the 8-bit frame on the device (grown on demand, kept) */
+	size_t srgbBytes = 0;
+	bool wgSinceCheck = false;               /* a workgroup-kernel launch has happened since the flag was last read (the default kernel never writes it) */
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
 	int wavesPerSimd = 4;
@@ -1136,6 +1142,8 @@ static int resolveTimes(crh_ctx *c, bool wait) {
 
 /* the workgroup kernel aborts instead of hanging: report it (call with the stream drained) */
 static int checkWatchdog(crh_ctx *c) {
+	if (!c->wgSinceCheck) return CRH_OK;          /* no blocking device-to-host copy per download / synchronize for the default kernel */
+	c->wgSinceCheck = false;
 	unsigned int err = 0;
 	HIP_TRY(hipMemcpy(&err, c->dErr, sizeof(err), hipMemcpyDeviceToHost));
 	if (err) {
@@ -1160,6 +1168,7 @@ static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
 /* Launch the instantiation the context's options select (counter level, register budget, rare features, sampler, kernel form). */
 static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_params *P, const BlockQueue &Q, float *dev_fb, int chunk) {
 	const bool wg = c->kernel == CRH_KERNEL_WG;
+	if (wg) c->wgSinceCheck = true;
 #define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace<LEVEL, WPS, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 												  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf)
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
@@ -1223,6 +1232,7 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 
 /* Load the code object of the selected instantiation now (HIP loads kernels lazily, ~40 ms on first launch) with a launch that finds
  * an empty work queue: crh_scene_upload calls it, so a renderer's first frame is not the one that pays for it. */
+static int variantKey(const crh_ctx *c) { return (c->hasPrograms ? 1 : 0) | (c->sampler << 1) | (c->counterLevel << 2) | (c->wavesPerSimd << 4) | (c->kernel << 8); }
 static int preloadKernel(crh_ctx *c) {
 	crh_render_params P;
 	memset(&P, 0, sizeof(P));
@@ -1250,10 +1260,13 @@ static int preloadKernel(crh_ctx *c) {
 		HIP_TRY(hipMalloc((void **)&c->dStage, waves * (size_t)c->unitItems * 3 * sizeof(float)));
 		c->stageFloats = waves * (size_t)c->unitItems * 3;
 	}
+	const int key = variantKey(c);
+	if (std::find(c->preloaded.begin(), c->preloaded.end(), key) != c->preloaded.end()) return CRH_OK;      /* crh_context_prepare has been here */
 	HIP_TRY(hipMemsetAsync(c->dWork, 0, sizeof(uint32_t), c->stream));
 	const hipError_t e = launchPathtrace(c, 1, &P, Q, nullptr, 1);
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("kernel preload: ") + hipGetErrorString(e));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->preloaded.push_back(key);
 	return CRH_OK;
 }
 
@@ -1319,6 +1332,8 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dQueues) (void)hipFree(c->dQueues);
 	if (c->dOvf) (void)hipFree(c->dOvf);
 	if (c->dErr) (void)hipFree(c->dErr);
+	if (c->dSrgb) (void)hipFree(c->dSrgb);
+	if (c->dGather) (void)hipFree(c->dGather);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return CRH_OK;
@@ -1391,6 +1406,18 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		}
 		default: return fail(CRH_ERR_INVALID, "unknown option");
 	}
+}
+
+/* Everything of crh_scene_upload that does not need the scene: the per-wave buffers of a full-size dispatch and the code objects of both
+ * feature variants of the kernel the current options select. A host calls it while it is still flattening its scene (renderer_hip.c). */
+int crh_context_prepare(crh_ctx *c) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_context_prepare: ctx is NULL");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	const bool had = c->hasPrograms;
+	for (int v = 0; v < 2 && rc == CRH_OK; ++v) { c->hasPrograms = (v == 1); rc = preloadKernel(c); }
+	c->hasPrograms = had;
+	return rc;
 }
 
 int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
@@ -1471,14 +1498,17 @@ int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int hei
 	int rc = setDevice(c);
 	if (rc) return rc;
 	const size_t n = (size_t)width * height * 3;
-	uint8_t *tmp = nullptr;
-	HIP_TRY(hipMalloc((void **)&tmp, n));
+	if (n > c->srgbBytes) {               /* kept by the context: an interactive host converts after every pass chunk */
+		if (c->dSrgb) HIP_TRY(hipFree(c->dSrgb));
+		c->dSrgb = nullptr; c->srgbBytes = 0;
+		HIP_TRY(hipMalloc((void **)&c->dSrgb, n));
+		c->srgbBytes = n;
+	}
 	const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-	hipLaunchKernelGGL(k_to_srgb8, dim3(grid), dim3(256), 0, c->stream, dev_fb, n, tmp);
+	hipLaunchKernelGGL(k_to_srgb8, dim3(grid), dim3(256), 0, c->stream, dev_fb, n, c->dSrgb);
 	hipError_t e = hipGetLastError();
-	if (e == hipSuccess) e = hipMemcpyAsync(host_rgb8, tmp, n, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(host_rgb8, c->dSrgb, n, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	(void)hipFree(tmp);
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_framebuffer_to_srgb8: ") + hipGetErrorString(e));
 	return CRH_OK;
 }
@@ -1532,9 +1562,11 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 	std::vector<crh_tile> &work = W.work;
 	work.assign(tiles, tiles + tile_count);
 	/* index of the first tile of the tail that holds the last `want` pixels (the boundary tile is split by rows) */
-	auto cutTail = [&work](uint64_t want) -> uint32_t {
+	int64_t insertedAt = -1;                /* position of the tile the last cutTail() inserted (-1: it split none) */
+	auto cutTail = [&work, &insertedAt](uint64_t want) -> uint32_t {
 		uint64_t got = 0;
 		uint32_t t = (uint32_t)work.size();
+		insertedAt = -1;
 		while (t > 0 && got < want) {
 			const crh_tile r = work[t - 1];
 			const uint64_t a = (uint64_t)(r.x1 - r.x0) * (uint64_t)(r.y1 - r.y0);
@@ -1546,6 +1578,7 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 			const int ySplit = r.y1 - rowsSmall;                 /* rows are independent: which part goes first is free */
 			work[t - 1] = crh_tile{r.x0, r.y0, r.x1, ySplit};
 			work.insert(work.begin() + t, crh_tile{r.x0, ySplit, r.x1, r.y1});
+			insertedAt = (int64_t)t;
 			break;
 		}
 		return t;
@@ -1565,7 +1598,11 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 		tbw = sbw; tbh = sbh;
 		if (tinyArea < smallArea && K.tail2Percent > 0 && K.tail2Percent < K.tailPercent) {
 			shapeOf(tinyArea, tbw, tbh);
-			firstTiny = std::max(firstSmall, cutTail(pixels * (uint64_t)K.tail2Percent / 100));
+			const uint32_t t2 = cutTail(pixels * (uint64_t)K.tail2Percent / 100);
+			/* with its + 25 % tolerance the second cut can reach a tile in front of the first one's (tail2Percent close to tailPercent): the
+			 * tile it inserts then shifts the quarter-size tail by one */
+			if (insertedAt >= 0 && (uint32_t)insertedAt <= firstSmall) ++firstSmall;
+			firstTiny = std::max(firstSmall, t2);
 		}
 	}
 	const uint32_t work_count = (uint32_t)work.size();
@@ -1586,7 +1623,7 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 	W.grid = (uint32_t)std::min<uint64_t>((uint64_t)K.cuCount * K.blocksPerCU, K.wg ? total : (total + 3) / 4);
 	/* passes per chunk: a chunk (block x passes) should also hold about unitItems paths, so that each lane runs >= 16
 	 * paths between two wave-wide folds */
-	W.chunk = std::min(P->pass_count, std::max(K.passChunk, (unitItems + area - 1) / area));
+	W.chunk = std::min(P->pass_count, std::max(K.passChunk, (unitItems + bw * bh - 1) / (bw * bh)));      /* bw x bh < area when the tiles are thinner than the block (strips) */
 	return CRH_OK;
 }
 
@@ -1684,7 +1721,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	}
 
 	/* per-launch tile list: pinned host slot -> device slot, asynchronously on the launch stream */
-	const uint32_t slot = c->workSlot++ % CRH_WORK_SLOTS;
+	const uint32_t slot = c->workSlot % CRH_WORK_SLOTS;          /* consumed below, once nothing can fail before the launch */
 	crh_ctx::TileSlot &ts = c->tileSlots[slot];
 	const size_t tileBytes = work_count * sizeof(crh_tile), startBytes = (work_count + 1) * sizeof(uint32_t);
 	if (ts.inFlight) { HIP_TRY(hipEventSynchronize(ts.done)); ts.inFlight = false; }
@@ -1713,6 +1750,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	Q.firstSmall = firstSmall; Q.sbw = sbw; Q.sbh = sbh;
 	Q.firstTiny = firstTiny; Q.tbw = tbw; Q.tbh = tbh;
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
+	c->workSlot++;
 
 	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */
 		hipLaunchKernelGGL(k_fold_black, dim3(64, std::min<uint32_t>(work_count, 1024u)), dim3(256), 0, c->stream, *P, Q.tiles, work_count, dev_fb, c->dCounters);
@@ -1751,12 +1789,50 @@ struct Rccl {
 	int (*GroupStart)() = nullptr;
 	int (*GroupEnd)() = nullptr;
 	int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+	int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+	int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
 	std::vector<int> devices;
 	std::vector<ncclComm_t> comms;
 	std::mutex mu;
 } g_rccl;
 const int kNcclFloat32 = 7, kNcclSum = 0;      /* ncclDataType_t / ncclRedOp_t values of rccl.h */
+
+/* librccl + one communicator per device of `devs` (ncclCommInitAll); g_rccl.mu held by the caller. Creating the communicators takes
+ * tens to hundreds of milliseconds: a host calls crh_frames_prepare() beside its scene set-up so that the frame does not pay for it. */
+int rcclReady(const std::vector<int> &devs) {
+	if (!g_rccl.lib) {
+		g_rccl.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!g_rccl.lib) g_rccl.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!g_rccl.lib) return fail(CRH_ERR_HIP, std::string("cannot load librccl: ") + dlerror());
+		g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(g_rccl.lib, "ncclCommInitAll");
+		g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
+		g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
+		g_rccl.Reduce = (decltype(g_rccl.Reduce))dlsym(g_rccl.lib, "ncclReduce");
+		g_rccl.Send = (decltype(g_rccl.Send))dlsym(g_rccl.lib, "ncclSend");
+		g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(g_rccl.lib, "ncclRecv");
+		g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+		if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce) {
+			g_rccl.lib = nullptr;
+			return fail(CRH_ERR_HIP, "librccl lacks the expected symbols");
+		}
+	}
+	if (devs != g_rccl.devices) {
+		g_rccl.comms.assign(devs.size(), nullptr);
+		const int rc = g_rccl.CommInitAll(g_rccl.comms.data(), (int)devs.size(), devs.data());
+		if (rc != 0) { g_rccl.devices.clear(); return fail(CRH_ERR_HIP, std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
+		g_rccl.devices = devs;
+	}
+	return CRH_OK;
+}
+std::string rcclError(const char *what, int rc) { return std::string(what) + ": " + (g_rccl.GetErrorString && rc > 0 ? g_rccl.GetErrorString(rc) : "error"); }
+}
+
+int crh_frames_prepare(const int *devices, int n) {
+	if (!devices || n < 1) return fail(CRH_ERR_INVALID, "crh_frames_prepare: bad argument");
+	if (n == 1 && !getenv("CRH_FORCE_RCCL")) return CRH_OK;
+	std::lock_guard<std::mutex> lock(g_rccl.mu);
+	return rcclReady(std::vector<int>(devices, devices + n));
 }
 
 int crh_frames_reduce(crh_ctx **ctxs, float **fbs, int n, int width, int height) {
@@ -1764,37 +1840,94 @@ int crh_frames_reduce(crh_ctx **ctxs, float **fbs, int n, int width, int height)
 	for (int i = 0; i < n; ++i) if (!ctxs[i] || !fbs[i]) return fail(CRH_ERR_INVALID, "crh_frames_reduce: NULL context or framebuffer");
 	if (n == 1 && !getenv("CRH_FORCE_RCCL")) return CRH_OK;     /* CRH_FORCE_RCCL: run the one-rank reduce through RCCL anyway (tests) */
 	std::lock_guard<std::mutex> lock(g_rccl.mu);
-	if (!g_rccl.lib) {
-		g_rccl.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (!g_rccl.lib) g_rccl.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-		if (!g_rccl.lib) return fail(CRH_ERR_HIP, std::string("crh_frames_reduce: cannot load librccl: ") + dlerror());
-		g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(g_rccl.lib, "ncclCommInitAll");
-		g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
-		g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
-		g_rccl.Reduce = (decltype(g_rccl.Reduce))dlsym(g_rccl.lib, "ncclReduce");
-		g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
-		if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce) {
-			g_rccl.lib = nullptr;
-			return fail(CRH_ERR_HIP, "crh_frames_reduce: librccl lacks the expected symbols");
-		}
-	}
 	std::vector<int> devs(n);
 	for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-	if (devs != g_rccl.devices) {
-		g_rccl.comms.assign(n, nullptr);
-		const int rc = g_rccl.CommInitAll(g_rccl.comms.data(), n, devs.data());
-		if (rc != 0) { g_rccl.devices.clear(); return fail(CRH_ERR_HIP, std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
-		g_rccl.devices = devs;
-	}
+	int rc = rcclReady(devs);                                   /* a no-op after crh_frames_prepare() */
+	if (rc != CRH_OK) return rc;
 	const size_t count = (size_t)width * height * 3;
-	int rc = g_rccl.GroupStart();
+	rc = g_rccl.GroupStart();
 	for (int i = 0; i < n && rc == 0; ++i) {
 		if (hipSetDevice(devs[i]) != hipSuccess) { rc = -1; break; }
 		rc = g_rccl.Reduce(fbs[i], fbs[i], count, kNcclFloat32, kNcclSum, 0, g_rccl.comms[i], ctxs[i]->stream);
 	}
 	const int rcEnd = g_rccl.GroupEnd();
 	if (rc == 0) rc = rcEnd;
-	if (rc != 0) return fail(CRH_ERR_HIP, std::string("ncclReduce: ") + (g_rccl.GetErrorString && rc > 0 ? g_rccl.GetErrorString(rc) : "error"));
+	if (rc != 0) return fail(CRH_ERR_HIP, rcclError("ncclReduce", rc));
+	for (int i = 0; i < n; ++i) {
+		HIP_TRY(hipSetDevice(devs[i]));
+		HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+	}
+	return CRH_OK;
+}
+
+/* The rows of GPU g's strips (host/share.h: strip i = rows [i R, i R + R) counted from the bottom of the image, owned by GPU i mod n), in strip
+ * order, between the float framebuffer (texture.c:24-28: row H - 1 - y) and a dense buffer. dir 0: pack, dir 1: unpack. */
+__global__ void k_strip_rows(float *fb, float *dense, int width, int height, int stripRows, int g, int n, int rows, int dir) {
+	const size_t rowFloats = (size_t)width * 3;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * rowFloats; i += (size_t)gridDim.x * blockDim.x) {
+		const int p = (int)(i / rowFloats);
+		const int y = (g + (p / stripRows) * n) * stripRows + p % stripRows;       /* only the top strip of the image can be ragged, and it is the last one of its owner */
+		if (y >= height) continue;
+		float *at = fb + (size_t)(height - 1 - y) * rowFloats + (i - (size_t)p * rowFloats);
+		if (dir == 0) dense[i] = *at; else *at = dense[i];
+	}
+}
+static int stripRowsOwned(int height, int stripRows, int g, int n) {
+	int rows = 0;
+	for (int y = g * stripRows; y < height; y += n * stripRows) rows += std::min(stripRows, height - y);
+	return rows;
+}
+
+int crh_frames_gather(crh_ctx **ctxs, float **fbs, int n, int width, int height, int strip_rows) {
+	if (!ctxs || !fbs || n < 1 || width <= 0 || height <= 0 || strip_rows < 1) return fail(CRH_ERR_INVALID, "crh_frames_gather: bad argument");
+	for (int i = 0; i < n; ++i) if (!ctxs[i] || !fbs[i]) return fail(CRH_ERR_INVALID, "crh_frames_gather: NULL context or framebuffer");
+	if (n == 1) return CRH_OK;
+	std::lock_guard<std::mutex> lock(g_rccl.mu);
+	std::vector<int> devs(n);
+	for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+	int rc = rcclReady(devs);
+	if (rc != CRH_OK) return rc;
+	if (!g_rccl.Send || !g_rccl.Recv) return fail(CRH_ERR_UNSUPPORTED, "crh_frames_gather: librccl has no ncclSend / ncclRecv");
+	const size_t rowFloats = (size_t)width * 3;
+	/* dense buffers: every sender's own rows on its device; on GPU 0 one slab per sender */
+	std::vector<size_t> rows(n), at(n, 0);
+	size_t total = 0;
+	for (int g = 1; g < n; ++g) { rows[g] = (size_t)stripRowsOwned(height, strip_rows, g, n); at[g] = total; total += rows[g] * rowFloats; }
+	auto room = [](crh_ctx *c, size_t floats) -> int {
+		if (floats <= c->gatherFloats) return CRH_OK;
+		HIP_TRY(hipSetDevice(c->device));
+		if (c->dGather) HIP_TRY(hipFree(c->dGather));
+		c->dGather = nullptr; c->gatherFloats = 0;
+		HIP_TRY(hipMalloc((void **)&c->dGather, std::max<size_t>(floats, 1) * sizeof(float)));
+		c->gatherFloats = floats;
+		return CRH_OK;
+	};
+	if ((rc = room(ctxs[0], total)) != CRH_OK) return rc;
+	for (int g = 1; g < n; ++g) {
+		if ((rc = room(ctxs[g], rows[g] * rowFloats)) != CRH_OK) return rc;
+		if (!rows[g]) continue;
+		HIP_TRY(hipSetDevice(devs[g]));
+		hipLaunchKernelGGL(k_strip_rows, dim3(1024), dim3(256), 0, ctxs[g]->stream, fbs[g], ctxs[g]->dGather, width, height, strip_rows, g, n, (int)rows[g], 0);
+		HIP_TRY(hipGetLastError());
+	}
+	rc = g_rccl.GroupStart();
+	for (int g = 1; g < n && rc == 0; ++g) {
+		if (!rows[g]) continue;
+		if (hipSetDevice(devs[g]) != hipSuccess) { rc = -1; break; }
+		rc = g_rccl.Send(ctxs[g]->dGather, rows[g] * rowFloats, kNcclFloat32, 0, g_rccl.comms[g], ctxs[g]->stream);
+		if (rc != 0) break;
+		if (hipSetDevice(devs[0]) != hipSuccess) { rc = -1; break; }
+		rc = g_rccl.Recv(ctxs[0]->dGather + at[g], rows[g] * rowFloats, kNcclFloat32, g, g_rccl.comms[0], ctxs[0]->stream);
+	}
+	const int rcEnd = g_rccl.GroupEnd();
+	if (rc == 0) rc = rcEnd;
+	if (rc != 0) return fail(CRH_ERR_HIP, rcclError("ncclSend / ncclRecv", rc));
+	HIP_TRY(hipSetDevice(devs[0]));
+	for (int g = 1; g < n; ++g) {
+		if (!rows[g]) continue;
+		hipLaunchKernelGGL(k_strip_rows, dim3(1024), dim3(256), 0, ctxs[0]->stream, fbs[0], ctxs[0]->dGather + at[g], width, height, strip_rows, g, n, (int)rows[g], 1);
+		HIP_TRY(hipGetLastError());
+	}
 	for (int i = 0; i < n; ++i) {
 		HIP_TRY(hipSetDevice(devs[i]));
 		HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));

@@ -9,27 +9,34 @@
  * tile.c, ui.c (SDL2 preview) and the PNG/BMP encoders keep working unmodified.
  *
  * What changes is who consumes the tile queue: instead of N pthread workers running the pixel x pass loop
- * (renderer.c:258-327) there is ONE host thread per GPU. Each flattens nothing itself — the scene is
- * flattened once (flatten.c) — owns a crh_ctx (libcray_hip.so) and renders ITS share of the frame — one GPU: the whole frame as one
- * region; several: every G-th 4-row strip — with ONE crh_render_tiles() dispatch per 512 passes (the
- * persistent kernel balances the work units inside a dispatch itself; a drain per tile batch would idle the GPU). Then
- * the per-GPU float framebuffers (disjoint pixels, zero elsewhere) are summed onto GPU 0 with
- * RCCL over xGMI (crh_frames_reduce), downloaded into state.renderBuffer, and converted to the 8-bit sRGB
- * output with the reference's own colorToSRGB()/setPixel() on the host.
+ * (renderer.c:258-327) there is ONE host thread per GPU. The scene is flattened once (flatten.c) by the main thread WHILE the GPU threads
+ * create their contexts, allocate the per-wave buffers and load the kernels' code objects (crh_context_prepare) and a helper thread
+ * creates the RCCL communicators (crh_frames_prepare): none of that is left inside the frame's timed part. Each GPU thread then uploads the
+ * scene and renders ITS share of the frame — one GPU: the whole frame as one region; several: every G-th 4-row strip — in dispatches of
+ * as many passes as take about a second (the persistent kernel balances the work units inside a dispatch itself; a frame is cut only along the
+ * pass axis, so that the preview window, the abort and the pause key get a turn). Between two dispatches the thread converts its share to
+ * 8-bit sRGB ON THE DEVICE (crh_framebuffer_to_srgb8: colorToSRGB + setPixel's truncation, bit for bit) into `output`, which the main
+ * thread keeps drawing (renderer.c:294-300 wrote it per sample). At the end the GPUs' strips are gathered onto GPU 0 with RCCL over xGMI
+ * (crh_frames_gather: 1/G of the frame per link; CRH_FRAMES=reduce selects the one-ncclReduce form), the 8-bit frame and the float buffer
+ * come back with one download each.
  *
  * --iterative (renderThreadInteractive, renderer.c:184-250): passes 1 .. sampleCount-1 with the Halton sampler, the frame
- * shown while it converges. Here the main thread drives every GPU pass-chunk by pass-chunk (every G-th 4-row strip belongs to
- * one GPU for the whole frame, so each pixel's running mean stays on one GPU), gathers the strips on the host after each chunk and redraws.
- * The result is the reference's single-thread result: with several threads the reference itself races on
- * state.finishedPasses and is not reproducible.
+ * shown while it converges. Here the main thread drives every GPU (every G-th 4-row strip belongs to one GPU for the whole frame, so each
+ * pixel's running mean stays on one GPU) in dispatches of as many passes as take about 16 ms, converts to 8-bit on the device after each
+ * and redraws; the float buffer is gathered once, at the end. The result is the reference's single-thread result: with several threads the
+ * reference itself races on state.finishedPasses and is not reproducible.
  *
- * Environment: CRAY_HIP_DEVICES=<n> caps the number of GPUs used; CRH_DUMP_F32=<path> dumps the float buffer.
+ * Environment: CRAY_HIP_DEVICES=<n> caps the number of GPUs used; CRH_DUMP_F32=<path> dumps the float buffer; CRH_DUMP_STATS=<path>
+ * writes where the frame's time went; CRH_FRAMES=reduce: see above.
  * No GPU => logr(error, ...) (which exits, src/utils/logging.c:69-73): there is no CPU fallback in this file.
  */
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdbool.h>
+#include <pthread.h>
+#include <errno.h>
+#include <time.h>
 
 #include "includes.h"
 #include "datatypes/image/imagefile.h"
@@ -52,24 +59,40 @@
 
 #define MAX_GPUS 16
 
+/* what the main thread and the GPU threads tell each other: "the scene is flattened" (main -> GPUs), "a GPU thread has finished" (GPUs -> main) */
+struct frameSync {
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	int sceneReady;          /* 1: flattened, -1: the flattener failed */
+	int finished;
+};
+
 struct gpuWorker {
 	struct renderer *r;
 	struct renderThreadState *state;
 	const crh_scene_desc *scene;
+	struct frameSync *sync;
+	struct texture *output;
+	struct timeval frameStart;   /* renderFrame() entry */
 	crh_ctx *ctx;
 	float *fb;
 	int device;
 	int failed;
 	char error[256];      /* crh_last_error() is per thread: the failing dispatch thread keeps its message here */
 	uint64_t rays;
-	long setupUs, renderUs;   /* context + upload + framebuffer; dispatch loop (first launch to last sync) */
+	long contextUs, uploadUs, renderUs;   /* context + buffers + code objects (beside the flattener); scene upload + framebuffer; dispatch loop (first launch to last sync) */
+	long readyUs;             /* renderFrame() entry -> this GPU ready to dispatch */
 	double kernelMs;          /* GPU time of the dispatches (HIP events around the kernels) */
 	long launchUs;            /* host time inside crh_render_tiles (work list, copies, launch) */
+	int dispatches;
 };
 
-/* passes per dispatch: one dispatch keeps the whole GPU busy from its first work unit to its last (no drain in between), so a
- * frame is cut only along the pass axis, and only when it is long enough that the preview window / abort key should get a turn */
-#define PASSES_PER_DISPATCH 512
+/* A dispatch keeps the whole GPU busy from its first work unit to its last (no drain in between), so a frame is cut only along the pass
+ * axis, and only when it is long: the first dispatch takes as many passes as make FIRST_DISPATCH_PATHS paths (the bench frame: all 256),
+ * the following ones as many as took about DISPATCH_TARGET_MS at the measured rate — the preview, the abort and the pause key wait no
+ * longer than that. */
+#define FIRST_DISPATCH_PATHS (256ull << 20)
+#define DISPATCH_TARGET_MS 1000.0
 
 /* The share of GPU g of G: G == 1 -> the whole frame; G > 1 -> every G-th 4-row strip
  * (static shares must be balanced, and dealing out the tile list is not: DESIGN.md section 6). Returns the tile count. */
@@ -89,6 +112,29 @@ static uint32_t gpuShare(const struct renderer *r, int g, int G, crh_tile **out)
 	return crh_strip_share(W, H, g, G, t);
 }
 
+/* renderer.c:294-300 for this GPU's share: colorToSRGB + setPixel's truncation on the device, then its rows into `output` (texture.c:18-22
+ * layout, the float buffer's). scratch (G > 1): a frame-sized byte buffer of this thread. */
+static int refreshOutput(crh_ctx *ctx, const float *fb, int W, int H, struct texture *output, const crh_tile *share, uint32_t n, int G, unsigned char *scratch) {
+	if (G == 1) return crh_framebuffer_to_srgb8(ctx, fb, W, H, output->data.byte_p);
+	const int rc = crh_framebuffer_to_srgb8(ctx, fb, W, H, scratch);
+	if (rc != CRH_OK) return rc;
+	for (uint32_t t = 0; t < n; ++t)
+		for (int y = share[t].y0; y < share[t].y1; ++y) {
+			const size_t row = ((size_t)(H - (y + 1)) * W + (size_t)share[t].x0) * 3;
+			memcpy(output->data.byte_p + row, scratch + row, 3 * (size_t)(share[t].x1 - share[t].x0));
+		}
+	return CRH_OK;
+}
+
+static void gpuThreadDone(struct gpuWorker *w) {
+	w->state->currentTileNum = -1;
+	w->state->threadComplete = true;
+	pthread_mutex_lock(&w->sync->mu);
+	w->sync->finished++;
+	pthread_cond_broadcast(&w->sync->cv);
+	pthread_mutex_unlock(&w->sync->mu);
+}
+
 static void *gpuThread(void *arg) {
 	struct gpuWorker *w = threadUserData(arg);
 	struct renderer *r = w->r;
@@ -102,27 +148,43 @@ static void *gpuThread(void *arg) {
 	struct timeval phase;
 	startTimer(&phase);
 
-	/* counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
-	if (crh_context_create(w->device, NULL, &w->ctx) != CRH_OK || crh_set_option(w->ctx, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK ||
-		crh_scene_upload(w->ctx, w->scene) != CRH_OK || crh_framebuffer_alloc(w->ctx, W, H, &w->fb) != CRH_OK ||
-		crh_synchronize(w->ctx) != CRH_OK) {           /* the scene copies are asynchronous: they belong to the setup, not to the first dispatch */
+	/* beside the flattener: the context, the per-wave buffers, the code objects.
+	 * counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
+	int ok = crh_context_create(w->device, NULL, &w->ctx) == CRH_OK && crh_set_option(w->ctx, CRH_OPT_COUNTER_LEVEL, 1) == CRH_OK &&
+			 crh_context_prepare(w->ctx) == CRH_OK && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
+	if (!ok) snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
+	w->contextUs = getUs(phase);
+	pthread_mutex_lock(&w->sync->mu);
+	while (!w->sync->sceneReady) pthread_cond_wait(&w->sync->cv, &w->sync->mu);
+	const int sceneOk = w->sync->sceneReady > 0;
+	pthread_mutex_unlock(&w->sync->mu);
+	startTimer(&phase);
+	if (ok && sceneOk && (crh_scene_upload(w->ctx, w->scene) != CRH_OK ||
+		crh_synchronize(w->ctx) != CRH_OK)) {           /* the scene copies are asynchronous: they belong to the setup, not to the first dispatch */
 		snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
-		logr(warning, "GPU %d: %s\n", w->device, w->error);
+		ok = 0;
+	}
+	if (!ok || !sceneOk) {
+		if (!ok) logr(warning, "GPU %d: %s\n", w->device, w->error);
 		w->failed = 1;
-		w->state->threadComplete = true;
+		gpuThreadDone(w);
 		return NULL;
 	}
 	crh_tile *share = NULL;
 	const uint32_t n = gpuShare(r, w->device, G, &share);
 	uint64_t pixels = 0;
 	for (uint32_t i = 0; i < n; ++i) pixels += (uint64_t)(share[i].x1 - share[i].x0) * (uint64_t)(share[i].y1 - share[i].y0);
-	if (G == 1) for (int i = 0; i < r->state.tileCount; ++i) r->state.renderTiles[i].isRendering = true;
+	unsigned char *scratch = G > 1 ? malloc((size_t)W * H * 3) : NULL;
 	w->state->currentTileNum = 0;
-	w->setupUs = getUs(phase);
+	w->uploadUs = getUs(phase);
+	w->readyUs = getUs(w->frameStart);
 	startTimer(&phase);
+	int passes = r->prefs.sampleCount;
+	if (pixels && (uint64_t)passes * pixels > FIRST_DISPATCH_PATHS) passes = (int)(FIRST_DISPATCH_PATHS / pixels);
+	if (passes < 1) passes = 1;
 	for (int done = 0; done < r->prefs.sampleCount && r->state.isRendering && !r->state.renderAborted; ) {
 		p.first_pass = done;
-		p.pass_count = r->prefs.sampleCount - done < PASSES_PER_DISPATCH ? r->prefs.sampleCount - done : PASSES_PER_DISPATCH;
+		p.pass_count = r->prefs.sampleCount - done < passes ? r->prefs.sampleCount - done : passes;
 		struct timeval tl;
 		startTimer(&tl);
 		int rc = n ? crh_render_tiles(w->ctx, &p, share, n, w->fb) : CRH_OK;
@@ -133,29 +195,47 @@ static void *gpuThread(void *arg) {
 			w->failed = 1;
 			break;
 		}
+		const long us = getUs(tl);
+		w->dispatches++;
 		done += p.pass_count;
 		w->state->completedSamples = done;
 		w->state->totalSamples = pixels * (uint64_t)done;
+		if (done < r->prefs.sampleCount) {
+			/* more to come: show what there is, and size the next dispatch by what this one cost */
+			if (n && refreshOutput(w->ctx, w->fb, W, H, w->output, share, n, G, scratch) != CRH_OK) logr(warning, "GPU %d: preview: %s\n", w->device, crh_last_error());
+			const double msPerPass = (double)us / 1e3 / (double)p.pass_count;
+			passes = msPerPass > 0.0 ? (int)(DISPATCH_TARGET_MS / msPerPass) : passes;
+			if (passes < 1) passes = 1;
+		}
 		while (w->state->paused && !r->state.renderAborted) sleepMSec(100);
 	}
 	w->renderUs = getUs(phase);
-	if (G == 1 && !w->failed && !r->state.renderAborted)
-		for (int i = 0; i < r->state.tileCount; ++i) { r->state.renderTiles[i].isRendering = false; r->state.renderTiles[i].renderComplete = true; }
 	crh_counters c;
 	if (!w->failed && crh_counters_get(w->ctx, &c) == CRH_OK) w->rays = c.rays;
 	{ float last = 0.0f; uint64_t launches = 0; if (!w->failed) crh_kernel_time_ms(w->ctx, &last, &w->kernelMs, &launches); }
 	free(share);
-	w->state->currentTileNum = -1;
-	w->state->threadComplete = true;
+	free(scratch);
+	gpuThreadDone(w);
 	return NULL;
 }
 
-/* renderer.c:294-300 for the whole frame: colorToSRGB + setPixel truncation on the host */
-static void resolveOutput(struct renderer *r, struct texture *output) {
-	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
-	for (int y = 0; y < H; ++y)
-		for (int x = 0; x < W; ++x)
-			setPixel(output, colorToSRGB(textureGetPixel(r->state.renderBuffer, x, y, false)), x, y);
+struct commWarm { int devices[MAX_GPUS]; int n; int rc; long us; };
+static void *commThread(void *arg) {
+	struct commWarm *cw = threadUserData(arg);
+	struct timeval t;
+	startTimer(&t);
+	cw->rc = crh_frames_prepare(cw->devices, cw->n);
+	cw->us = getUs(t);
+	return NULL;
+}
+
+/* the G per-GPU framebuffers -> GPU 0's: the strips (1 / G of the frame per link), or — CRH_FRAMES=reduce, or a librccl without send / receive — one ncclReduce */
+static void assembleFrame(crh_ctx **ctxs, float **fbs, int gpus, int W, int H) {
+	if (gpus < 2) return;
+	const char *how = getenv("CRH_FRAMES");
+	int rc = (how && !strcmp(how, "reduce")) ? CRH_ERR_UNSUPPORTED : crh_frames_gather(ctxs, fbs, gpus, W, H, CRH_STRIP_ROWS);
+	if (rc == CRH_ERR_UNSUPPORTED) rc = crh_frames_reduce(ctxs, fbs, gpus, W, H);
+	if (rc != CRH_OK) logr(error, "c-ray-hip: assembling the frame on GPU 0 failed: %s\n", crh_last_error());
 }
 
 /* --iterative: returns the rays traced, fills state.renderBuffer and output */
@@ -165,7 +245,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	float *fb[MAX_GPUS];
 	crh_tile *tiles[MAX_GPUS];
 	uint32_t ntiles[MAX_GPUS];
-	float *gather = malloc(sizeof(float) * (size_t)W * H * 3);
+	unsigned char *scratch = gpus > 1 ? malloc((size_t)W * H * 3) : NULL;
 	for (int g = 0; g < gpus; ++g) {
 		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
 			crh_set_option(ctx[g], CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
@@ -178,34 +258,36 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	memset(&p, 0, sizeof(p));
 	p.image_width = W; p.image_height = H; p.max_passes = r->prefs.sampleCount; p.bounces = r->prefs.bounces;
 	int done = 0;
+	int chunk = 1;                                           /* the first preview after one pass; then as many passes per dispatch as take about a display refresh */
 	while (done < passes && !r->state.renderAborted) {
-		const int chunk = done < 8 ? 1 : (passes - done < 8 ? passes - done : 8);      /* first previews quickly, then fewer round trips */
+		if (chunk > passes - done) chunk = passes - done;
 		p.first_pass = done; p.pass_count = chunk;
+		struct timeval tc;
+		startTimer(&tc);
 		for (int g = 0; g < gpus; ++g)
 			if (ntiles[g] && crh_render_tiles(ctx[g], &p, tiles[g], ntiles[g], fb[g]) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+		/* the 8-bit frame of this chunk, converted where the float buffer lives (stream order: after the chunk's kernel) */
 		for (int g = 0; g < gpus; ++g)
-			if (crh_synchronize(ctx[g]) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+			if (ntiles[g] && refreshOutput(ctx[g], fb[g], W, H, output, tiles[g], ntiles[g], gpus, scratch) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+		const double chunkMs = (double)getUs(tc) / 1e3;
 		done += chunk;
 		r->state.finishedPasses = done + 1;
-		for (int g = 0; g < gpus; ++g) {                      /* gather: every tile from the GPU that owns it */
+		for (int g = 0; g < gpus; ++g) {
 			r->state.threadStates[g].completedSamples = done;
 			r->state.threadStates[g].totalSamples += (uint64_t)chunk;
-			float *dst = r->state.renderBuffer->data.float_p;
-			const float *src = gather;
-			if (gpus == 1) dst = r->state.renderBuffer->data.float_p, src = NULL;
-			if (crh_framebuffer_download(ctx[g], fb[g], W, H, gpus == 1 ? dst : gather) != CRH_OK) logr(error, "c-ray-hip: download: %s\n", crh_last_error());
-			if (!src) continue;
-			for (uint32_t t = 0; t < ntiles[g]; ++t)
-				for (int y = tiles[g][t].y0; y < tiles[g][t].y1; ++y) {
-					const size_t row = ((size_t)(H - (y + 1)) * W + (size_t)tiles[g][t].x0) * 3;      /* texture.c:24-28 row order */
-					memcpy(dst + row, src + row, sizeof(float) * 3 * (size_t)(tiles[g][t].x1 - tiles[g][t].x0));
-				}
 		}
-		resolveOutput(r, output);
 		getKeyboardInput(r);
 		drawWindow(r, output);
 		while (r->state.threadStates[0].paused && !r->state.renderAborted) { getKeyboardInput(r); sleepMSec(100); }
+		/* ~16 ms of GPU work between two redraws: the host side of a chunk (launch, 8-bit download, redraw) stays a small part of it */
+		const double msPerPass = chunkMs / (double)chunk;
+		int next = msPerPass > 0.0 ? (int)(16.0 / msPerPass) : chunk;
+		if (next > 2 * chunk) next = 2 * chunk;              /* grow gently: the first passes' previews are the ones a user watches */
+		chunk = next < 1 ? 1 : (next > 256 ? 256 : next);
 	}
+	/* the float buffer: once, at the end */
+	assembleFrame(ctx, fb, gpus, W, H);
+	if (crh_framebuffer_download(ctx[0], fb[0], W, H, r->state.renderBuffer->data.float_p) != CRH_OK) logr(error, "c-ray-hip: download: %s\n", crh_last_error());
 	uint64_t rays = 0;
 	for (int g = 0; g < gpus; ++g) {
 		crh_counters c;
@@ -215,12 +297,14 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 		free(tiles[g]);
 		r->state.threadStates[g].threadComplete = true;
 	}
-	free(gather);
+	free(scratch);
 	return rays;
 }
 
 struct texture *renderFrame(struct renderer *r) {
 	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	struct timeval frame;
+	startTimer(&frame);
 	struct texture *output = newTexture(char_p, r->prefs.imageWidth, r->prefs.imageHeight, 3);
 
 	int gpus = crh_device_count();
@@ -232,23 +316,31 @@ struct texture *renderFrame(struct renderer *r) {
 	logr(info, "Starting C-ray MI355X renderer for frame %i\n", r->prefs.imgCount);
 	logr(info, "Rendering at %i x %i, %i samples, %i bounces on %i GPU%s.\n", W, H, r->prefs.sampleCount, r->prefs.bounces, gpus, PLURAL(gpus));
 
-	crh_scene_desc scene;
-	struct timeval phase;
-	startTimer(&phase);
-	const int frc = crh_flatten_world(r, &scene);
-	const long flattenUs = getUs(phase);
-	if (frc != CRH_OK) logr(error, "c-ray-hip: the scene cannot be flattened for the GPU (%i)\n", frc);
-
 	r->state.isRendering = true;
 	r->state.renderAborted = false;
 	r->state.saveImage = true;
 	r->prefs.threadCount = gpus;              /* ui.c indexes threadStates[0..threadCount) */
 	r->state.threads = calloc((size_t)gpus, sizeof(*r->state.threads));
 	r->state.threadStates = calloc((size_t)gpus, sizeof(*r->state.threadStates));
+
+	/* the RCCL communicators of a multi-GPU frame: created beside everything else, not inside the frame's gather */
+	struct commWarm warm = {.n = gpus};
+	struct crThread warmThread = {.threadFunc = commThread, .userData = &warm};
+	bool warming = false;
+	if (gpus > 1) {
+		for (int g = 0; g < gpus; ++g) warm.devices[g] = g;
+		warming = threadStart(&warmThread) == 0;
+	}
+
+	crh_scene_desc scene;
+	struct timeval phase;
 	if (isSet("interactive")) {
+		startTimer(&phase);
+		if (crh_flatten_world(r, &scene) != CRH_OK) logr(error, "c-ray-hip: the scene cannot be flattened for the GPU\n");
 		logr(info, "Pathtracing iteratively...\n");
 		for (int g = 0; g < gpus; ++g)
 			r->state.threadStates[g] = (struct renderThreadState){.thread_num = g, .renderer = r, .output = output, .currentTileNum = -1};
+		if (warming) threadWait(&warmThread);
 		const uint64_t rays = renderInteractive(r, output, &scene, gpus);
 		r->state.isRendering = false;
 		const char *dumpi = getenv("CRH_DUMP_F32");
@@ -260,68 +352,104 @@ struct texture *renderFrame(struct renderer *r) {
 		crh_flatten_free(&scene);
 		return output;
 	}
+	struct frameSync sync;
+	pthread_mutex_init(&sync.mu, NULL);
+	pthread_cond_init(&sync.cv, NULL);
+	sync.sceneReady = 0; sync.finished = 0;
 	struct gpuWorker workers[MAX_GPUS];
 	memset(workers, 0, sizeof(workers));
+	for (int i = 0; i < r->state.tileCount; ++i) r->state.renderTiles[i].isRendering = true;      /* every GPU works on the whole frame (strips): all tiles are "being rendered" until the frame is done */
 	for (int g = 0; g < gpus; ++g) {
 		r->state.threadStates[g] = (struct renderThreadState){.thread_num = g, .renderer = r, .output = output, .currentTileNum = -1};
-		workers[g] = (struct gpuWorker){.r = r, .state = &r->state.threadStates[g], .scene = &scene, .device = g};
+		workers[g] = (struct gpuWorker){.r = r, .state = &r->state.threadStates[g], .scene = &scene, .device = g, .sync = &sync, .output = output, .frameStart = frame};
 		r->state.threads[g] = (struct crThread){.threadFunc = gpuThread, .userData = &workers[g]};
 		if (threadStart(&r->state.threads[g])) logr(error, "Failed to create the dispatch thread of GPU %i.\n", g);
 		r->state.activeThreads++;
 	}
+	/* main thread: flatten the scene while the GPU threads set themselves up */
+	startTimer(&phase);
+	const int frc = crh_flatten_world(r, &scene);
+	const long flattenUs = getUs(phase);
+	pthread_mutex_lock(&sync.mu);
+	sync.sceneReady = frc == CRH_OK ? 1 : -1;
+	pthread_cond_broadcast(&sync.cv);
+	pthread_mutex_unlock(&sync.mu);
 
-	/* main thread: keep the preview window / key handling alive while the GPUs work (ui.c contract) */
+	/* main thread: keep the preview window / key handling alive while the GPUs work (ui.c contract); a finishing GPU thread wakes it at once */
 	for (;;) {
-		int done = 0;
-		for (int g = 0; g < gpus; ++g) done += r->state.threadStates[g].threadComplete ? 1 : 0;
-		if (done == gpus) break;
+		pthread_mutex_lock(&sync.mu);
+		if (sync.finished < gpus) {
+			struct timespec until;
+			clock_gettime(CLOCK_REALTIME, &until);
+			until.tv_nsec += (r->state.renderAborted ? 1 : 16) * 1000000L;
+			if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+			pthread_cond_timedwait(&sync.cv, &sync.mu, &until);
+		}
+		const int finished = sync.finished;
+		pthread_mutex_unlock(&sync.mu);
+		if (finished == gpus) break;
 		getKeyboardInput(r);
 		drawWindow(r, output);
-		sleepMSec(r->state.renderAborted ? 1 : 4);
 	}
 	for (int g = 0; g < gpus; ++g) threadWait(&r->state.threads[g]);
+	if (warming) threadWait(&warmThread);
 	r->state.activeThreads = 0;
 	r->state.isRendering = false;
+	if (frc != CRH_OK) logr(error, "c-ray-hip: the scene cannot be flattened for the GPU (%i)\n", frc);
 
 	int failed = 0;
 	uint64_t rays = 0;
 	const char *firstError = "";
 	for (int g = gpus - 1; g >= 0; --g) { failed += workers[g].failed; rays += workers[g].rays; if (workers[g].failed) firstError = workers[g].error; }
 	if (failed) logr(error, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), firstError);
+	if (warming && warm.rc != CRH_OK) logr(warning, "c-ray-hip: RCCL set-up beside the frame failed; the gather will retry\n");
+	if (!r->state.renderAborted)
+		for (int i = 0; i < r->state.tileCount; ++i) { r->state.renderTiles[i].isRendering = false; r->state.renderTiles[i].renderComplete = true; }
 
 	startTimer(&phase);
-	/* assemble the frame on GPU 0 (RCCL reduce over xGMI; tiles are disjoint so the sum is a gather) */
-	if (gpus > 1) {
-		crh_ctx *ctxs[MAX_GPUS];
-		float *fbs[MAX_GPUS];
-		for (int g = 0; g < gpus; ++g) { ctxs[g] = workers[g].ctx; fbs[g] = workers[g].fb; }
-		if (crh_frames_reduce(ctxs, fbs, gpus, W, H) != CRH_OK) logr(error, "c-ray-hip: framebuffer reduce failed: %s\n", crh_last_error());
-	}
-	struct texture *buf = r->state.renderBuffer;
-	if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
-		logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
-
+	/* assemble the frame on GPU 0 (RCCL over xGMI; the shares are disjoint) */
+	crh_ctx *ctxs[MAX_GPUS];
+	float *fbs[MAX_GPUS];
+	for (int g = 0; g < gpus; ++g) { ctxs[g] = workers[g].ctx; fbs[g] = workers[g].fb; }
+	assembleFrame(ctxs, fbs, gpus, W, H);
 	const long gatherUs = getUs(phase);
 	startTimer(&phase);
-	resolveOutput(r, output);      /* 8-bit output exactly like renderer.c:294-300 */
+	/* 8-bit output exactly like renderer.c:294-300 — on the device — and the float buffer: one download each */
+	struct texture *buf = r->state.renderBuffer;
+	if (crh_framebuffer_to_srgb8(workers[0].ctx, workers[0].fb, W, H, output->data.byte_p) != CRH_OK)
+		logr(error, "c-ray-hip: sRGB conversion failed: %s\n", crh_last_error());
 	const long resolveUs = getUs(phase);
-	/* CRH_DUMP_STATS=<path>: where the render phase (src/c-ray.c:279-281) went, for bench.py's `dropin` object */
+	startTimer(&phase);
+	if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
+		logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
+	const long downloadUs = getUs(phase);
+	const long frameUs = getUs(frame);
+	/* CRH_DUMP_STATS=<path>: where the frame went, for bench.py's `dropin` object. render_phase_ms is SURVEY.md 8(d)'s phase — the timer
+	 * of src/c-ray.c:279-281 around renderFrame() minus the set-up (flatten / context / upload: everything before the slowest GPU was ready
+	 * to dispatch): dispatches + gather + 8-bit conversion + downloads + the host in between. */
 	const char *statsPath = getenv("CRH_DUMP_STATS");
 	if (statsPath) {
-		long setupUs = 0, renderUs = 0, launchUs = 0;
+		long contextUs = 0, uploadUs = 0, renderUs = 0, launchUs = 0, readyUs = 0;
 		double kernelMs = 0.0;
+		int dispatches = 0;
 		for (int g = 0; g < gpus; ++g) {
-			if (workers[g].setupUs > setupUs) setupUs = workers[g].setupUs;
+			if (workers[g].contextUs > contextUs) contextUs = workers[g].contextUs;
+			if (workers[g].uploadUs > uploadUs) uploadUs = workers[g].uploadUs;
+			if (workers[g].readyUs > readyUs) readyUs = workers[g].readyUs;
 			if (workers[g].renderUs > renderUs) renderUs = workers[g].renderUs;
 			if (workers[g].launchUs > launchUs) launchUs = workers[g].launchUs;
 			if (workers[g].kernelMs > kernelMs) kernelMs = workers[g].kernelMs;
+			if (workers[g].dispatches > dispatches) dispatches = workers[g].dispatches;
 		}
 		FILE *f = fopen(statsPath, "w");
 		if (f) {
 			fprintf(f, "{\"gpus\": %d, \"width\": %d, \"height\": %d, \"samples\": %d, \"bounces\": %d, \"rays\": %llu, \"flatten_ms\": %.3f, "
-					"\"context_upload_ms\": %.3f, \"render_ms\": %.3f, \"kernel_ms\": %.3f, \"launch_host_ms\": %.3f, \"reduce_download_ms\": %.3f, \"resolve_srgb_ms\": %.3f}\n",
-					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, setupUs / 1e3, renderUs / 1e3,
-					kernelMs, launchUs / 1e3, gatherUs / 1e3, resolveUs / 1e3);
+					"\"context_ms\": %.3f, \"upload_ms\": %.3f, \"context_upload_ms\": %.3f, \"setup_ms\": %.3f, \"render_ms\": %.3f, \"kernel_ms\": %.3f, \"launch_host_ms\": %.3f, "
+					"\"dispatches\": %d, \"reduce_download_ms\": %.3f, \"gather_ms\": %.3f, \"resolve_srgb_ms\": %.3f, \"download_ms\": %.3f, \"rccl_setup_ms\": %.3f, "
+					"\"frame_ms\": %.3f, \"render_phase_ms\": %.3f}\n",
+					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, contextUs / 1e3, uploadUs / 1e3,
+					(contextUs + uploadUs) / 1e3, readyUs / 1e3, renderUs / 1e3, kernelMs, launchUs / 1e3, dispatches, (gatherUs + downloadUs) / 1e3, gatherUs / 1e3,
+					resolveUs / 1e3, downloadUs / 1e3, warm.us / 1e3, frameUs / 1e3, (frameUs - readyUs) / 1e3);
 			fclose(f);
 		}
 	}
@@ -337,6 +465,8 @@ struct texture *renderFrame(struct renderer *r) {
 		crh_framebuffer_free(workers[g].ctx, workers[g].fb);
 		crh_context_destroy(workers[g].ctx);
 	}
+	pthread_mutex_destroy(&sync.mu);
+	pthread_cond_destroy(&sync.cv);
 	crh_flatten_free(&scene);
 	return output;
 }

@@ -3,8 +3,9 @@
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm). Every rank holds a
 replica of the flattened scene, takes its share of the frame — every world-th 4-row strip (owned_tiles below; one
 rank: the whole frame as one region) — and renders it with ONE crh_render_tiles dispatch into a zeroed float
-framebuffer; a single reduce(SUM) to rank 0 then assembles the frame — pixels a rank does not own are
-exactly 0.0f, so the sum is a gather and the result is bit-identical to the 1-GPU frame.
+framebuffer; rank 0 then assembles the frame: either a single reduce(SUM) — pixels a rank does not own are
+exactly 0.0f, so the sum is a gather — or (default) a gather of the owned strips only, 1 / world of the bytes
+(StripGather). Both give the 1-GPU frame bit for bit.
 PyTorch is used for device memory, the stream and the collective only; all rendering is behind the C-ABI.
 """
 from . import tiles as tiles_mod
@@ -35,6 +36,41 @@ def reduce_frame(fb, world, dist=None, dst=0):
     return fb
 
 
+def strip_rows(height, rank, world):
+    """Framebuffer rows (texture.c:24-28: row H - 1 - y) of the strips `rank` owns, in strip order — the rows crh_frames_gather packs (C host)."""
+    rows = []
+    for y0 in range(rank * STRIP_ROWS, height, world * STRIP_ROWS):
+        rows.extend(height - 1 - y for y in range(y0, min(y0 + STRIP_ROWS, height)))
+    return rows
+
+
+class StripGather:
+    """The frame with 1 / world of the bytes on the links: every rank packs the rows of ITS strips (one index_select), one gather brings
+    them to `dst` (RCCL: grouped send / receive, the peers' xGMI links in parallel), `dst` writes them into its framebuffer (index_copy_).
+    Bit-identical to reduce_frame for strip shares: a sum with 0.0f changes nothing. Torch is plumbing here: copies and the collective."""
+
+    def __init__(self, torch, width, height, rank, world, device, dst=0):
+        self.torch, self.rank, self.world, self.dst = torch, rank, world, dst
+        self.rows = [torch.tensor(strip_rows(height, r, world), dtype=torch.long, device=device) for r in (range(world) if rank == dst else [rank])]
+        self.mine = self.rows[rank] if rank == dst else self.rows[0]
+        most = (height + STRIP_ROWS - 1) // STRIP_ROWS            # strips in the frame
+        most = ((most + world - 1) // world) * STRIP_ROWS          # rows of the rank with the most strips: gather wants equal shapes
+        self.pack = torch.zeros((most, width * 3), dtype=torch.float32, device=device)
+        self.recv = [torch.empty_like(self.pack) for _ in range(world)] if rank == dst else None
+
+    def __call__(self, fb, dist):
+        flat = fb.view(fb.shape[0], -1)
+        n = self.mine.numel()
+        if n:
+            self.torch.index_select(flat, 0, self.mine, out=self.pack[:n])
+        dist.gather(self.pack, self.recv, dst=self.dst)
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.dst and self.rows[r].numel():
+                    flat.index_copy_(0, self.rows[r], self.recv[r][:self.rows[r].numel()])
+        return fb
+
+
 class FrameRenderer:
     """renderFrame() for one GPU rank: scene replica + float framebuffer (a torch CUDA tensor) + dispatch."""
 
@@ -55,6 +91,7 @@ class FrameRenderer:
         with torch.cuda.stream(self.stream):
             self.fb = torch.zeros((self.height, self.width, 3), dtype=torch.float32, device=self.device)
         self.tiles = owned_tiles(self.width, self.height, tile[0], tile[1], order, rank, world)
+        self.gather = StripGather(torch, self.width, self.height, rank, world, self.device) if world > 1 else None
 
     def render(self, samples, bounces, clear=True):
         """Enqueue this rank's tiles (asynchronous on the stream)."""
@@ -64,8 +101,11 @@ class FrameRenderer:
             if self.tiles:
                 self.ctx.render_tiles(self.fb.data_ptr(), self.width, self.height, samples, bounces, self.tiles)
 
-    def reduce(self, dist=None):
+    def reduce(self, dist=None, how="gather"):
+        """Assemble the frame on rank 0: how = "gather" (the owned strips only, 1 / world of the bytes) or "reduce" (one reduce(SUM) of the whole buffer)."""
         with self.torch.cuda.stream(self.stream):
+            if self.world > 1 and how == "gather":
+                return self.gather(self.fb, dist)
             return reduce_frame(self.fb, self.world, dist)
 
     def close(self):

@@ -256,6 +256,10 @@ int crh_abi_version(void);
  * stream) or an existing hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream). */
 int crh_context_create(int device, void *stream, crh_ctx **out);
 int crh_context_destroy(crh_ctx *ctx);
+/* Optional: the part of crh_scene_upload that does not need the scene — the per-wave buffers of a full-size dispatch and the code objects
+ * of the kernel the options set so far select (HIP loads kernels lazily). A host calls it after crh_set_option and before its scene is
+ * flattened, on the context's own thread, so that this work overlaps the flattening (renderer_hip.c); crh_scene_upload then skips it. */
+int crh_context_prepare(crh_ctx *ctx);
 
 /* Per-context knobs. */
 #define CRH_OPT_COUNTER_LEVEL 1   /* 2 (default): every crh_counters field; 1: paths + rays only (timed runs)      */
@@ -268,8 +272,8 @@ int crh_context_destroy(crh_ctx *ctx);
                                    * | n<<12: a node / triangle run continues while n/8 of its lanes still want that step (default 4)
                                    * | m<<16: inside a node run, triangles are tested as soon as m lanes wait for them (default 12; 65 = never)
                                    * | k<<24: likewise instance entries / sphere tests (control steps), as soon as k lanes wait (default 12; 65 = never)
-                                   * | s<<32: surface hits are shaded in batches of one shade class (instances whose hits run the same shading code);
-                                   *          a batch starts once s hits of one class wait (1..128, default 64; 0 = keep), or 128 hits in all */
+                                   * | s<<32: a shading step starts once 64 hits wait; in scenes with four or more shade classes (instances whose hits run
+                                   *          the same shading code) it takes whole classes, largest first, until at least s lanes are busy (1..128, default 48; 0 = keep) */
 #define CRH_OPT_UNITS_PER_WAVE 8  /* shrink the pixel blocks until every wave gets at least this many work units (default 8) */
 #define CRH_OPT_SAMPLER       9   /* which sampler seeds a (pixel, pass): CRH_SAMPLER_RANDOM = renderThread (sampler.c:41-44, default),
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */
@@ -330,6 +334,14 @@ int crh_render_tiles(crh_ctx *ctx, const crh_render_params *params, const crh_ti
  * a gather. Replaces the TCP submitWork of 8-bit tiles (src/utils/protocol/worker.c:128-136, server.c:159-174).
  * librccl is loaded on first use; n == 1 is a no-op. (Python hosts use torch.distributed instead: render.py.) */
 int crh_frames_reduce(crh_ctx **ctxs, float **dev_fbs, int n, int width, int height);
+/* The same frame with 1/n of the bytes on the links: GPU g owns the strips g, g + n, ... of strip_rows pixel rows (host/share.h; render.py:
+ * owned_tiles), so it packs exactly those rows, sends them to GPU 0 with ONE ncclSend (GPU 0: one ncclRecv per peer, all in one group — the
+ * peers' xGMI links work in parallel), and GPU 0 writes them into its framebuffer. Bit-identical to crh_frames_reduce for strip shares
+ * (adding 0.0f changes nothing); CRH_ERR_UNSUPPORTED if the librccl found has no send / receive. */
+int crh_frames_gather(crh_ctx **ctxs, float **dev_fbs, int n, int width, int height, int strip_rows);
+/* Load librccl and create the communicators of these devices now (ncclCommInitAll: tens to hundreds of milliseconds) — from any thread,
+ * before or while the contexts are being created — so that the frame's first reduce / gather does not pay for it. Optional. */
+int crh_frames_prepare(const int *devices, int n);
 /* Block until everything queued on the context's stream has finished. */
 int crh_synchronize(crh_ctx *ctx);
 

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, blob, w, h, spp, bounces, out_path):
+def _worker(rank, world, port, blob, w, h, spp, bounces, out_path, how="reduce"):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import torch
@@ -37,7 +37,10 @@ def _worker(rank, world, port, blob, w, h, spp, bounces, out_path):
     for t in mine:
         oracle_py.render(scene, w, h, spp, bounces, region=t, fb=fb, threads=2)
     tfb = torch.from_numpy(fb)
-    pkg.render.reduce_frame(tfb, world, dist, dst=0)
+    if how == "gather":        # the default of FrameRenderer.reduce: only the owned strips travel
+        tfb = pkg.render.StripGather(torch, w, h, rank, world, torch.device("cpu"))(tfb, dist)
+    else:
+        pkg.render.reduce_frame(tfb, world, dist, dst=0)
     if rank == 0:
         np.save(out_path, tfb.numpy())
     dist.barrier()
@@ -63,6 +66,31 @@ def test_eight_rank_strip_sharding_reproduces_the_frame(manifest, golden_blob, g
     mp.spawn(_worker, args=(8, _free_port(), golden_blob("fence"), m["width"], m["height"], m["samples"], m["bounces"], out),
              nprocs=8, join=True)
     assert np.array_equal(np.load(out), golden_ref("fence")), "8-rank frame differs from the reference's single-process frame"
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_strip_gather_reproduces_the_frame(world, manifest, golden_blob, golden_ref, tmp_path):
+    """The same frames with the strips gathered instead of the whole buffer reduced (render.py: StripGather, the bench's default):
+    ragged height, ranks with unequal row counts (padded to a common shape for the gather)."""
+    import torch.multiprocessing as mp
+    m = manifest["fence"]
+    out = str(tmp_path / f"frame_gather{world}.npy")
+    mp.spawn(_worker, args=(world, _free_port(), golden_blob("fence"), m["width"], m["height"], m["samples"], m["bounces"], out, "gather"),
+             nprocs=world, join=True)
+    assert np.array_equal(np.load(out), golden_ref("fence")), f"{world}-rank gathered frame differs from the reference's single-process frame"
+
+
+def test_strip_rows_match_the_c_hosts_pack_order(pkg):
+    """render.py: strip_rows lists, per rank, the framebuffer rows k_strip_rows (cray_hip.hip: crh_frames_gather) packs: strip by strip, bottom row of a strip first."""
+    for h, world in ((100, 8), (720, 8), (7, 3), (3, 2), (9, 16)):
+        seen = []
+        for r in range(world):
+            rows = pkg.render.strip_rows(h, r, world)
+            ys = [h - 1 - x for x in rows]
+            want = [(r + (p // 4) * world) * 4 + p % 4 for p in range(len(rows))]      # k_strip_rows' y of packed row p
+            assert ys == want, (h, world, r)
+            seen += ys
+        assert sorted(seen) == list(range(h))
 
 
 @pytest.mark.parametrize("width,height,gpus", [(160, 100, 8), (1280, 720, 8), (3840, 2160, 8), (33, 7, 3), (64, 3, 2), (5, 9, 16)])

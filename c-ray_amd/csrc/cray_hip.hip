@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -38,9 +39,27 @@ using namespace crh;
 
 /* ---- tunables ---------------------------------------------------------------------------------- */
 #define CRH_BLOCK 256            /* 4 waves of 64 */
-#ifndef CRH_STACK_LDS
-#define CRH_STACK_LDS 23         /* traversal stack entries kept in LDS per lane; with the 13 park slots, the id stacks and cursors: < 40 KB per block, 4 blocks per CU */
+/* Quad-cooperative record fetch (round 3 experiment, -DCRH_EXP_COOP_FETCH, fetch64 below): the vector L1 prices a divergent 16-byte-per-lane load by the
+ * cache lines it touches per instruction, and a lane that reads a 64-byte record with four loads pays for the same line four times (tools/ubench_l1.hip on
+ * the MI355X, 16 waves per CU, dependent chain: 1201 ns per wave-step in an L2-resident set, 64 lanes; the same bytes fetched by the four lanes of a quad
+ * side by side, one instruction per quad member: 470 ns; 826 -> 479 ns at 32 lanes in a 160 MB set). The records land in LDS (global_load_lds_dwordx4),
+ * 4160 bytes per wave, paid for with ten stack entries and seven park slots. In the real kernel it LOSES: the ~22 vector and ~16 scalar instructions per node
+ * step it adds for ALL 64 lanes (quad broadcasts, exec masks, M0) cost more than the L1 look-ups it saves, because the vector ALU is the other
+ * resource the walk is short of (74 % busy): hdr.json -12 %, statues -8 %, 1 M soup -11 % on top of the -2...-9 % of the smaller LDS stack and
+ * the re-derived slab constants (profiles/r03c_ab_coop_fetch.log; frames bit-identical). Kept as a tested option. */
+#ifdef CRH_EXP_COOP_FETCH          /* measured slower in the real kernel (profiles/r03c_ab_coop_fetch.log): not in the default library */
+#define CRH_COOP_FETCH 1
 #endif
+#ifndef CRH_STACK_LDS
+#ifdef CRH_COOP_FETCH
+#define CRH_STACK_LDS 13         /* traversal stack entries kept in LDS per lane; with the 6 park slots, the fetch slabs, the id stacks and cursors: < 40 KB per block, 4 blocks per CU */
+#else
+#define CRH_STACK_LDS 23
+#endif
+#endif
+#define CRH_REC_STRIDE_WORDS 260u                          /* one slab = what one global_load_lds_dwordx4 writes (64 lanes x 16 B) + 16 B of skew: the four lanes of a quad
+                                                            * read their records from four slabs, and the skew puts the 16 lanes of a ds_read_b128 pass on distinct banks */
+#define CRH_REC_WORDS_PER_WAVE (4u * CRH_REC_STRIDE_WORDS)
 
 /* CRH_LOCKSTEP(): marks a place where the lanes of a wave hand data to each other through LDS with no wave collective in between,
  * relying on what the hardware guarantees anyway — a wave executes in lockstep and its LDS operations in program order. It expands to
@@ -66,7 +85,7 @@ static int fail(int code, const std::string &msg) { t_err = msg; return code; }
  * access into a flat_load / flat_store. LDS + overflow cover the worst case the scene compiler can report
  * (64 + 5 + 64 + 1, bvh.c:32). The park slots (pt_device.h: PK_*) are LDS too. */
 #define CRH_STACK_OVF (134 - CRH_STACK_LDS)
-#define CRH_OVF_WORDS_PER_WAVE (120u * 64u)    /* overflow columns of one wave in the context's global buffer (both kernel forms: >= 134 - 15 entries x 64 lanes, for any CRH_STACK_LDS >= 15) */
+#define CRH_OVF_WORDS_PER_WAVE (128u * 64u)    /* overflow columns of one wave in the context's global buffer (both kernel forms: >= 134 - 6 entries x 64 lanes, for any CRH_STACK_LDS >= 6) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
 /* k_pathtrace: the overflow entries live in a per-wave column block of a global buffer (entry i of lane l at ovf[(i - CRH_STACK_LDS) * 64]
@@ -194,6 +213,43 @@ __device__ __forceinline__ uint32_t laneRank(unsigned long long m) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+/* value of lane m of this lane's quad (DPP quad_perm [m,m,m,m]); every lane of the wave must execute it */
+__device__ __forceinline__ uint32_t quadBcast(uint32_t v, int m) {
+	switch (m) {
+		case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);
+		case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xF, 0xF, true);
+		case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xF, 0xF, true);
+		default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);
+	}
+}
+#ifndef CRH_WAIT_VMEM             /* every vector-memory operation of the wave has completed (the LDS writes of global_load_lds among them); the emulation's loads are synchronous */
+#define CRH_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#if defined(__clang__)
+typedef float crh_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 ldsLoadF4(const lds_u32 *p) { const crh_v4f v = *(const __attribute__((address_space(3))) crh_v4f *)p; return f4{v.x, v.y, v.z, v.w}; }     /* ds_read_b128 */
+#else
+static inline f4 ldsLoadF4(const uint32_t *p) { f4 r; memcpy(&r, p, sizeof(r)); return r; }
+#endif
+/* One 64-byte record per lane — base[fi .. fi + 4), fi = CRH_NONE for a lane that wants none — fetched by the QUADS of the wave: for each of the four members of a
+ * quad in turn, its four lanes load one quarter each (64 contiguous bytes: one cache-line look-up per quad and instruction instead of four per lane), straight
+ * into the wave's LDS slabs; then every lane reads its own record back. ALL 64 lanes must call it (a lane serves its quad's members even when it wants nothing). */
+__device__ __forceinline__ void fetch64(lds_u32 *slab, uint32_t lane, const f4 *base, uint32_t fi, f4 &a, f4 &b, f4 &c, f4 &d) {
+	const uint32_t q = lane & 3u;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		const uint32_t fm = quadBcast(fi, m);
+		if (fm != CRH_NONE)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + fm + q), (__attribute__((address_space(3))) void *)(slab + (uint32_t)m * CRH_REC_STRIDE_WORDS), 16, 0, 0);
+	}
+	CRH_WAIT_VMEM();
+	CRH_LOCKSTEP();               /* the quarters other lanes fetched are in LDS */
+	if (fi != CRH_NONE) {
+		const lds_u32 *mine = slab + q * CRH_REC_STRIDE_WORDS + (lane & ~3u) * 4u;
+		a = ldsLoadF4(mine); b = ldsLoadF4(mine + 4); c = ldsLoadF4(mine + 8); d = ldsLoadF4(mine + 12);
+	}
+}
+
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
 #ifndef CRH_WPS_OVERRIDE
 #define CRH_WPS_OVERRIDE WPS
@@ -205,7 +261,13 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 														   float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
+#ifdef CRH_COOP_FETCH
+	__shared__ __attribute__((aligned(16))) uint32_t s_rec[(CRH_BLOCK / 64) * CRH_REC_WORDS_PER_WAVE];
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32 + CRH_REC_WORDS_PER_WAVE * 4) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+	lds_u32 *const rec = (lds_u32 *)&s_rec[(threadIdx.x >> 6) * CRH_REC_WORDS_PER_WAVE];
+#else
 	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+#endif
 	const DScene S = globalize(Sarg);
 	CRH_EM_POW_TABLES_INIT();
 	const unsigned long long tStart = wall_clock64();
@@ -325,7 +387,16 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 					case ST_NODE: {          /* keep stepping while at least runNum/8 (half) of the lanes that started this run still want node steps */
 						int now = nN;
 						do {
+#ifdef CRH_COOP_FETCH
+							{
+								const bool act = w.phase == PH_NODE;
+								f4 l0, l1, r0, r1;
+								fetch64(rec, lane, S.nodes, act ? 2u * w.node : CRH_NONE, l0, l1, r0, r1);
+								if (act) stepNodeLoaded<true>(S, w, stk, cnt, port, l0, l1, r0, r1);
+							}
+#else
 							if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
+#endif
 							if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
 							/* lanes that reached a leaf or an instance: serve them inside the run once enough of them wait (no scheduling
 							 * round in between, and the node lanes they become again rejoin this run) */
@@ -1414,8 +1485,11 @@ int crh_context_prepare(crh_ctx *c) {
 	if (!c) return fail(CRH_ERR_INVALID, "crh_context_prepare: ctx is NULL");
 	int rc = setDevice(c);
 	if (rc) return rc;
+	/* the plain variant only: scenes with node programs or volumes are rare (crh_scene_upload loads theirs), and a launch of that variant —
+	 * twice the scratch per lane — would make the runtime size the queue's scratch memory for it */
 	const bool had = c->hasPrograms;
-	for (int v = 0; v < 2 && rc == CRH_OK; ++v) { c->hasPrograms = (v == 1); rc = preloadKernel(c); }
+	c->hasPrograms = getenv("CRH_FORCE_PROGRAMS") != nullptr;
+	rc = preloadKernel(c);
 	c->hasPrograms = had;
 	return rc;
 }
@@ -1939,6 +2013,17 @@ int crh_synchronize(crh_ctx *c) {
 	if (!c) return fail(CRH_ERR_INVALID, "crh_synchronize: ctx is NULL");
 	int rc = setDevice(c);
 	if (rc) return rc;
+	if (getenv("CRH_TRACE_SYNC") && !c->pendingTimes.empty()) {        /* dev: when does the stream reach the kernel, when does it leave it, when does the host notice? */
+		const auto t0 = std::chrono::steady_clock::now();
+		auto us = [&]() { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
+		const crh_ctx::Timed ev = c->pendingTimes.back();
+		while (hipEventQuery(ev.a) == hipErrorNotReady) {}
+		const long ta = us();
+		while (hipEventQuery(ev.b) == hipErrorNotReady) {}
+		const long tb = us();
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		fprintf(stderr, "crh_synchronize trace: event before the kernel done after %ld us, event after it after %ld us, stream synchronized after %ld us\n", ta, tb, us());
+	}
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	rc = resolveTimes(c, true);
 	for (auto &ts : c->tileSlots) ts.inFlight = false;

@@ -833,7 +833,17 @@ struct TravHit {
  */
 #define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
 /* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside a BLAS */
+/* (-DCRH_EXP_PARK_RAY_ONLY, round 3 experiment: park the ray only — origin and direction — and recompute the slab constants and the octant when the lane
+ * leaves the BLAS (makeRayK is a pure function: the same bits); frees seven LDS words per lane, which the quad-cooperative fetch of cray_hip.hip needs,
+ * and costs three correctly rounded divisions per instance visit: -2.4 % on hdr.json, -6 % on statues.json) */
+#if !defined(CRH_EXP_COOP_FETCH) && !defined(CRH_EXP_PARK_RAY_ONLY)
+#define CRH_PARK_FULL 1        /* (measured: the recomputation costs 2-6 %, profiles/r03c_ab_coop_fetch.log) */
+#endif
+#ifdef CRH_PARK_FULL
 enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT, CRH_PARK_SLOTS };
+#else
+enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, CRH_PARK_SLOTS };
+#endif
 
 enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6, PH_NODE_SLOW = 7 };   /* PH_NODE_SLOW: a node step for a degenerate ray (rare; served with the control steps) */   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
@@ -936,11 +946,16 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	 * reads, far cheaper than a scheduling round at the occupancy such a step would get. */
 	if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
 	w.inBlas = 0; w.instFound = 0;
+#ifdef CRH_PARK_FULL
 	w.k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
 	w.k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
 	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
 	w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
 	w.k.oct = stk.unpark(PK_OCT);
+#else
+	w.k = makeRayK(v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))},
+				   v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))});         /* the same function of the same ray: the same bits as at walkBegin */
+#endif
 	w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
 	w.spBase = 0;
 	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
@@ -969,10 +984,9 @@ CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v
 
 /* NODE: bvh.c:391-436 */
 /* FAST = true serves PH_NODE lanes (regular rays: no degenerate-slab code in the step at all), FAST = false PH_NODE_SLOW lanes */
+/* (the child pair arrives as four 16-byte quarters: stepNode loads them itself; k_pathtrace fetches the pairs of a whole wave quad-cooperatively and calls this) */
 template <bool FAST = true, class Stack, class Cnt, class Port>
-CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
-	const uint32_t node = w.node;
-	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
+CRH_DEV void stepNodeLoaded(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port, const f4 l0, const f4 l1, const f4 r0, const f4 r1) {
 	float tL, tR;
 	CRH_COUNT(cnt, node_tests, 2);
 	const bool hitL = intersectNode<FAST>(l0, l1, w.k, w.hit.t, tL);
@@ -992,6 +1006,12 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 	if (inL && inR) stk.push(w.sp++, swap ? fl : fr);
 	w.node = (inL && inR) ? (swap ? fr : fl) : (inL ? fl : (inR ? fr : CRH_NONE));
 	walkAdvance(S, w, stk, cnt, port);
+}
+template <bool FAST = true, class Stack, class Cnt, class Port>
+CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
+	const uint32_t node = w.node;
+	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
+	stepNodeLoaded<FAST>(S, w, stk, cnt, port, l0, l1, r0, r1);
 }
 
 /* TRI: poly.c:17-53 on the prepared record (one triangle per step) */
@@ -1078,9 +1098,11 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			stk.push(w.sp++, w.node); stk.push(w.sp++, w.pA); stk.push(w.sp++, w.pAe); stk.push(w.sp++, w.pB); stk.push(w.sp++, w.pBe);
 			stk.park(PK_OX, asU32(w.k.o.x)); stk.park(PK_OY, asU32(w.k.o.y)); stk.park(PK_OZ, asU32(w.k.o.z));
 			stk.park(PK_DX, asU32(w.k.d.x)); stk.park(PK_DY, asU32(w.k.d.y)); stk.park(PK_DZ, asU32(w.k.d.z));
+#ifdef CRH_PARK_FULL
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
 			stk.park(PK_SX, asU32(w.k.ss.x)); stk.park(PK_SY, asU32(w.k.ss.y)); stk.park(PK_SZ, asU32(w.k.ss.z));
 			stk.park(PK_OCT, w.k.oct);
+#endif
 			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
 			else { w.node = inst->root; w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;

@@ -151,7 +151,7 @@ static void *gpuThread(void *arg) {
 	/* beside the flattener: the context, the per-wave buffers, the code objects.
 	 * counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
 	int ok = crh_context_create(w->device, NULL, &w->ctx) == CRH_OK && crh_set_option(w->ctx, CRH_OPT_COUNTER_LEVEL, 1) == CRH_OK &&
-			 crh_context_prepare(w->ctx) == CRH_OK && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
+			 (getenv("CRH_DROPIN_NO_PREPARE") || crh_context_prepare(w->ctx) == CRH_OK) && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
 	if (!ok) snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 	w->contextUs = getUs(phase);
 	pthread_mutex_lock(&w->sync->mu);

@@ -256,8 +256,8 @@ int crh_abi_version(void);
  * stream) or an existing hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream). */
 int crh_context_create(int device, void *stream, crh_ctx **out);
 int crh_context_destroy(crh_ctx *ctx);
-/* Optional: the part of crh_scene_upload that does not need the scene — the per-wave buffers of a full-size dispatch and the code objects
- * of the kernel the options set so far select (HIP loads kernels lazily). A host calls it after crh_set_option and before its scene is
+/* Optional: the part of crh_scene_upload that does not need the scene — the per-wave buffers of a full-size dispatch and the code object
+ * of the kernel the options set so far select (HIP loads kernels lazily; the plain variant: a scene with node programs or volumes loads its own). A host calls it after crh_set_option and before its scene is
  * flattened, on the context's own thread, so that this work overlaps the flattening (renderer_hip.c); crh_scene_upload then skips it. */
 int crh_context_prepare(crh_ctx *ctx);
 

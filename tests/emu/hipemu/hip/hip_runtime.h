@@ -170,6 +170,9 @@ static __forceinline__ unsigned hipemu_mbcnt_hi(unsigned mask, unsigned base) {
 }
 #define __builtin_amdgcn_mbcnt_lo(m, b) hipemu_mbcnt_lo(m, b)
 #define __builtin_amdgcn_mbcnt_hi(m, b) hipemu_mbcnt_hi(m, b)
+/* global_load_lds_dwordx4 (cray_hip.hip: fetch64): lane l's `size` bytes land at the LDS base + offset + l * size; synchronous here */
+#define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) ((void)memcpy((char *)(dst) + (off) + hipemu_lane_id() * (unsigned)(size), (const void *)(src), (size)))
+#define CRH_WAIT_VMEM() do { } while (0)
 /* cray_hip.hip's marker for "the lanes exchange data through LDS here, relying on lockstep": a rendezvous of the wave */
 #define CRH_LOCKSTEP() ((void)hipemu::collective(hipemu::W_LOCKSTEP, 0, 0, HIPEMU_SITE))
 #define __syncthreads() ((void)hipemu::collective(hipemu::W_BARRIER, 0, 0, HIPEMU_SITE))

@@ -375,7 +375,7 @@ def test_interactive_mode_halton_sampler(pkg, ctx, manifest, golden_blob, golden
 
 def test_full_size_properties_cfg2(pkg, ctx, oracle):
     """BASELINE.json configs[1] at full resolution (needs scenes/_built/cfg2_hdr.blob, made by build()):
-    deterministic, tile decomposition exact, ray count within 0.2 % of the oracle, image within tolerance —
+    deterministic, tile decomposition exact, ray count and every float of the frame equal to the oracle's —
     checked at 16 spp so that the CPU side stays in seconds; the 256-spp frame is what bench.py times."""
     import os
     from __graft_entry__ import BUILT
@@ -399,8 +399,8 @@ def test_full_size_properties_cfg2(pkg, ctx, oracle):
 
 def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest, golden_blob, golden_ref, tmp_path):
     """c-ray-hip = the reference's own main.c / loader / encoders with renderer.c replaced by renderer_hip.c.
-    Its float buffer must equal the library path bit for bit (same kernels) and the reference within tolerance;
-    the BMP it writes goes through the reference's untouched encoder."""
+    Its float buffer must equal the library path's and the reference's bit for bit; the BMP it writes — the reference's untouched encoder fed by
+    the 8-bit frame renderer_hip.c converts on the device — must equal the real reference's file byte for byte."""
     import json
     import os
     import subprocess
@@ -426,8 +426,12 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     assert np.array_equal(img, golden_ref("cfg1_scene"))
     bmp = [f for f in os.listdir(tmp_path) if f.endswith(".bmp")]
     assert bmp, "the reference's encoder wrote no image"
+    import hashlib
     data = open(tmp_path / bmp[0], "rb").read()
     assert data[:2] == b"BM" and len(data) >= w * h * 3
+    # byte for byte the file the real reference writes (tools/gen_bmp_golden.py): its encoder, fed by an 8-bit frame that was converted on the device
+    assert hashlib.md5(data).hexdigest() == m["bmp_md5"], "the BMP differs from c-ray-ref-strict's"
+    os.remove(tmp_path / bmp[0])
     # --iterative: the interactive mode of the same program (Halton sampler, passes 1 .. samples-1, progressive chunks)
     mi = manifest["cfg1_scene_iterative"]
     scene = refrun.rewrite_scene("scene.json", w, h, mi["samples"], mi["bounces"], out_dir=str(tmp_path))
@@ -444,6 +448,8 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     finally:
         ctx.set_option(pkg.abi.OPT_SAMPLER, pkg.abi.SAMPLER_RANDOM)
     assert np.array_equal(img, golden_ref("cfg1_scene_iterative"))
+    bmp = [f for f in os.listdir(tmp_path) if f.endswith(".bmp")]
+    assert bmp and hashlib.md5(open(tmp_path / bmp[0], "rb").read()).hexdigest() == mi["bmp_md5"], "the --iterative BMP differs from c-ray-ref-strict's"
 
 
 def test_c_host_reduce_goes_through_rccl(pkg, manifest, golden_blob, tmp_path):

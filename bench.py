@@ -37,7 +37,28 @@ WORKLOADS = {   # BASELINE.json configs[1..4]; the default (and the headline) is
     "soup": {"scene": "soup_1000000.json", "blob": "soup_1m", "width": 2560, "height": 1440, "samples": 512, "bounces": 8, "tile": (64, 64), "tile_order": 1,
              "what": "synthetic 1 M-triangle soup {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[4] at 1 M triangles; the 10 M blob is built on the box by tools/make_soup.sh)"},
 }
+WORKLOADS["soup10m"] = {"scene": None, "blob": "soup_10m", "width": 2560, "height": 1440, "samples": 512, "bounces": 8, "tile": (64, 64), "tile_order": 1, "triangles": 10000000,
+                        "what": "synthetic 10 M-triangle soup {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[4] at its real size; the 1.04 GB scene is built on this box by "
+                                "tools/make_soup_blob.py: gen_soup's triangles as the reference's loader reads them + the GPU BVH builder, the reference's tree)"}
 WORKLOAD = WORKLOADS["cfg2"]
+# what `other_workloads` measures beside the headline (reduced spp: the rate does not depend on it once a dispatch holds enough paths)
+OTHER_WORKLOADS = (("cfg3", 32), ("cfg4", 4), ("soup", 16), ("soup10m", 8))
+
+
+def workload_blob(key, built_dir):
+    """Path of a workload's scene blob; the 10 M soup is built here on first use (tools/make_soup_blob.py, kept in the temp directory)."""
+    wl = WORKLOADS[key]
+    path = os.path.join(built_dir, wl["blob"] + ".blob")
+    if os.path.exists(path) or not wl.get("triangles"):
+        return path
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"crh_{wl['blob']}.blob")
+    if not os.path.exists(path):
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import make_soup_blob
+        make_soup_blob.build(wl["triangles"], path + ".tmp", builder="gpu")
+        os.replace(path + ".tmp", path)
+    return path
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -116,7 +137,7 @@ def kernel_source_md5():
 def measured_profile(workload_key):
     """(traffic bytes per launch, VALU roofline dict) from the committed rocprofv3 PMC summary — or (None, None) when that summary
     was taken from different kernel sources or another workload (stale numbers are not quoted)."""
-    path = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    path = os.path.join(REPO, "profiles", "hbm_traffic.json" if workload_key == "cfg2" else f"hbm_traffic_{workload_key}.json")
     try:
         t = json.load(open(path))
     except Exception:
@@ -124,6 +145,71 @@ def measured_profile(workload_key):
     if t.get("source_md5") != kernel_source_md5() or t.get("workload", "cfg2") != workload_key:
         return None, None
     return t.get("hbm_bytes_per_launch"), t.get("valu")
+
+
+def measure_other_workloads(api, abi, built_dir):
+    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region: one counting dispatch + two timed ones each, at a reduced sample
+    count (stated). Mray/s, algorithmic bytes and fraction of the HBM roofline per workload; `traffic` where profiles/ holds a PMC measurement of
+    that workload on this device code (per dispatch of the stated spp)."""
+    out = {}
+    for key, spp in OTHER_WORKLOADS:
+        wl = WORKLOADS[key]
+        t0 = time.perf_counter()
+        try:
+            blob = workload_blob(key, built_dir)
+            if not os.path.exists(blob):
+                out[key] = {"skipped": f"{blob} not built"}
+                continue
+            scene = api.Scene(blob)
+            ctx = api.Context(0)
+            ctx.upload(scene)
+            w, h, b = wl["width"], wl["height"], wl["bounces"]
+            fb = ctx.framebuffer(w, h)
+            ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+            ctx.reset_counters()
+            ctx.render_region(fb, w, h, spp, b)
+            ctx.synchronize()
+            full = ctx.counters()
+            ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
+            ctx.reset_counters()
+            for _ in range(2):
+                ctx.clear(fb, w, h)
+                ctx.render_region(fb, w, h, spp, b)
+            ctx.synchronize()
+            _, total_ms, n = ctx.kernel_time_ms()
+            ms = total_ms / max(n, 1)
+            alg = algorithmic_bytes(full, path_state=False)
+            traffic = None
+            try:
+                t = json.load(open(os.path.join(REPO, "profiles", f"hbm_traffic_{key}.json")))
+                if t.get("source_md5") == kernel_source_md5() and t.get("spp") == spp:
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            out[key] = {"workload": wl["what"].format(W=w, H=h, SPP=f"{spp} of {wl['samples']}", B=b), "mrays": round(full["rays"] / ms / 1e3, 1), "kernel_ms": round(ms, 2),
+                        "rays": full["rays"], "rays_per_path": round(full["rays"] / max(full["paths"], 1), 2),
+                        "node_tests_per_ray": round(full["node_tests"] / max(full["rays"], 1), 1), "tri_tests_per_ray": round(full["tri_tests"] / max(full["rays"], 1), 1),
+                        "bytes_per_ray": round(alg / max(full["rays"], 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "setup_s": round(time.perf_counter() - t0 - 3 * ms / 1e3, 2)}
+            ctx.close()
+            scene.close()
+        except Exception as e:      # a missing blob / failed build must not take the headline line with it
+            out[key] = {"failed": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def parity_columns(img, ref):
+    """BASELINE.md section 3's parity columns for two float frames: share of pixels whose 8-bit sRGB value differs by more than 1 LSB in any channel,
+    mean and 99.9th percentile of the per-pixel L2 distance (linear values clipped to [0, 1]), RMSE, share of floats that differ at all."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_py
+    a8, b8 = oracle_py.to_srgb8(img).astype(np.int16), oracle_py.to_srgb8(ref).astype(np.int16)
+    a, b = np.clip(img.astype(np.float64), 0.0, 1.0), np.clip(ref.astype(np.float64), 0.0, 1.0)
+    per_px = np.sqrt(((a - b) ** 2).sum(axis=2))
+    return {"pixels_gt_1lsb_pct": round(float((np.abs(a8 - b8).max(axis=2) > 1).mean() * 100.0), 4), "mean_l2": float(per_px.mean()),
+            "p999_l2": float(np.percentile(per_px, 99.9)), "rmse": float(np.sqrt(((a - b) ** 2).mean())),
+            "floats_that_differ": int((img.view(np.uint32) != ref.view(np.uint32)).sum())}
 
 
 def dropin_timing(workload):
@@ -162,8 +248,10 @@ def dropin_timing(workload):
                     "buffer's download and the host in between; mrays = rays / render_phase_ms. process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
 
 
-def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
-    """Reference pthread renderer on the host cores, bounded sample of the same frame (reduced spp)."""
+def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0, frames=None):
+    """Reference pthread renderer on the host cores, bounded sample of the same frame (reduced spp). `frames` (dict) receives the float frames the CPU
+    side rendered — "strict" (the bit-exact restatement of c-ray-ref-strict) and "default" (c-ray-ref, upstream's default flags) — and their spp."""
+    frames = {} if frames is None else frames
     import numpy as np
     sys.path.insert(0, os.path.join(REPO, "tools"))
     cores = os.cpu_count() or 1
@@ -174,14 +262,17 @@ def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0):
     probe = max(time.time() - t, 1e-3)
     spp = int(max(2, min(64, budget_s / probe)))
     ref_exe = os.path.join(REPO, "oracle", "_ref", "c-ray-ref")
-    overlay = os.path.join(REPO, "oracle", "_ref", "input", WORKLOAD["scene"])
+    overlay = os.path.join(REPO, "oracle", "_ref", "input", WORKLOAD["scene"] or "-")       # (the 10 M soup has no scene file on this box: the restatement is its CPU baseline)
     t = time.time()
-    _, cnt = oracle_py.render(oscene, w, h, spp, bounces)
+    port_img, cnt = oracle_py.render(oscene, w, h, spp, bounces)
     port_s = time.time() - t
+    frames["spp"] = spp
+    frames["strict"] = port_img          # the restatement = c-ray-ref-strict bit for bit (tests/golden: 15 fixtures)
     if os.path.exists(ref_exe) and os.path.exists(overlay):
         try:
             import refrun
-            _, st = refrun.render_reference(WORKLOAD["scene"], w, h, spp, bounces, flavour="default", threads=cores)
+            ref_img, st = refrun.render_reference(WORKLOAD["scene"], w, h, spp, bounces, flavour="default", threads=cores)
+            frames["default"] = ref_img
             secs = st["render_ms"] / 1e3
             return {"value": round(cnt["rays"] / secs / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "reference",
                     "sample": f"oracle/_ref/c-ray-ref -j {cores}: {WORKLOAD['scene']} {w}x{h}, {spp} spp (of {WORKLOAD['samples']}), {bounces} bounces, "
@@ -201,10 +292,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
-                    help="cfg2 (default, the headline: BASELINE.json configs[1]); cfg4 = configs[3], the scene the 1/2/4/8-GPU curve is quoted on")
+                    help="cfg2 (default, the headline: BASELINE.json configs[1]); cfg4 = configs[3], the scene the 1/2/4/8-GPU curve is quoted on; "
+                         "soup10m = configs[4] at its real size (the scene is built on this box on first use)")
     ap.add_argument("--samples", type=int, default=0, help=argparse.SUPPRESS)   # dev only: fewer passes than the config names
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-dropin", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-others", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     global WORKLOAD
     WORKLOAD = WORKLOADS[a.workload]
@@ -234,7 +327,10 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     W, H, SPP, B = WORKLOAD["width"], WORKLOAD["height"], a.samples, WORKLOAD["bounces"]
-    blob = os.path.join(BUILT, WORKLOAD["blob"] + ".blob")
+    blob = workload_blob(a.workload, BUILT) if rank == 0 or not WORKLOAD.get("triangles") else None
+    if world > 1 and WORKLOAD.get("triangles"):          # built once, by rank 0
+        dist.barrier()
+        blob = workload_blob(a.workload, BUILT)
     if not os.path.exists(blob):
         raise SystemExit(f"bench.py: {blob} missing — run __graft_entry__.build() where /root/reference exists")
     scene = api.Scene(blob)
@@ -318,7 +414,24 @@ def main():
         if world == 1 and not a.no_cpu:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import oracle_py
-            out["cpu_baseline"] = cpu_baseline(oracle_py, blob, W, H, B)
+            frames = {}
+            out["cpu_baseline"] = cpu_baseline(oracle_py, blob, W, H, B, frames=frames)
+            if frames.get("spp") and WORKLOAD.get("scene"):
+                # BASELINE.md section 3's parity columns: the GPU frame at the CPU sample's spp (the seed depends on the sample count: sampler.c:42) against
+                # the strict flavour (the parity contract: 0 everywhere) and against upstream's default flags (FMA contraction on: how far the contract's
+                # flavour is from what a user's own build renders — chaos, not error: DESIGN.md section 5)
+                try:
+                    import numpy as np
+                    fbp = ctx.framebuffer(W, H)
+                    ctx.render_region(fbp, W, H, frames["spp"], B)
+                    gpu_img = ctx.download(fbp, W, H)
+                    out["parity"] = {"frame": f"{W}x{H}, {frames['spp']} spp, {B} bounces",
+                                     "vs_reference_strict_flavour": parity_columns(gpu_img, frames["strict"])}
+                    if "default" in frames:
+                        out["parity"]["vs_reference_default_flags"] = parity_columns(gpu_img, frames["default"])
+                        out["parity"]["reference_strict_vs_default_flags"] = parity_columns(frames["strict"], frames["default"])
+                except Exception as e:
+                    out["parity"] = {"failed": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and not a.no_dropin and SPP == WORKLOAD["samples"] and a.workload == "cfg2":
             try:
                 fr.close()                 # the drop-in is its own process with its own context
@@ -327,6 +440,8 @@ def main():
             out["dropin"] = dropin_timing(WORKLOAD)
             if isinstance(out["dropin"].get("render_phase_ms"), (int, float)):
                 out["dropin"]["vs_bench_ms_per_step"] = round(out["dropin"]["render_phase_ms"] / ms_per_step, 3)
+        if world == 1 and not a.no_others and a.workload == "cfg2" and SPP == WORKLOAD["samples"]:
+            out["other_workloads"] = measure_other_workloads(api, abi, BUILT)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

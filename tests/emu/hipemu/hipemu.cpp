@@ -274,7 +274,10 @@ hipError_t hipGetLastError(void) { return hipSuccess; }
  * threads — renderer_hip.c — run its partition and gather logic */
 static int deviceCount() { const char *e = getenv("HIPEMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : (n > 16 ? 16 : n); }
 hipError_t hipGetDeviceCount(int *n) { if (!n) return hipErrorInvalidValue; *n = deviceCount(); return hipSuccess; }
-hipError_t hipSetDevice(int device) { return device >= 0 && device < deviceCount() ? hipSuccess : hipErrorInvalidDevice; }
+/* HIPEMU_FAIL_DEVICE=<d>: every hipMalloc of a thread whose current device is d fails (a GPU that cannot be set up: renderer_hip.c's failed-worker path) */
+static thread_local int t_device = 0;
+static int failDevice() { const char *e = getenv("HIPEMU_FAIL_DEVICE"); return e ? atoi(e) : -1; }
+hipError_t hipSetDevice(int device) { if (device < 0 || device >= deviceCount()) return hipErrorInvalidDevice; t_device = device; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device) {
 	if (!prop || device < 0 || device >= deviceCount()) return hipErrorInvalidValue;
 	memset(prop, 0, sizeof(*prop));
@@ -287,6 +290,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device) {
 hipError_t hipMalloc(void **p, size_t bytes) {
 	if (!p) return hipErrorInvalidValue;
 	*p = nullptr;
+	if (t_device == failDevice()) return hipErrorOutOfMemory;
 	if (posix_memalign(p, 256, bytes ? bytes : 1) != 0) return hipErrorOutOfMemory;
 	return hipSuccess;
 }

@@ -232,10 +232,12 @@ def test_dropin_program_and_cluster_worker_on_emulation(children):
 
 
 def test_dropin_program_on_several_emulated_gpus(emu_lib, manifest, golden_ref, tmp_path):
-    """renderer_hip.c with more than one GPU, which no single-GPU box can run: HIPEMU_DEVICES emulated devices, one dispatch thread each,
-    4-row strips dealt to them (host/share.h), the float framebuffers summed onto GPU 0 through the RCCL entry points (a stand-in library:
-    tests/emu/fake_rccl.c), downloaded, resolved — and, with --iterative, the per-chunk gather of every GPU's strips on the host. The frame
-    is the reference's, bit for bit, whatever the number of GPUs."""
+    """renderer_hip.c with more than one GPU, which no single-GPU box can run: HIPEMU_DEVICES emulated devices (2, 5, 8), one dispatch thread each,
+    4-row strips dealt to them (host/share.h), the strips gathered onto GPU 0 through the RCCL entry points (grouped ncclSend / ncclRecv; a stand-in
+    library: tests/emu/fake_rccl.c, which checks the call pattern), the 8-bit frame converted on every "device" and assembled from the strips — and,
+    with --iterative (3 and 8 devices), the per-dispatch conversion and gather. The frame is the reference's, bit for bit, and so is the BMP, whatever the
+    number of GPUs; the one-ncclReduce form gives the same frame; a GPU that cannot be set up ends the program with an error that names it."""
+    import hashlib
     import json
     import numpy as np
     exe = os.path.join(REPO, "c-ray_amd", "_lib", "c-ray-hip")
@@ -245,7 +247,7 @@ def test_dropin_program_on_several_emulated_gpus(emu_lib, manifest, golden_ref, 
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import refrun
     libdir = os.path.join(EMU_DIR, "_dropin_libs")
-    for mode, key, gpu_counts in (((), "cfg1_scene", (2, 5)), (("--iterative",), "cfg1_scene_iterative", (3,))):
+    for mode, key, gpu_counts in (((), "cfg1_scene", (2, 5, 8)), (("--iterative",), "cfg1_scene_iterative", (3, 8))):
         m = manifest[key]
         w, h = manifest["cfg1_scene"]["width"], manifest["cfg1_scene"]["height"]
         scene = refrun.rewrite_scene("scene.json", w, h, m["samples"], m["bounces"], out_dir=str(tmp_path))
@@ -258,3 +260,23 @@ def test_dropin_program_on_several_emulated_gpus(emu_lib, manifest, golden_ref, 
             assert proc.returncode == 0 and f"on {gpus} GPUs" in out, out[-2000:]
             img = np.fromfile(dump, dtype=np.float32).reshape(h, w, 3)
             assert np.array_equal(img.view(np.uint32), golden_ref(key).view(np.uint32)), (key, gpus)
+            bmp = [f for f in os.listdir(tmp_path) if f.endswith(".bmp")]
+            assert bmp and hashlib.md5(open(tmp_path / bmp[0], "rb").read()).hexdigest() == m["bmp_md5"], (key, gpus, "the 8-bit frame (converted per GPU, strips gathered) differs from the reference's BMP")
+            os.remove(tmp_path / bmp[0])
+    # the one-ncclReduce form of the frame assembly (CRH_FRAMES=reduce) gives the same frame as the default strip gather
+    m = manifest["cfg1_scene"]
+    scene = refrun.rewrite_scene("scene.json", w, h, m["samples"], m["bounces"], out_dir=str(tmp_path))
+    dump = str(tmp_path / "hip_reduce.f32")
+    env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES="4", HIPEMU_DEVICES="4", HIPEMU_CUS="2", HIPEMU_THREADS="4", CRH_FRAMES="reduce",
+               LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    proc = subprocess.run([exe], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-2000:]
+    assert np.array_equal(np.fromfile(dump, dtype=np.float32).reshape(h, w, 3).view(np.uint32), golden_ref("cfg1_scene").view(np.uint32))
+    # a GPU that cannot be set up (every allocation on device 2 fails): the program says which one and why, and exits with an error — no partial frame
+    os.remove(dump)
+    env = dict(env, HIPEMU_FAIL_DEVICE="2")
+    env.pop("CRH_FRAMES")
+    proc = subprocess.run([exe], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = proc.stdout.decode(errors="replace")
+    assert proc.returncode != 0 and "GPU 2" in out and "dispatch thread failed" in out, out[-2000:]
+    assert not os.path.exists(dump)

@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_pathtrace_wg(const DScene Sarg
 	}
 }
 
-__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits) {
+__global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, const float *rays, uint64_t n, crh_hit *hits, uint32_t rayFlags) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	const DScene S = globalize(Sarg);
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 		memset(&cnt, 0, sizeof(cnt));
 		const v3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
 		TravHit h;
-		traverse(S, stk, o, d, h, cnt);
+		traverse(S, stk, o, d, h, cnt, rayFlags);
 		crh_hit out;
 		memset(&out, 0, sizeof(out));
 		out.inst = h.inst < 0 ? -1 : (int32_t)S.instances[h.inst].orig; out.distance = h.t; out.node_tests = cnt.node_tests; out.tri_tests = cnt.tri_tests;
@@ -1151,6 +1151,7 @@ struct crh_ctx {
 	size_t gatherFloats = 0;
 	uint8_t *dSrgb = nullptr;                /* crh_framebuffer_to_srgb8: the 8-bit frame on the device (grown on demand, kept) */
 	size_t srgbBytes = 0;
+	bool traceExactSlabs = false;            /* CRH_OPT_TRACE_SLABS: crh_trace_rays walks degenerate rays like the render kernels do (exact slabs) instead of like the reference (NaN arithmetic) */
 	bool wgSinceCheck = false;               /* a workgroup-kernel launch has happened since the flag was last read (the default kernel never writes it) */
 	float *dQueues = nullptr;
 	size_t queueFloats = 0;
@@ -1460,6 +1461,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_PASS_CHUNK:
 			if (value < 1 || value > 4096) return fail(CRH_ERR_INVALID, "pass chunk must be 1..4096");
 			c->passChunk = (int)value; return CRH_OK;
+		case CRH_OPT_TRACE_SLABS:
+			if (value != CRH_TRACE_SLABS_LITERAL && value != CRH_TRACE_SLABS_EXACT) return fail(CRH_ERR_INVALID, "trace slabs must be CRH_TRACE_SLABS_LITERAL or CRH_TRACE_SLABS_EXACT");
+			c->traceExactSlabs = value == CRH_TRACE_SLABS_EXACT; return CRH_OK;
 		case CRH_OPT_KERNEL:
 #ifdef CRH_EXP_ROLLING_UNITS
 			if (value == CRH_KERNEL_ROLL) { c->kernel = (int)value; return CRH_OK; }
@@ -2126,7 +2130,7 @@ int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits
 	if (e == hipSuccess) e = hipMalloc((void **)&dHits, n * sizeof(crh_hit));
 	if (e == hipSuccess) e = hipMemcpyAsync(dRays, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, dRays, n, dHits);
+		hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, dRays, n, dHits, c->traceExactSlabs ? 0u : (uint32_t)CRH_RAY_LITERAL);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(hits_host, dHits, n * sizeof(crh_hit), hipMemcpyDeviceToHost, c->stream);

@@ -728,6 +728,7 @@ CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
  * bit 7: some component of the ray is not finite (reference NaN semantics are then followed literally). */
 struct RayK { v3 o, d, inv, ss; uint32_t oct; };
 #define CRH_RAY_SLOW 0xF0u
+#define CRH_RAY_LITERAL 0x100u   /* degenerate slabs follow the reference's NaN arithmetic literally instead of being tested exactly (set by the caller of walkBegin) */
 CRH_DEV bool finitef(float x) { return fabsf(x) <= FLT_MAX; }
 CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
 	RayK k;
@@ -747,7 +748,9 @@ CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
  * two slab parameters because invDir carries the sign the octant was taken from), so v_min / v_max / v_max3 /
  * v_min3 give the same boolean and the same tEntry (up to the sign of zero, which no comparison sees).
  *
- * Slow path, two deliberate differences ("degenerate rays"; result-preserving except where the reference's extra visits find a
+ * Slow path. With CRH_RAY_LITERAL in k.oct (crh_trace_rays by default since round 3) every ray follows the reference's select chain literally — NaN
+ * slabs and all: the same node visits, the same record, whatever the ray. Without it (the render kernels), two deliberate differences
+ * ("degenerate rays"; result-preserving except where the reference's extra visits find a
  * hit its own rounding error allows — an origin one ulp beside an axis-aligned face, the ray parallel to it: 5 of 190 750 adversarial
  * zero / denormal-component rays in tools/emu_fuzz_rays.py, none of the rendered fixtures and configurations):
  *  - a direction component that is zero (or so small that 1/d > 1e30): the reference computes
@@ -789,7 +792,7 @@ CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDis
 	float tMinX = ox ? xb : xa, tMaxX = ox ? xa : xb;
 	float tMinY = oy ? yb : ya, tMaxY = oy ? ya : yb;
 	float tMinZ = oz ? zb : za, tMaxZ = oz ? za : zb;
-	if (!(k.oct & 128u)) {
+	if (!(k.oct & (128u | CRH_RAY_LITERAL))) {
 		const float inf = __builtin_inff();
 		if (k.oct & 16u) { const bool in = (n0.x <= k.o.x) && (k.o.x <= n0.y); tMinX = in ? -inf : inf; tMaxX = in ? inf : -inf; }
 		if (k.oct & 32u) { const bool in = (n0.z <= k.o.y) && (k.o.y <= n0.w); tMinY = in ? -inf : inf; tMaxY = in ? inf : -inf; }
@@ -903,7 +906,7 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 		port.save(VP_T1, asU32(tWalk));
 		const DInstance *inst = &S.instances[w.curInst];
 		const v3 d = w.k.d;
-		w.k = makeRayK(alongRay(w.k.o, d, tWalk + 0.0001f), d);
+		{ const uint32_t lit = w.k.oct & CRH_RAY_LITERAL; w.k = makeRayK(alongRay(w.k.o, d, tWalk + 0.0001f), d); w.k.oct |= lit; }
 		w.inBlas = BLAS_VOL_EXIT;
 		w.pA = w.pAe = w.pB = w.pBe = 0;
 		w.node = CRH_NONE;
@@ -953,8 +956,12 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
 	w.k.oct = stk.unpark(PK_OCT);
 #else
-	w.k = makeRayK(v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))},
-				   v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))});         /* the same function of the same ray: the same bits as at walkBegin */
+	{
+		const uint32_t lit = w.k.oct & CRH_RAY_LITERAL;
+		w.k = makeRayK(v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))},
+					   v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))});         /* the same function of the same ray: the same bits as at walkBegin */
+		w.k.oct |= lit;
+	}
 #endif
 	w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
 	w.spBase = 0;
@@ -964,12 +971,13 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 }
 
 template <class Stack, class Cnt, class Port>
-CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v3 d, Cnt &cnt, Port &port) {
+CRH_DEV void walkBegin(const DScene &S, Walk &w, Stack &stk, const v3 o, const v3 d, Cnt &cnt, Port &port, uint32_t rayFlags = 0u) {
 	w.hit.t = FLT_MAX; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -1; w.hit.inst = -1;
 	w.node = CRH_NONE; w.pA = w.pAe = w.pB = w.pBe = 0; w.sp = 0; w.spBase = 0;
 	w.inBlas = 0; w.instFound = 0; w.curInst = -1;
 	CRH_COUNT1(cnt, rays, 1);
 	w.k = makeRayK(o, d);
+	w.k.oct |= rayFlags;                                                    /* CRH_RAY_LITERAL travels with the ray into every BLAS */
 	if (S.tlas_node_count < 1u) { w.phase = PH_SHADE; return; }              /* bvh.c:362-365 */
 	if (S.tlas_node_count == 1u) {                                          /* bvh.c:382-387 */
 		const f4 n0 = S.nodes[2u * S.tlas_root], n1 = S.nodes[2u * S.tlas_root + 1u];
@@ -1080,11 +1088,12 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 		}
 	} else if (kind == CRH_DINST_MESH_EMPTY) {
 		if (!volume) w.hit.inst = -1;                                        /* bvh.c:362-365 via instance.c:175 (a volume walks a COPY of the record) */
-	} else if (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z) {
+	} else if (!(w.k.oct & CRH_RAY_LITERAL) && (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z)) {
 		/* A NaN anywhere in the ray makes u (poly.c:30) NaN for every triangle, so no triangle can be accepted;
 		 * the reference still walks the whole BLAS (every box test passes on NaN). Same result, no walk. */
 	} else {
-		const RayK ko = makeRayK(o, d);
+		RayK ko = makeRayK(o, d);
+		ko.oct |= w.k.oct & CRH_RAY_LITERAL;
 		bool enter = true;
 		uint32_t rootA = 0, rootAe = 0;
 		if (kind == CRH_DINST_MESH_LEAF) {                                 /* bvh.c:382-387 */
@@ -1118,10 +1127,10 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 
 /* The whole walk for one lane (k_trace_rays, host emulation): run steps until the walk hands over to shading. */
 template <class Stack, class Cnt>
-CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD, TravHit &hit, Cnt &cnt) {
+CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD, TravHit &hit, Cnt &cnt, uint32_t rayFlags = 0u) {
 	Walk w;
 	NullPort port;                    /* caller rays have no path: scenes with volumes are refused before this runs */
-	walkBegin(S, w, stk, rayO, rayD, cnt, port);
+	walkBegin(S, w, stk, rayO, rayD, cnt, port, rayFlags);
 	while (w.phase != PH_SHADE) {
 		if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
 		else if (w.phase == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port);

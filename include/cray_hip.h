@@ -282,6 +282,13 @@ int crh_context_prepare(crh_ctx *ctx);
 #define CRH_OPT_KERNEL       12   /* which form of the path-tracing kernel: CRH_KERNEL_WAVE = every wave a self-contained machine (default),
                                    * CRH_KERNEL_WG = the four waves of a workgroup share one path table and take walker / shader roles */
 #define CRH_OPT_SCHED_WG     13   /* workgroup kernel scheduler: linger | drainAt<<8 | maxDrainers<<20 | partialMin<<24 | walkMin<<32 | fillTo<<40 */
+#define CRH_OPT_TRACE_SLABS  14   /* crh_trace_rays and rays with a zero / denormal direction component (a slab the reference's arithmetic turns into NaN, bvh.c:326-352):
+                                   * CRH_TRACE_SLABS_LITERAL (default) = the reference's select chain followed literally: its record and its node / triangle test counts,
+                                   * whatever the ray (such a ray visits most of the scene, like the reference's); CRH_TRACE_SLABS_EXACT = what the render kernels do:
+                                   * that slab is tested exactly (inside iff min <= start <= max): never more node visits, the same hit except an origin one ulp
+                                   * beside an axis-aligned face — a frame's one such camera ray costs microseconds instead of a third of a second */
+#define CRH_TRACE_SLABS_LITERAL 0
+#define CRH_TRACE_SLABS_EXACT   1
 #define CRH_KERNEL_WAVE 0
 #define CRH_KERNEL_WG   1
 #define CRH_SAMPLER_RANDOM 0

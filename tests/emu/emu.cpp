@@ -128,7 +128,7 @@ int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, c
 		memset(&cnt, 0, sizeof(cnt));
 		const v3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, dd{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
 		TravHit h;
-		traverse(d, stk, o, dd, h, cnt);
+		traverse(d, stk, o, dd, h, cnt);          /* the render kernels' walk: degenerate slabs tested exactly (crh_trace_rays' CRH_TRACE_SLABS_EXACT) */
 		crh_hit *oh = &hits[i];
 		memset(oh, 0, sizeof(*oh));
 		oh->inst = h.inst < 0 ? -1 : (int32_t)d.instances[h.inst].orig; oh->distance = h.t; oh->node_tests = cnt.node_tests; oh->tri_tests = cnt.tri_tests;

@@ -105,8 +105,8 @@ def test_soup_10m(pkg, oracle, tmp_path):
     px = rng.integers(0, w, 100000)
     py = rng.integers(0, h, 100000)
     rays[:100000] = [0, 0, -3.5, 0, 0, 1]
-    rays[:100000, 3] = (px - w / 2) / h * 1.1547
-    rays[:100000, 4] = (py - h / 2) / h * 1.1547
+    rays[:100000, 3] = (px + 0.5 - w / 2) / h * 1.1547          # pixel centres: no direction component is exactly zero (such a ray walks the whole
+    rays[:100000, 4] = (py + 0.5 - h / 2) / h * 1.1547          # 7.4 M-node scene in the reference, and in crh_trace_rays: tests/test_gpu_parity.py covers that on a small scene)
     rays[100000:, :3] = rng.uniform(-1.2, 1.2, (100000, 3))
     rays[100000:, 3:] = rng.normal(size=(100000, 3))
     got = ctx.trace_rays(rays)

@@ -1,19 +1,16 @@
 #!/usr/bin/env python3
 """emu_fuzz_rays.py — dev / test: k_trace_rays (getClosestIsect for caller rays) on the kernel emulation against the oracle, on ADVERSARIAL rays:
 direction components that are exactly zero or -0 (the slab test's NaN cases), denormal, huge; origins on box faces, on vertices of the scene's
-geometry, far outside, exactly on the camera; axis-aligned rays through box edges. The hit record (instance, polygon, distance, point, normal, uv,
-material) of every ray whose direction components all have finite reciprocals must be the oracle's bit for bit, and no ray may cost more
-node tests than the reference's. Rays with a zero (or denormal) component take the device's exact-slab path: fewer node
-tests, and — rarely — a different record; those are counted and printed.
+geometry, far outside, exactly on the camera; axis-aligned rays through box edges. Since round 3 crh_trace_rays follows the reference's slab
+arithmetic literally for such rays (CRH_TRACE_SLABS_LITERAL, the default): the hit record (instance, polygon, distance, point, normal, uv, material)
+AND the node / triangle test counts of EVERY ray must be the oracle's, bit for bit.
 
-Where degenerate rays differ (about 1 in 10^5 of these adversarial rays): (a) the origin sits one ulp beside an axis-aligned face and the ray runs
-parallel to it — the reference's NaN slab test lets it into the box, and its triangle test, whose rounding error exceeds that ulp, reports a hit
-the exact slab test has already excluded; (b) a direction so long that d.d or (d.o)^2 overflows fp32 (|d| beyond ~1e18) AND with a zero component. The reference's
-arithmetic is NaN all the way then — its slab test lets the ray into every box and sphere.c:30-47 reports a "hit" at distance NaN (every
-comparison with NaN is false) — while the device's exact test of a zero-component slab culls the box first. Likewise directions whose LARGEST
-component is tiny (1e-30 with a zero beside it): hit distances of 1e32 times denormal components are numerical noise, and the noise the reference
-finds in boxes its NaN slab test should not have let it into is not the noise the device finds. Rays the renderer makes are unit length;
-both cases need a caller of crh_trace_rays who passes such a direction.
+History (rounds 1-2, and still what the render kernels do — CRH_TRACE_SLABS_EXACT): a slab the reference turns into NaN is tested exactly instead
+(fewer node visits by orders of magnitude). Of 190 750 such adversarial rays 5 then differed from the reference: (a) the origin one ulp beside an
+axis-aligned face with the ray parallel to it — the reference's NaN slab test lets it into the box, and its triangle test, whose rounding error
+exceeds that ulp, reports a hit the exact slab test has already excluded; (b) a direction so long that d.d or (d.o)^2 overflows fp32 with a zero
+component, or whose LARGEST component is tiny (1e-30 with a zero beside it): numerical noise on both sides, but not the same noise. Rays the
+renderer makes are unit length; both cases need a caller who passes such a direction.
 
     python tools/emu_fuzz_rays.py [--seeds A:B] [--fixtures cfg1_scene,fence,...] [--rays N]
 """
@@ -87,7 +84,11 @@ for seed in range(lo, hi):
     for f in ("distance", "point", "normal", "uv"):
         rec_differs |= (np.ascontiguousarray(hg[f]).view(np.uint32) != np.ascontiguousarray(ho[f]).view(np.uint32)).reshape(n, -1).any(axis=1)
     regular_differs = int((rec_differs & ~degenerate).sum())
-    ok = regular_differs == 0 and more == 0
+    fewer = int((hg["node_tests"] < ho["node_tests"]).sum())
+    tri_differs = int((hg["tri_tests"] != ho["tri_tests"]).sum())
+    # since round 3 crh_trace_rays follows the reference's NaN slab arithmetic literally (CRH_TRACE_SLABS_LITERAL): every ray — degenerate or not — must
+    # give the reference's record and its node / triangle test counts
+    ok = not rec_differs.any() and more == 0 and fewer == 0 and tri_differs == 0
     bad += 0 if ok else 1
     if a.dump and not ok:
         np.save(os.path.join(a.dump, f"rays_{seed}.npy"), rays); np.save(os.path.join(a.dump, f"emu_{seed}.npy"), hg); np.save(os.path.join(a.dump, f"oracle_{seed}.npy"), ho)

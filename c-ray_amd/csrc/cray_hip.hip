@@ -1530,6 +1530,11 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
 	c->hasVolumes = cs.has_volumes;
 	c->haveScene = true;
+	/* The copies above went through the NULL stream from pageable memory: hipMemcpy returns once the data is in the runtime's staging buffers, the DMA may
+	 * still be running — and the context's stream is non-blocking, so synchronizing IT does not wait for them (measured in round 3: the first dispatch's
+	 * kernel started 11-25 ms after its launch, behind the tail of these copies; until then a blocking device-to-host copy of the watchdog flag in
+	 * crh_synchronize had been the accidental barrier). The scene is resident when this function returns. */
+	HIP_TRY(hipDeviceSynchronize());
 	return preloadKernel(c);
 }
 

@@ -49,10 +49,21 @@ static void *gpuWorkerThread(void *arg) {
 	crh_scene_desc scene;
 	crh_ctx *ctx = NULL;
 	float *fb = NULL;
-	if (crh_flatten_world(r, &scene) != CRH_OK) logr(error, "c-ray-hip --worker: the scene cannot be flattened for the GPU\n");
+	/* A GPU that cannot be set up, or that fails in the middle of the job, ends THIS thread only (threadComplete): the tiles it held are re-issued by the
+	 * master once its queue is empty (tile.c:33-42) and rendered by the other GPUs / workers. logr(error) would exit the whole worker with them. */
+	if (crh_flatten_world(r, &scene) != CRH_OK) {
+		logr(warning, "c-ray-hip --worker: the scene cannot be flattened for the GPU\n");
+		threadState->threadComplete = true;
+		return 0;
+	}
 	if (crh_context_create(threadState->thread_num, NULL, &ctx) != CRH_OK || crh_set_option(ctx, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK ||
-		crh_scene_upload(ctx, &scene) != CRH_OK || crh_framebuffer_alloc(ctx, W, H, &fb) != CRH_OK)
-		logr(error, "c-ray-hip --worker: GPU %i: %s\n", threadState->thread_num, crh_last_error());
+		crh_scene_upload(ctx, &scene) != CRH_OK || crh_framebuffer_alloc(ctx, W, H, &fb) != CRH_OK) {
+		logr(warning, "c-ray-hip --worker: GPU %i: %s\n", threadState->thread_num, crh_last_error());
+		if (ctx) crh_context_destroy(ctx);
+		crh_flatten_free(&scene);
+		threadState->threadComplete = true;
+		return 0;
+	}
 	crh_render_params p;
 	memset(&p, 0, sizeof(p));
 	p.image_width = W; p.image_height = H;
@@ -68,10 +79,17 @@ static void *gpuWorkerThread(void *arg) {
 	threadState->completedSamples = 1;
 	while (more && r->state.isRendering && !r->state.renderAborted) {
 		int n = 0;
-		lockMutex(sockMutex);
-		while (n < batchMax) {
+		int want = batchMax;
+		while (n < want) {
+			/* one request per lock: the statistics sender and the other GPUs' threads of this worker get their turn in between */
+			lockMutex(sockMutex);
 			struct renderTile t = getWork(sock);
+			releaseMutex(sockMutex);
 			if (t.tileNum == -1) { more = false; break; }
+			/* tiles leave the master's queue in list order (tile.c:22-45), so a first-issue tile's number says how many are left: near the end
+			 * of the frame a batch takes a quarter of them at most, and the other workers are not left idle while this one holds the tail */
+			const int left = r->state.tileCount - 1 - t.tileNum;
+			if (left / 4 + 1 < want - n) want = n + left / 4 + 1;
 			/* once its queue is empty the master re-issues network tiles that are not back yet (tile.c:33-42) — i.e. the ones of this very
 			 * batch: such a tile ends the batch (it is already in it; rendering it twice in one dispatch would race on its pixels) */
 			bool mine = false;
@@ -81,10 +99,11 @@ static void *gpuWorkerThread(void *arg) {
 			rects[n] = (crh_tile){t.begin.x, t.begin.y, t.end.x, t.end.y};
 			++n;
 		}
-		releaseMutex(sockMutex);
 		if (n == 0) break;
-		if (crh_render_tiles(ctx, &p, rects, (uint32_t)n, fb) != CRH_OK || crh_synchronize(ctx) != CRH_OK)
-			logr(error, "c-ray-hip --worker: GPU %i: %s\n", threadState->thread_num, crh_last_error());
+		if (crh_render_tiles(ctx, &p, rects, (uint32_t)n, fb) != CRH_OK || crh_synchronize(ctx) != CRH_OK) {
+			logr(warning, "c-ray-hip --worker: GPU %i: %s\n", threadState->thread_num, crh_last_error());
+			break;                                     /* the batch is never submitted: the master re-issues its tiles */
+		}
 		threadState->completedSamples = r->prefs.sampleCount;
 		for (int i = 0; i < n; ++i) {
 			const struct renderTile tile = tiles[i];
@@ -92,8 +111,11 @@ static void *gpuWorkerThread(void *arg) {
 			const int storedRow0 = H - tile.end.y, nrows = tile.end.y - tile.begin.y;
 			const size_t need = (size_t)nrows * W * 3;
 			if (need > rowsCap) { free(rows); rows = malloc(need * sizeof(float)); rowsCap = need; }
-			if (crh_framebuffer_download(ctx, fb + (size_t)storedRow0 * W * 3, W, nrows, rows) != CRH_OK)
-				logr(error, "c-ray-hip --worker: download: %s\n", crh_last_error());
+			if (crh_framebuffer_download(ctx, fb + (size_t)storedRow0 * W * 3, W, nrows, rows) != CRH_OK) {
+				logr(warning, "c-ray-hip --worker: download: %s\n", crh_last_error());
+				more = false;
+				break;
+			}
 			struct texture *tileBuffer = newTexture(char_p, tile.width, tile.height, 3);
 			for (int y = tile.end.y - 1; y > tile.begin.y - 1; --y) {
 				for (int x = tile.begin.x; x < tile.end.x; ++x) {

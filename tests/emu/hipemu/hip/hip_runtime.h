@@ -229,6 +229,7 @@ const char *hipGetErrorString(hipError_t e);
 hipError_t hipGetLastError(void);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int device);
+hipError_t hipDeviceSynchronize(void);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device);
 hipError_t hipMalloc(void **p, size_t bytes);
 template <class T> static inline hipError_t hipMalloc(T **p, size_t bytes) { return hipMalloc((void **)p, bytes); }

@@ -304,6 +304,7 @@ hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t) { ret
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { if (!s) return hipErrorInvalidValue; *s = new hipemu_stream{0}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { if (!e) return hipErrorInvalidValue; *e = new hipemu_event{{}, false}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

@@ -1334,6 +1334,18 @@ static int preloadKernel(crh_ctx *c) {
 	}
 	const int key = variantKey(c);
 	if (std::find(c->preloaded.begin(), c->preloaded.end(), key) != c->preloaded.end()) return CRH_OK;      /* crh_context_prepare has been here */
+	{   /* the copy paths a dispatch uses — pinned host -> device (its tile list) and back — are set up by the runtime on first use (measured: the first
+		 * dispatch's kernel started 7-15 ms after its launch, behind its own 64-byte tile list): first use is here */
+		crh_ctx::TileSlot &ts = c->tileSlots[0];
+		if (!ts.dev) {
+			HIP_TRY(hipMalloc(&ts.dev, 4096));
+			HIP_TRY(hipHostMalloc(&ts.host, 4096, hipHostMallocDefault));
+			ts.cap = 4096;
+			memset(ts.host, 0, 4096);
+		}
+		HIP_TRY(hipMemcpyAsync(ts.dev, ts.host, 64, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(ts.host, ts.dev, 64, hipMemcpyDeviceToHost, c->stream));
+	}
 	HIP_TRY(hipMemsetAsync(c->dWork, 0, sizeof(uint32_t), c->stream));
 	const hipError_t e = launchPathtrace(c, 1, &P, Q, nullptr, 1);
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("kernel preload: ") + hipGetErrorString(e));
@@ -1530,12 +1542,15 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
 	c->hasVolumes = cs.has_volumes;
 	c->haveScene = true;
-	/* The copies above went through the NULL stream from pageable memory: hipMemcpy returns once the data is in the runtime's staging buffers, the DMA may
-	 * still be running — and the context's stream is non-blocking, so synchronizing IT does not wait for them (measured in round 3: the first dispatch's
-	 * kernel started 11-25 ms after its launch, behind the tail of these copies; until then a blocking device-to-host copy of the watchdog flag in
-	 * crh_synchronize had been the accidental barrier). The scene is resident when this function returns. */
-	HIP_TRY(hipDeviceSynchronize());
-	return preloadKernel(c);
+	/* The scene is resident, and the device has nothing left to do, when this function returns: a blocking device-to-host copy on the NULL stream ends the
+	 * set-up. Measured in round 3 (CRH_TRACE_SYNC): without it the first dispatch's kernel starts 7-25 ms after its launch — behind work the runtime
+	 * still owes the pageable host-to-device copies above, which neither hipStreamSynchronize on the context's (non-blocking) stream nor
+	 * hipDeviceSynchronize waits for; with it, 1-5 us. (Until round 3 the watchdog flag's copy in crh_synchronize was this barrier by accident.) */
+	rc = preloadKernel(c);
+	if (rc != CRH_OK) return rc;
+	unsigned int flag = 0;
+	HIP_TRY(hipMemcpy(&flag, c->dErr, sizeof(flag), hipMemcpyDeviceToHost));
+	return CRH_OK;
 }
 
 int crh_framebuffer_alloc(crh_ctx *c, int width, int height, float **dev_out) {

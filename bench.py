@@ -250,6 +250,27 @@ def dropin_timing(workload):
                     "buffer's download and the host in between; mrays = rays / render_phase_ms. process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
 
 
+def dropin_iterative(workload, samples=129):
+    """c-ray-hip --iterative (renderThreadInteractive's replacement) on the same frame, `samples` - 1 passes: how busy the GPU stays while the host converts
+    to 8 bit on the device, downloads and redraws between dispatches of about 16 ms."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    exe = os.path.join(REPO, "c-ray_amd", "_lib", "c-ray-hip")
+    overlay = os.path.join(REPO, "oracle", "_ref", "input")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(overlay, workload["scene"] or "-"))):
+        return {"skipped": "c-ray-hip or the asset overlay is not built"}
+    import refrun
+    with tempfile.TemporaryDirectory() as tmp:
+        scene = refrun.rewrite_scene(workload["scene"], workload["width"], workload["height"], samples, workload["bounces"], tile=workload["tile"], out_dir=tmp)
+        stats = os.path.join(tmp, "stats.json")
+        proc = subprocess.run([exe, "--iterative"], input=json.dumps(scene).encode(), cwd=overlay, env=dict(os.environ, CRH_DUMP_STATS=stats, CRAY_HIP_DEVICES="1"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        if proc.returncode != 0 or not os.path.exists(stats):
+            return {"failed": proc.stdout.decode(errors="replace")[-300:]}
+        return json.load(open(stats))
+
+
 def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0, frames=None):
     """Reference pthread renderer on the host cores, bounded sample of the same frame (reduced spp). `frames` (dict) receives the float frames the CPU
     side rendered — "strict" (the bit-exact restatement of c-ray-ref-strict) and "default" (c-ray-ref, upstream's default flags) — and their spp."""
@@ -440,6 +461,7 @@ def main():
             except Exception:
                 pass
             out["dropin"] = dropin_timing(WORKLOAD)
+            out["dropin_iterative"] = dropin_iterative(WORKLOAD)
             if isinstance(out["dropin"].get("render_phase_ms"), (int, float)):
                 out["dropin"]["vs_bench_ms_per_step"] = round(out["dropin"]["render_phase_ms"] / ms_per_step, 3)
         if world == 1 and not a.no_others and a.workload == "cfg2" and SPP == WORKLOAD["samples"]:

@@ -3,8 +3,8 @@
  *
  * With -DCRH_GPU_BVH (the c-ray-hip host; NOT the oracle's crh-flatten, whose blobs must stay the reference's own
  * output) buildBottomLevelBvh() (bvh.c:299-301) is replaced by the GPU builder behind crh_bvh_build_triangles()
- * (SURVEY.md 8(f) row 1): same struct bvh out, same tree bit for bit, one mutex because the reference builds every
- * mesh on its own thread (scene.c:50-78) and a crh_ctx belongs to one thread at a time. The reference's function
+ * (SURVEY.md 8(f) row 1): same struct bvh out, same tree bit for bit; builder threads (the reference builds every mesh on its
+ * own, scene.c:50-78) borrow a context from a small pool. The reference's function
  * stays in the object under another name; nothing calls it. */
 #ifdef CRH_GPU_BVH
 #define buildBottomLevelBvh crh_reference_buildBottomLevelBvh
@@ -25,8 +25,48 @@ _Static_assert(sizeof(struct bvhNode) == sizeof(crh_bvh_node), "crh_bvh_node mus
 #include "utils/logging.h"
 _Static_assert(sizeof(struct poly) == sizeof(crh_poly), "crh_poly must mirror struct poly (40 B)");
 
+/* A small pool of builder contexts: the reference builds every mesh on its own thread (scene.c:50-78) and a crh_ctx belongs to one thread at a time, so a
+ * builder thread borrows a free context (each has its own stream and scratch: uploads, builds and downloads of different meshes overlap) or waits for one.
+ * Created on first use, destroyed when the process exits. */
+#define CRH_BVH_POOL 4
 static pthread_mutex_t g_bvh_lock = PTHREAD_MUTEX_INITIALIZER;
-static crh_ctx *g_bvh_ctx;
+static pthread_cond_t g_bvh_free = PTHREAD_COND_INITIALIZER;
+static struct { crh_ctx *ctx; int busy; } g_bvh_pool[CRH_BVH_POOL];
+static int g_bvh_exit_hooked;
+
+static void bvhPoolDestroy(void) {
+	pthread_mutex_lock(&g_bvh_lock);
+	for (int i = 0; i < CRH_BVH_POOL; ++i)
+		if (g_bvh_pool[i].ctx && !g_bvh_pool[i].busy) { crh_context_destroy(g_bvh_pool[i].ctx); g_bvh_pool[i].ctx = NULL; }
+	pthread_mutex_unlock(&g_bvh_lock);
+}
+
+/* a free builder context (index in *slot), created if the pool has room; NULL + rc if the device cannot give one and none exists to wait for */
+static crh_ctx *bvhPoolAcquire(int *slot, int *rc) {
+	pthread_mutex_lock(&g_bvh_lock);
+	if (!g_bvh_exit_hooked) { g_bvh_exit_hooked = 1; atexit(bvhPoolDestroy); }
+	for (;;) {
+		int empty = -1, existing = 0;
+		for (int i = 0; i < CRH_BVH_POOL; ++i) {
+			if (g_bvh_pool[i].ctx && !g_bvh_pool[i].busy) { g_bvh_pool[i].busy = 1; *slot = i; pthread_mutex_unlock(&g_bvh_lock); return g_bvh_pool[i].ctx; }
+			if (g_bvh_pool[i].ctx) ++existing;
+			else if (empty < 0) empty = i;
+		}
+		if (empty >= 0) {
+			crh_ctx *c = NULL;
+			*rc = crh_context_create(0, NULL, &c);
+			if (*rc == CRH_OK) { g_bvh_pool[empty].ctx = c; g_bvh_pool[empty].busy = 1; *slot = empty; pthread_mutex_unlock(&g_bvh_lock); return c; }
+			if (!existing) { pthread_mutex_unlock(&g_bvh_lock); return NULL; }
+		}
+		pthread_cond_wait(&g_bvh_free, &g_bvh_lock);
+	}
+}
+static void bvhPoolRelease(int slot) {
+	pthread_mutex_lock(&g_bvh_lock);
+	g_bvh_pool[slot].busy = 0;
+	pthread_cond_signal(&g_bvh_free);
+	pthread_mutex_unlock(&g_bvh_lock);
+}
 
 struct bvh *buildBottomLevelBvh(struct poly *polys, unsigned count) {
 	struct bvh *bvh = malloc(sizeof(*bvh));
@@ -48,13 +88,13 @@ struct bvh *buildBottomLevelBvh(struct poly *polys, unsigned count) {
 	memcpy(local, polys, sizeof(*local) * count);
 	for (unsigned i = 0; i < count; ++i)
 		for (int k = 0; k < 3; ++k) local[i].v[k] -= vmin;
-	pthread_mutex_lock(&g_bvh_lock);
-	int rc = CRH_OK;
-	if (!g_bvh_ctx) rc = crh_context_create(0, NULL, &g_bvh_ctx);
-	if (rc == CRH_OK)
-		rc = crh_bvh_build_triangles(g_bvh_ctx, local, count, (const float *)(g_vertices + vmin), (uint64_t)(vmax - vmin + 1),
+	int rc = CRH_OK, slot = -1;
+	crh_ctx *ctx = bvhPoolAcquire(&slot, &rc);
+	if (ctx) {
+		rc = crh_bvh_build_triangles(ctx, local, count, (const float *)(g_vertices + vmin), (uint64_t)(vmax - vmin + 1),
 		                             (crh_bvh_node *)bvh->nodes, bvh->primIndices, &bvh->nodeCount, NULL);
-	pthread_mutex_unlock(&g_bvh_lock);
+		bvhPoolRelease(slot);
+	}
 	free(local);
 	if (rc != CRH_OK) logr(error, "c-ray-hip: GPU BVH build failed (%i): %s\n", rc, crh_last_error());   /* exits: no CPU path here */
 	bvh->nodes = realloc(bvh->nodes, sizeof(struct bvhNode) * bvh->nodeCount);   /* bvh.c:283 */

@@ -3,6 +3,7 @@
  * pixel x pass loop (worker.c:138-217) a worker thread per GPU pulls BATCHES of tiles from the master with the file's own getWork(),
  * renders a batch with one crh_render_tiles() dispatch, and hands every tile back with the file's own submitWork() as the same 8-bit
  * sRGB tile texture the reference ships (protocol.c:102-114). The master cannot tell the difference: tiles are bit-identical.
+ * (CRH_WORKER_FLOAT_TILES=1 ships the linear float means instead — the second half of SURVEY 8(f) rank 3 — for masters that keep a float frame.)
  *
  * How the body is swapped without editing the reference: inside this TU `workerThread` is renamed (the reference's loop stays in the
  * object, unused) and `threadStart` is routed through a shim that replaces that thread function by the GPU one. Only c-ray-hip is
@@ -116,13 +117,17 @@ static void *gpuWorkerThread(void *arg) {
 				more = false;
 				break;
 			}
-			struct texture *tileBuffer = newTexture(char_p, tile.width, tile.height, 3);
+			/* CRH_WORKER_FLOAT_TILES=1: ship the tile's linear float means instead of 8-bit sRGB — the wire format carries either (protocol.c:102-127:
+			 * isFloatPrecision). Opt-in: the reference's own master pastes whatever it gets into its 8-bit output without the sRGB transform
+			 * (server.c:164-169), so it shows float tiles too dark; a master that keeps a float frame (the test's, a multi-node reduce) wants them. */
+			const bool floatTiles = getenv("CRH_WORKER_FLOAT_TILES") != NULL;
+			struct texture *tileBuffer = newTexture(floatTiles ? float_p : char_p, tile.width, tile.height, 3);
 			for (int y = tile.end.y - 1; y > tile.begin.y - 1; --y) {
 				for (int x = tile.begin.x; x < tile.end.x; ++x) {
 					const float *px = rows + ((size_t)(H - (y + 1) - storedRow0) * W + (size_t)x) * 3;
 					struct color output = {px[0], px[1], px[2], 0.0f};
 					setPixel(r->state.renderBuffer, output, x, y);
-					output = colorToSRGB(output);
+					if (!floatTiles) output = colorToSRGB(output);
 					setPixel(tileBuffer, output, x - tile.begin.x, y - tile.begin.y);
 				}
 			}

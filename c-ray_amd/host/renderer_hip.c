@@ -259,6 +259,9 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	p.image_width = W; p.image_height = H; p.max_passes = r->prefs.sampleCount; p.bounces = r->prefs.bounces;
 	int done = 0;
 	int chunk = 1;                                           /* the first preview after one pass; then as many passes per dispatch as take about a display refresh */
+	int dispatches = 0;
+	struct timeval loop;
+	startTimer(&loop);
 	while (done < passes && !r->state.renderAborted) {
 		if (chunk > passes - done) chunk = passes - done;
 		p.first_pass = done; p.pass_count = chunk;
@@ -271,6 +274,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 			if (ntiles[g] && refreshOutput(ctx[g], fb[g], W, H, output, tiles[g], ntiles[g], gpus, scratch) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
 		const double chunkMs = (double)getUs(tc) / 1e3;
 		done += chunk;
+		++dispatches;
 		r->state.finishedPasses = done + 1;
 		for (int g = 0; g < gpus; ++g) {
 			r->state.threadStates[g].completedSamples = done;
@@ -284,6 +288,21 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 		int next = msPerPass > 0.0 ? (int)(16.0 / msPerPass) : chunk;
 		if (next > 2 * chunk) next = 2 * chunk;              /* grow gently: the first passes' previews are the ones a user watches */
 		chunk = next < 1 ? 1 : (next > 256 ? 256 : next);
+	}
+	const long loopUs = getUs(loop);
+	/* CRH_DUMP_STATS: how busy the GPU was while the frame converged (kernel time of GPU 0 / wall time of the loop: launches, 8-bit downloads, redraws are the rest) */
+	const char *statsPath = getenv("CRH_DUMP_STATS");
+	if (statsPath) {
+		double kernelMs = 0.0;
+		float last = 0.0f;
+		uint64_t launches = 0;
+		crh_kernel_time_ms(ctx[0], &last, &kernelMs, &launches);
+		FILE *f = fopen(statsPath, "w");
+		if (f) {
+			fprintf(f, "{\"mode\": \"iterative\", \"gpus\": %d, \"width\": %d, \"height\": %d, \"passes\": %d, \"dispatches\": %d, \"loop_ms\": %.3f, \"kernel_ms\": %.3f, \"gpu_busy\": %.4f}\n",
+					gpus, W, H, done, dispatches, loopUs / 1e3, kernelMs, loopUs > 0 ? kernelMs / (loopUs / 1e3) : 0.0);
+			fclose(f);
+		}
 	}
 	/* the float buffer: once, at the end */
 	assembleFrame(ctx, fb, gpus, W, H);

@@ -549,14 +549,17 @@ def test_frame_renderer_on_torch_stream(pkg, ctx, manifest, golden_blob):
     assert not (np.abs(parts[0]) * np.abs(parts[1])).any()      # disjoint ownership
 
 
-def test_cluster_worker_renders_its_tiles_on_the_gpu(pkg, oracle, manifest, golden_ref):
+@pytest.mark.parametrize("float_tiles", [False, True], ids=["srgb8", "float"])
+def test_cluster_worker_renders_its_tiles_on_the_gpu(float_tiles, pkg, oracle, manifest, golden_ref):
     """`c-ray-hip --worker` is the reference's network worker (handshake, asset / scene transfer, tile protocol:
     src/utils/protocol/worker.c compiled unmodified) with its render threads replaced by one GPU dispatch thread. A minimal master in
     this test speaks the reference's wire protocol (networking.c:44-131 framing, server.c:45-52, 296-345, 148-175 messages): it syncs
     input/scene.json, hands out 32x32 tiles, and every 8-bit sRGB tile the worker submits must equal, byte for byte, that tile of the
     real reference's frame (golden fixture through colorToSRGB, renderer.c:294-300 = worker.c:176-181).
     (The reference's own master is not used: in v0.6.3 it pastes tiles with a row slip (server.c:166), dies of SIGPIPE when the worker
-    closes first, and corrupts its heap with -j 0; it is marked experimental upstream.)"""
+    closes first, and corrupts its heap with -j 0; it is marked experimental upstream.)
+    float: CRH_WORKER_FLOAT_TILES=1 — the same tiles as linear float means (protocol.c:102-127 carries isFloatPrecision): equal to the reference's
+    float buffer bit for bit."""
     import base64
     import json
     import os
@@ -612,7 +615,8 @@ def test_cluster_worker_renders_its_tiles_on_the_gpu(pkg, oracle, manifest, gold
     tiles = pkg.tiles.quantize_image(w, h, 32, 32, pkg.tiles.ORDER_FROM_MIDDLE)
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    worker = subprocess.Popen([gpu_worker, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1", **dropin_env()),
+    extra = {"CRH_WORKER_FLOAT_TILES": "1"} if float_tiles else {}
+    worker = subprocess.Popen([gpu_worker, "--worker", str(port)], cwd=overlay, env=dict(os.environ, CRAY_HIP_DEVICES="1", **extra, **dropin_env()),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     got = {}
     try:
@@ -647,8 +651,8 @@ def test_cluster_worker_renders_its_tiles_on_the_gpu(pkg, oracle, manifest, gold
                     send(sock, {"action": "renderComplete"})
             elif act == "submitWork":
                 t, r = req["tile"], req["result"]
-                assert not r["isFloatPrecision"] and r["channels"] == 3 and r["width"] == t["width"] and r["height"] == t["height"]
-                got[t["tileNum"]] = (t, np.frombuffer(base64.b64decode(r["data"]), np.uint8).reshape(r["height"], r["width"], 3))
+                assert bool(r["isFloatPrecision"]) == float_tiles and r["channels"] == 3 and r["width"] == t["width"] and r["height"] == t["height"]
+                got[t["tileNum"]] = (t, np.frombuffer(base64.b64decode(r["data"]), np.float32 if float_tiles else np.uint8).reshape(r["height"], r["width"], 3))
                 send(sock, {"action": "ok"})
             elif act == "stats":
                 pass
@@ -664,4 +668,5 @@ def test_cluster_worker_renders_its_tiles_on_the_gpu(pkg, oracle, manifest, gold
     for num, (t, px) in got.items():
         x0, y0, x1, y1 = tiles[num]
         assert (t["beginX"], t["beginY"], t["endX"], t["endY"]) == (x0, y0, x1, y1)
-        assert np.array_equal(px, expected8[h - y1:h - y0, x0:x1]), f"tile {num} {tiles[num]} differs from the reference's frame"
+        want = golden_ref("cfg1_scene")[h - y1:h - y0, x0:x1] if float_tiles else expected8[h - y1:h - y0, x0:x1]
+        assert np.array_equal(px.view(np.uint32) if float_tiles else px, want.view(np.uint32) if float_tiles else want), f"tile {num} {tiles[num]} differs from the reference's frame"

@@ -42,7 +42,7 @@ GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of 
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
     # the reference's own program with renderer.c replaced (c-ray-hip: its main.c, JSON / OBJ loaders, encoders, renderer_hip.c, flatten.c, the GPU
     # BVH builder behind buildBottomLevelBvh) and its cluster worker, bound to the emulation library (LD_LIBRARY_PATH -> tests/emu/_dropin_libs): the drop-in boundary on the CPU
-    "dropin": (["test_gpu_parity.py"], "dropin_binary or cluster_worker", 2),
+    "dropin": (["test_gpu_parity.py"], "dropin_binary or cluster_worker", 3),
 }
 ROLL_FIXTURES = ["cfg1_scene", "refraction", "volumes", "nodezoo", "glowmetal"]
 

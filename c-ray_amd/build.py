@@ -9,6 +9,10 @@ hipcc cross-compiles without a GPU. Flags that matter for parity with the refere
 and one that matters for speed:
   -mllvm -disable-machine-licm                   the path-tracing kernel is one big loop; hoisting every loop-invariant constant and
                                                  address out of it keeps them live across everything: 87 -> 44 spilled VGPRs, +3..11 %
+  -fno-slp-vectorize                             the SLP vectoriser pairs float operations into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (350 of them in the
+                                                 bench kernel), and on gfx950 those are far slower than the two plain instructions they replace (measured in
+                                                 round 3: six v_pk_fma_f32 in the node step cost 19-30 %): without them +4..5.6 % on every workload, 29
+                                                 instead of 38 spilled VGPRs (profiles/r03h_ab_noslp.log); per-component IEEE results are the same
 The library has no CPU path: without a HIP device every entry point returns CRH_ERR_NO_DEVICE.
 """
 import os
@@ -27,7 +31,7 @@ C_SOURCES = [os.path.join(HERE, "host", "scene_blob.c")]
 DEPS = SOURCES + CXX_SOURCES + C_SOURCES + [os.path.join(CSRC, "pt_device.h"), os.path.join(CSRC, "exact_math.h"), os.path.join(CSRC, "scene_compile.h"), os.path.join(CSRC, "ctx_access.h"),
                               os.path.join(REPO, "include", "cray_hip.h"), os.path.abspath(__file__)]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize",
          "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 
 

@@ -30,7 +30,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     co = os.path.join(out, os.path.basename(src) + ".co")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-           "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-I" + os.path.join(REPO, "include"),
+           "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-I" + os.path.join(REPO, "include"),
            "-I" + os.path.join(REPO, "c-ray_amd", "csrc"), "--cuda-device-only", "--no-gpu-bundle-output", "-c", src, "-o", co] + extra
     if not os.environ.get("KREGS_REUSE"):
         subprocess.check_call(cmd)

@@ -4,7 +4,7 @@
 # Afterwards, here:  python tools/parse_prof.py TAG
 TAG=${1:-r01}
 WORKLOAD=${2:-cfg2}          # bench.py --workload; SAMPLES (env) = dev override for the long configs
-EXTRA="--workload $WORKLOAD --no-cpu --no-dropin ${SAMPLES:+--samples $SAMPLES}"
+EXTRA="--workload $WORKLOAD --no-cpu --no-dropin --no-others ${SAMPLES:+--samples $SAMPLES}"
 cd "$(dirname "$0")/.." || exit 1
 REPO=$(pwd)
 export TMPDIR=/tmp

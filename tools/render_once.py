@@ -23,7 +23,7 @@ sched = dict(node=70, tri=160, ctrl=120, swap_min=16, fill_to=160, run_num=4, tr
 if any(k in opts for k in sched):
     sched.update({k: v for k, v in opts.items() if k in sched})
     ctx.set_sched(**sched)
-ctx.upload(api.Scene(os.path.join(BUILT, name + ".blob")))
+ctx.upload(api.Scene(name if os.path.isabs(name) else os.path.join(BUILT, name + ".blob")))        # a name under scenes/_built, or an absolute path
 fb = ctx.framebuffer(w, h)
 ctx.reset_counters()
 ctx.render_region(fb, w, h, spp, b); ctx.synchronize()

@@ -16,7 +16,7 @@
  *   k_to_srgb8           colorToSRGB + setPixel truncation.
  * bvh_build.hip (same library): the reference's binned-SAH BVH builder on the GPU (crh_bvh_build_triangles).
  * No CPU fallback: every entry point fails with CRH_ERR_NO_DEVICE when there is no GPU.
- * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see c-ray_amd/build.py).
+ * Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -fno-slp-vectorize (see c-ray_amd/build.py).
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>

@@ -779,18 +779,9 @@ CRH_DEV float hwmin3(float a, float b, float c) { return fminf(fminf(a, b), c); 
 /* FAST = true: the caller knows the ray is regular (no zero / non-finite direction component: !(oct & CRH_RAY_SLOW)) */
 template <bool FAST = false>
 CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDist, float &tEntry) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CRH_EXP_PK_FMA)
-	/* the two slab parameters of an axis with one packed fma (v_pk_fma_f32: the same IEEE fma twice) */
-	typedef float crh_f2 __attribute__((ext_vector_type(2)));
-	const crh_f2 px = __builtin_elementwise_fma(crh_f2{n0.x, n0.y}, crh_f2{k.inv.x, k.inv.x}, crh_f2{k.ss.x, k.ss.x});
-	const crh_f2 py = __builtin_elementwise_fma(crh_f2{n0.z, n0.w}, crh_f2{k.inv.y, k.inv.y}, crh_f2{k.ss.y, k.ss.y});
-	const crh_f2 pz = __builtin_elementwise_fma(crh_f2{n1.x, n1.y}, crh_f2{k.inv.z, k.inv.z}, crh_f2{k.ss.z, k.ss.z});
-	const float xa = px.x, xb = px.y, ya = py.x, yb = py.y, za = pz.x, zb = pz.y;
-#else
 	const float xa = __builtin_fmaf(n0.x, k.inv.x, k.ss.x), xb = __builtin_fmaf(n0.y, k.inv.x, k.ss.x);
 	const float ya = __builtin_fmaf(n0.z, k.inv.y, k.ss.y), yb = __builtin_fmaf(n0.w, k.inv.y, k.ss.y);
 	const float za = __builtin_fmaf(n1.x, k.inv.z, k.ss.z), zb = __builtin_fmaf(n1.y, k.inv.z, k.ss.z);
-#endif
 	if (FAST || !(k.oct & CRH_RAY_SLOW)) {
 		const float tMin = hwmax3(hwmax(hwmin(xa, xb), hwmin(ya, yb)), hwmin(za, zb), 0.0f);
 		const float tMax = hwmin3(hwmin(hwmax(xa, xb), hwmax(ya, yb)), hwmax(za, zb), maxDist);
@@ -1026,13 +1017,8 @@ CRH_DEV void stepNodeLoaded(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port
 }
 template <bool FAST = true, class Stack, class Cnt, class Port>
 CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
-#ifdef CRH_EXP_ADDR          /* one address, three immediate offsets (32-bit index arithmetic may wrap, so the compiler cannot fold 2 n + 2 into the first address itself) */
-	const f4 *pair = S.nodes + (size_t)w.node * 2u;
-	const f4 l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
-#else
 	const uint32_t node = w.node;
 	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
-#endif
 	stepNodeLoaded<FAST>(S, w, stk, cnt, port, l0, l1, r0, r1);
 }
 
@@ -1058,15 +1044,8 @@ CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port)
 	const uint32_t slot = w.pA;
 	const bool two = slot + 1u < w.pAe;
 	const uint32_t slot2 = two ? slot + 1u : slot;
-#ifdef CRH_EXP_ADDR
-	const f4 *ta = S.tris + (size_t)slot * 3u;
-	const f4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
-	f4 b0 = a0, b1 = a1, b2 = a2;
-	if (two) { b0 = ta[3]; b1 = ta[4]; b2 = ta[5]; }          /* the second triangle of the pair is the next record; a single-triangle range asks the L1 for nothing more */
-#else
 	const f4 a0 = S.tris[3u * slot], a1 = S.tris[3u * slot + 1u], a2 = S.tris[3u * slot + 2u];
 	const f4 b0 = S.tris[3u * slot2], b1 = S.tris[3u * slot2 + 1u], b2 = S.tris[3u * slot2 + 2u];
-#endif
 	w.pA = slot2 + 1u;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
 	testTriangle(a0, a1, a2, slot, w, cnt);

@@ -29,7 +29,7 @@ def main():
     out = os.environ.get("KREGS_OUT", "/tmp/kregs")
     os.makedirs(out, exist_ok=True)
     co = os.path.join(out, os.path.basename(src) + ".co")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off",
            "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-I" + os.path.join(REPO, "include"),
            "-I" + os.path.join(REPO, "c-ray_amd", "csrc"), "--cuda-device-only", "--no-gpu-bundle-output", "-c", src, "-o", co] + extra
     if not os.environ.get("KREGS_REUSE"):

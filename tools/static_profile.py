@@ -12,7 +12,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 W = "/tmp/static_profile"
 os.makedirs(W, exist_ok=True)
 scene = sys.argv[1:6] or ["cfg2_hdr", "320", "180", "8", "8"]
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize",
+flags = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize",
          "-fPIC", "-I" + REPO + "/include", "-I" + REPO + "/c-ray_amd/csrc", "-DCRH_DEV_ONLY_BENCH_VARIANT", "-g", "--cuda-device-only", "--no-gpu-bundle-output"]
 co = W + "/dbg.co"
 if not os.environ.get("SP_REUSE"):

@@ -50,11 +50,32 @@ using namespace crh;
 #ifdef CRH_EXP_COOP_FETCH          /* measured slower in the real kernel (profiles/r03c_ab_coop_fetch.log): not in the default library */
 #define CRH_COOP_FETCH 1
 #endif
+/* Instance records in LDS (k_pathtrace; c-ray scenes are a handful of spheres and meshes): the workgroup stages line 0 of every record — what an instance
+ * VISIT reads: Ainv, kind, root, ray offset, radius — when the scene has at most CRH_INST_LDS0_MAX instances, and line 1 — what FINISHING a hit reads besides:
+ * A, material — when it has at most CRH_INST_LDS1_MAX; LdsStack::instLine serves them with ds_read_b128 instead of four divergent 16-byte look-ups in the
+ * vector L1 per lane and line (profiles/r03a_pmc_deep.txt: that unit is busy 93 % of the time; hdr.json visits 2.05 instances per ray and finishes a hit on
+ * 0.6 of them: a fifth of all its L1 look-ups). Measured against the same kernel without the tables (profiles/r03k_ab_inst_lds.log, d3 vs d4): hdr.json +4.5 %,
+ * statues.json (55 instances, 4.7 visits per ray) +3 %, venus.json +3 %, the 1 M soup +0.3 %. 8 KB of LDS: the three park slots the slab offsets no longer
+ * occupy (pt_device.h: PK_*) and five of the 23 traversal-stack entries (18 stay; deeper entries live in the global overflow columns — 18 / 21 / 24 / 26 entries
+ * measured equal). 0 / 0 = off. */
+#ifndef CRH_INST_LDS0_MAX
+#define CRH_INST_LDS0_MAX 64u
+#endif
+#ifndef CRH_INST_LDS1_MAX
+#define CRH_INST_LDS1_MAX 64u
+#endif
+#define CRH_INST_LDS_BYTES ((CRH_INST_LDS0_MAX + CRH_INST_LDS1_MAX) * 64u)
+/* Top-level BVH in LDS (-DCRH_TLAS_LDS=1, with the instance records: scenes with at most CRH_INST_LDS_MAX instances have at most 31 TLAS nodes = 1 KB): every
+ * ray starts with three or four node steps in that tiny tree, which always hit the L1 and still cost it four look-ups per lane each. */
+#ifndef CRH_TLAS_LDS
+#define CRH_TLAS_LDS 0
+#endif
+#define CRH_TLAS_LDS_NODES 32u
 #ifndef CRH_STACK_LDS
 #ifdef CRH_COOP_FETCH
 #define CRH_STACK_LDS 13         /* traversal stack entries kept in LDS per lane; with the 6 park slots, the fetch slabs, the id stacks and cursors: < 40 KB per block, 4 blocks per CU */
 #else
-#define CRH_STACK_LDS 23
+#define CRH_STACK_LDS ((40960 - 3968 - (int)CRH_INST_LDS_BYTES - CRH_TLAS_LDS * 1024) / 1024 - 10)     /* what the LDS holds after the id stacks, tables and park slots (18 with the default instance tables) */
 #endif
 #endif
 #define CRH_REC_STRIDE_WORDS 260u                          /* one slab = what one global_load_lds_dwordx4 writes (64 lanes x 16 B) + 16 B of skew: the four lanes of a quad
@@ -90,10 +111,36 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
 /* k_pathtrace: the overflow entries live in a per-wave column block of a global buffer (entry i of lane l at ovf[(i - CRH_STACK_LDS) * 64]
  * from the lane's own base: coalesced, and no private memory behind every lane for a depth real scenes almost never reach) */
+#if defined(__clang__)
+typedef float crh_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 ldsLoadF4(const lds_u32 *p) { const crh_v4f v = *(const __attribute__((address_space(3))) crh_v4f *)p; return f4{v.x, v.y, v.z, v.w}; }     /* ds_read_b128 */
+#else
+static inline f4 ldsLoadF4(const uint32_t *p) { f4 r; memcpy(&r, p, sizeof(r)); return r; }
+#endif
 struct LdsStack {
 	lds_u32 *lds;        /* &s_stack[threadIdx.x] */
 	lds_u32 *parkp;      /* &s_park[threadIdx.x]  */
 	glb_u32 *ovf;        /* wave-uniform: &ovfAll[wave * CRH_OVF_WORDS_PER_WAVE]; the lane's column starts at its lane index */
+#if CRH_TLAS_LDS
+	const lds_u32 *tlas; /* workgroup-uniform: the LDS copy of TLAS nodes 1 .. (8 words each), or null */
+	__device__ __forceinline__ bool tlasInLds() const { return tlas != nullptr; }
+	__device__ __forceinline__ void nodePair(const DScene &S, uint32_t node, f4 &l0, f4 &l1, f4 &r0, f4 &r1) const {
+		const lds_u32 *p = tlas + (node - S.tlas_first) * 8u;
+		l0 = ldsLoadF4(p); l1 = ldsLoadF4(p + 4); r0 = ldsLoadF4(p + 8); r1 = ldsLoadF4(p + 12);
+	}
+#endif
+#if CRH_INST_LDS_BYTES > 0
+	const lds_u32 *inst0, *inst1; /* workgroup-uniform: the LDS copies of the instance records' lines 0 / 1 (16 words per instance each), or null */
+	__device__ __forceinline__ InstLine instLine(const DScene &S, int32_t idx, int line) const {
+		const lds_u32 *t = line == 0 ? inst0 : inst1;
+		if (t) {
+			const lds_u32 *p = t + (uint32_t)idx * 16u;
+			return InstLine{ldsLoadF4(p), ldsLoadF4(p + 4), ldsLoadF4(p + 8), ldsLoadF4(p + 12)};
+		}
+		const f4 *g = (const f4 *)(S.instances + idx) + 4 * line;
+		return InstLine{g[0], g[1], g[2], g[3]};
+	}
+#endif
 	__device__ __forceinline__ void park(int i, uint32_t v) { parkp[i * CRH_BLOCK] = v; }
 	__device__ __forceinline__ uint32_t unpark(int i) { return parkp[i * CRH_BLOCK]; }
 	__device__ __forceinline__ void push(uint32_t i, uint32_t v) {
@@ -225,12 +272,6 @@ __device__ __forceinline__ uint32_t quadBcast(uint32_t v, int m) {
 #ifndef CRH_WAIT_VMEM             /* every vector-memory operation of the wave has completed (the LDS writes of global_load_lds among them); the emulation's loads are synchronous */
 #define CRH_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
-#if defined(__clang__)
-typedef float crh_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4 ldsLoadF4(const lds_u32 *p) { const crh_v4f v = *(const __attribute__((address_space(3))) crh_v4f *)p; return f4{v.x, v.y, v.z, v.w}; }     /* ds_read_b128 */
-#else
-static inline f4 ldsLoadF4(const uint32_t *p) { f4 r; memcpy(&r, p, sizeof(r)); return r; }
-#endif
 /* One 64-byte record per lane — base[fi .. fi + 4), fi = CRH_NONE for a lane that wants none — fetched by the QUADS of the wave: for each of the four members of a
  * quad in turn, its four lanes load one quarter each (64 contiguous bytes: one cache-line look-up per quad and instruction instead of four per lane), straight
  * into the wave's LDS slabs; then every lane reads its own record back. ALL 64 lanes must call it (a lane serves its quad's members even when it wants nothing). */
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32 + CRH_REC_WORDS_PER_WAVE * 4) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 	lds_u32 *const rec = (lds_u32 *)&s_rec[(threadIdx.x >> 6) * CRH_REC_WORDS_PER_WAVE];
 #else
-	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 + 256 + CRH_INST_LDS_BYTES + CRH_TLAS_LDS * CRH_TLAS_LDS_NODES * 32 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 #endif
 	const DScene S = globalize(Sarg);
 	CRH_EM_POW_TABLES_INIT();
@@ -289,6 +330,27 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		__syncthreads();
 	}
 	stk.ovf = (glb_u32 *)ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_OVF_WORDS_PER_WAVE;
+#if CRH_TLAS_LDS
+	__shared__ __attribute__((aligned(16))) uint32_t s_tlas[CRH_TLAS_LDS_NODES * 8u];
+	stk.tlas = nullptr;
+	if (S.tlas_node_count > 1u && S.tlas_node_count - 1u <= CRH_TLAS_LDS_NODES) {
+		for (uint32_t i = threadIdx.x; i < (S.tlas_node_count - 1u) * 8u; i += CRH_BLOCK) s_tlas[i] = ((const uint32_t *)(S.nodes + 2u * S.tlas_first))[i];
+		__syncthreads();
+		stk.tlas = (const lds_u32 *)s_tlas;
+	}
+#endif
+#if CRH_INST_LDS_BYTES > 0
+	__shared__ __attribute__((aligned(16))) uint32_t s_inst[CRH_INST_LDS_BYTES / 4u];
+	stk.inst0 = stk.inst1 = nullptr;
+	{
+		const bool st0 = S.instance_count <= CRH_INST_LDS0_MAX, st1 = S.instance_count <= CRH_INST_LDS1_MAX;
+		if (st0) for (uint32_t i = threadIdx.x; i < S.instance_count * 16u; i += CRH_BLOCK) s_inst[i] = ((const uint32_t *)(S.instances + (i >> 4)))[i & 15u];
+		if (st1) for (uint32_t i = threadIdx.x; i < S.instance_count * 16u; i += CRH_BLOCK) s_inst[CRH_INST_LDS0_MAX * 16u + i] = ((const uint32_t *)(S.instances + (i >> 4)))[16u + (i & 15u)];
+		if (st0 || st1) __syncthreads();
+		if (st0) stk.inst0 = (const lds_u32 *)s_inst;
+		if (st1) stk.inst1 = (const lds_u32 *)s_inst + CRH_INST_LDS0_MAX * 16u;
+	}
+#endif
 	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
 	const int passEnd = P.first_pass + P.pass_count;
 	/* the wave's path table, its id stacks and their wave-uniform fill levels (LDS: lane 0 writes, every lane reads; as
@@ -498,7 +560,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							const uint32_t item = asU32(q1.w);
 							TravHit h;
 							h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
-							(void)shadeCore(S, P, o, d, h, r, cnt);
+							(void)shadeCore(S, P, o, d, h, r, cnt, stk);
 							float *so = myStage + (size_t)item * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
 							ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - lane] = (uint8_t)id;
 						}
@@ -587,7 +649,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 							h.t = q4.x; h.u = q4.y; h.v = q4.z;
 							h.slot = (int32_t)asU32(q4.w); h.inst = (int32_t)asU32(q[5].x);
 							__builtin_assume(h.inst >= 0);
-							cont = shadeCore(S, P, o, d, h, r, cnt);
+							cont = shadeCore(S, P, o, d, h, r, cnt, stk);
 							done = !cont;
 							if (cont) putPathRay(q, o, d, r, item);
 							else {
@@ -1536,6 +1598,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(textures, cs.textures.data(), cs.textures.size());
 	UP(texels, cs.texels.data(), cs.texels.size());
 #undef UP
+	d.tlas_first = cs.tlas_first;
 	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base; d.shade_classes = cs.shade_classes; d.instance_count = (uint32_t)cs.instances.size();
 	d.background = cs.background; d.camera = cs.camera;
 	c->d = d;

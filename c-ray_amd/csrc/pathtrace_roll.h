@@ -61,6 +61,12 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	LdsStack stk;
 	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
 	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
+#if CRH_TLAS_LDS
+	stk.tlas = nullptr;
+#endif
+#if CRH_INST_LDS_BYTES > 0
+	stk.inst0 = stk.inst1 = nullptr;          /* this kernel form reads the instance records from global memory */
+#endif
 	CountersT<LEVEL, PROG> cnt;
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;

@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <float.h>
+#include <type_traits>
+#include <utility>
 #include "cray_hip.h"
 #include "exact_math.h"     /* sinf, cosf, tanf, powf, logf, log10f, atan2f, acosf, asinf with the host libm's bits (namespace crh::em) */
 
@@ -65,6 +67,7 @@ struct alignas(16) DInstance {
 	uint32_t material;    /* sphere: material index; mesh: material_base */
 	float    density;     /* volumes */
 };
+static_assert(sizeof(DInstance) == 128, "two 64-byte lines (InstLine)");
 
 /* Per BLAS prim slot, next to tris[]: what finishing a hit on that triangle needs, so that poly.c:37-48 + instance.c:150-167
  * read ONE 64-B record instead of prim index -> polygon -> three normals / three texture coordinates -> mesh. */
@@ -133,6 +136,7 @@ struct DScene {
 	uint32_t background;        /* gnode index of the background bsdf */
 	uint32_t shade_classes;     /* distinct shade classes among the instances (CRH_DINST_CLASS); <= 1: hits need no sorting */
 	uint32_t instance_count;    /* records in instances[] */
+	uint32_t tlas_first;        /* device index of the first TLAS node after the root (the TLAS nodes tlas_first .. tlas_first + tlas_node_count - 2 are contiguous) */
 	crh_camera camera;
 };
 
@@ -183,10 +187,13 @@ CRH_DEV v3 vneg(v3 v) { return v3{-v.x, -v.y, -v.z}; }
 CRH_DEV v3 vreflect(v3 I, v3 N) { return vsub(I, vscale(N, vdot(N, I) * 2.0f)); }
 CRH_DEV float wrapMax(float x, float mx) { return fmodf(mx + fmodf(x, mx), mx); }
 CRH_DEV float wrapMinMax(float x, float mn, float mx) { return mn + wrapMax(x - mn, mx - mn); }
-/* wrapMinMax(x, 0, 1) (vector.h:215-221) without the two fmodf for the common 0 <= x < 1: fmodf(x, 1) = x exactly,
- * 1 + x rounds once into [1, 2], and fmodf(that, 1) is exact (that - 1, or 0 when the sum rounded up to 2). Same bits. */
+/* wrapMinMax(x, 0, 1) (vector.h:215-221) without the two fmodf for -1 <= x < 1 (every texture coordinate the shipped scenes produce; an fmodf is
+ * ~150 instructions, and half of all background look-ups have a negative v). 0 <= x < 1: fmodf(x, 1) = x exactly, 1 + x rounds once into [1, 2], and
+ * fmodf(that, 1) is exact (that - 1, or 0 when the sum rounded up to 2). -1 <= x < 0: fmodf(x, 1) = x again (-0 for x = -1), 1 + x rounds once into
+ * [0, 1], and fmodf(that, 1) is that, or 0 when the sum rounded up to 1. Same bits (tests/test_exact_math.py: every float of both ranges). */
 CRH_DEV float wrap01(float x) {
 	if (x >= 0.0f && x < 1.0f) { const float y = 1.0f + x; return 0.0f + (y < 2.0f ? y - 1.0f : 0.0f); }
+	if (x >= -1.0f && x < 0.0f) { const float y = 1.0f + x; return 0.0f + (y < 1.0f ? y : 0.0f); }
 	return wrapMinMax(x, 0.0f, 1.0f);
 }
 CRH_DEV float rmin(float a, float b) { return a < b ? a : b; }     /* includes.h:20 */
@@ -367,6 +374,50 @@ CRH_DEV v3 xfVectorT(v3 v, const float *m) {
 }
 CRH_DEV v3 alongRay(v3 o, v3 d, float t) { return vadd(o, vscale(d, t)); }   /* lightray.h:31 */
 
+/* ---- instance records: one 64-byte LINE at a time -------------------------------------------------
+ * Line 0 = what entering an instance needs (Ainv rows, then kind / root / ray_offset / radius), line 1 = what finishing a hit needs (A rows,
+ * then orig / poly_base / material / density). The lines come from the scene's array in global memory — or from wherever the caller's
+ * "hot table source" keeps a copy: k_pathtrace stages the records of scenes with few instances in LDS (cray_hip.hip: LdsStack::instLine;
+ * the vector L1 is the walk's scarcest resource, and an instance visit is four 16-byte look-ups per lane that always hit the same few lines).
+ * A source is any object with instLine(S, idx, line); everything else (host emulation, crh_trace_rays, the other kernel forms) reads global memory. */
+struct InstLine { f4 a, b, c, d; };
+CRH_DEV uint32_t instKind(const InstLine &l0) { return asU32(l0.d.x); }
+CRH_DEV uint32_t instRoot(const InstLine &l0) { return asU32(l0.d.y); }
+CRH_DEV float instRayOffset(const InstLine &l0) { return l0.d.z; }
+CRH_DEV float instRadius(const InstLine &l0) { return l0.d.w; }
+CRH_DEV uint32_t instOrig(const InstLine &l1) { return asU32(l1.d.x); }
+CRH_DEV uint32_t instPolyBase(const InstLine &l1) { return asU32(l1.d.y); }
+CRH_DEV uint32_t instMaterial(const InstLine &l1) { return asU32(l1.d.z); }
+CRH_DEV float instDensity(const InstLine &l1) { return l1.d.w; }
+struct GlobalTables {};          /* "no hot tables": every record comes from global memory */
+template <class T, class = void> struct has_inst_line : std::false_type {};
+template <class T> struct has_inst_line<T, std::void_t<decltype(std::declval<const T &>().instLine(std::declval<const DScene &>(), 0, 0))>> : std::true_type {};
+template <class Src>
+CRH_DEV InstLine instLine(const DScene &S, const Src &src, int32_t idx, int line) {
+	if constexpr (has_inst_line<Src>::value) return src.instLine(S, idx, line);
+	else {
+		(void)src;
+		const f4 *g = (const f4 *)(S.instances + idx) + 4 * line;
+		return InstLine{g[0], g[1], g[2], g[3]};
+	}
+}
+/* transforms.c:76-116 on the three rows of a line (the same operations in the same order as xfPoint / xfVector / xfVectorT on float[12]) */
+CRH_DEV v3 xfPoint(v3 v, const InstLine &m) {
+	return v3{(m.a.x * v.x) + (m.a.y * v.y) + (m.a.z * v.z) + m.a.w,
+			  (m.b.x * v.x) + (m.b.y * v.y) + (m.b.z * v.z) + m.b.w,
+			  (m.c.x * v.x) + (m.c.y * v.y) + (m.c.z * v.z) + m.c.w};
+}
+CRH_DEV v3 xfVector(v3 v, const InstLine &m) {
+	return v3{(m.a.x * v.x) + (m.a.y * v.y) + (m.a.z * v.z),
+			  (m.b.x * v.x) + (m.b.y * v.y) + (m.b.z * v.z),
+			  (m.c.x * v.x) + (m.c.y * v.y) + (m.c.z * v.z)};
+}
+CRH_DEV v3 xfVectorT(v3 v, const InstLine &m) {
+	return v3{(m.a.x * v.x) + (m.b.x * v.y) + (m.c.x * v.z),
+			  (m.a.y * v.x) + (m.b.y * v.y) + (m.c.y * v.z),
+			  (m.a.z * v.x) + (m.b.z * v.y) + (m.c.z * v.z)};
+}
+
 /* ---- camera.c:46-87 ---------------------------------------------------------------------------- */
 CRH_DEV float triangleDistribution(float v) {
 	const float orig = v * 2.0f - 1.0f;
@@ -450,10 +501,15 @@ CRH_DEV rgba evalImage(const TexCtx S, const DImage im, v2 uv, Cnt &cnt) {
 		out = textureGetPixelFiltered(S, t, uv.x, uv.y, cnt);
 	}
 	if (im.options & CRH_IMAGE_SRGB_TRANSFORM) {       /* color.h:66-73 on r, g, b: the channels rotate through ONE inlined powf */
+		/* a grey sample (the three channels hold the same bits: grids, masks, most of a typical albedo map's filtered texels) is transformed once —
+		 * the same function of the same bits — instead of three times: an exact powf is ~140 instructions of mostly double arithmetic */
+		const bool grey = asU32(out.r) == asU32(out.g) && asU32(out.g) == asU32(out.b);
+		const int n = grey ? 1 : 3;
 #if defined(__HIPCC__)
 #pragma clang loop unroll(disable)
 #endif
-		for (int i = 0; i < 3; ++i) { const float t = SRGBToLinear(out.r); out.r = out.g; out.g = out.b; out.b = t; }
+		for (int i = 0; i < n; ++i) { const float t = SRGBToLinear(out.r); out.r = out.g; out.g = out.b; out.b = t; }
+		if (grey) { out.r = out.b; out.g = out.b; }
 	}
 	return out;
 }
@@ -647,47 +703,39 @@ CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &re
 		if (kind == CRH_BSDF_METAL || kind == CRH_BSDF_GLASS || kind == CRH_BSDF_EMISSION) vb = evalValue(S, n.b, rec, cnt);
 		rgba col = rgba{0.0f, 0.0f, 0.0f, 0.0f};      /* the colour operand: a, for the plastic coat its roughness b (plastic.c:68) */
 		if (kind >= CRH_BSDF_DIFFUSE && kind <= CRH_BSDF_ISOTROPIC) col = evalColor(S, kind == CRH_BSDF_PLASTIC ? n.b : n.a, rec, cnt);
-		switch (kind) {
-			case CRH_BSDF_PLASTIC: {      /* plastic.c:66-72: the reflecting coat */
-				v3 reflected = vreflect(rec.dir, rec.normal);
-				const float roughness = col.r;
-				if (roughness > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), roughness));
-				res.out = reflected;
-				col = rgba{1.0f, 1.0f, 1.0f, 1.0f};
-				break;
+		/* The outgoing direction. A batch of hits runs the union of its lanes' code, so what several kinds compute is computed at ONE site each
+		 * (round 3: randomOnUnitSphere was inlined six times, vnorm four times, vreflect three times): the random unit vector — the first draw of
+		 * every kind that uses it, so the sampler's order is the reference's —, one normalisation, one reflection. Per kind:
+		 *   plastic coat (plastic.c:66-72)  reflect(dir, n) [+ sphere * roughness]                colour white
+		 *   diffuse      (diffuse.c:40-47)  norm(n + sphere)
+		 *   metal        (metal.c:40-55)    reflect(norm(dir), n) [+ sphere * roughness]
+		 *   glass        (glass.c:41-87)    reflect(dir, n) [+ fuzz] or refracted [+ fuzz], fuzz = sphere * roughness, chosen by one more draw
+		 *   transparent  (transparent.c:40-44) dir
+		 *   emission     (emission.c:42-49) norm(n + sphere)                                       colour * strength
+		 *   isotropic    (isotropic.c:40-47) norm(sphere) */
+		const bool lambert = kind == CRH_BSDF_DIFFUSE || kind == CRH_BSDF_EMISSION, iso = kind == CRH_BSDF_ISOTROPIC;
+		const bool mirror = kind == CRH_BSDF_PLASTIC || kind == CRH_BSDF_METAL || kind == CRH_BSDF_GLASS;
+		const float rough = kind == CRH_BSDF_PLASTIC ? col.r : vb;         /* read by the mirror kinds only */
+		const bool fuzzy = mirror && rough > 0.0f;
+		v3 sph = v3{0.0f, 0.0f, 0.0f};
+		if (lambert || iso || fuzzy) sph = randomOnUnitSphere(rng);
+		v3 unit = v3{0.0f, 0.0f, 0.0f};
+		if (lambert || iso || kind == CRH_BSDF_METAL) unit = vnorm(kind == CRH_BSDF_METAL ? rec.dir : (lambert ? vadd(rec.normal, sph) : sph));
+		res.out = unit;                                                    /* diffuse, emission, isotropic */
+		if (mirror) {
+			v3 reflected = vreflect(kind == CRH_BSDF_METAL ? unit : rec.dir, rec.normal);
+			if (fuzzy) {
+				const v3 fuzz = vscale(sph, rough);
+				reflected = vadd(reflected, fuzz);
+				refracted = vadd(refracted, fuzz);                         /* (glass; dead otherwise) */
 			}
-			case CRH_BSDF_DIFFUSE:        /* diffuse.c:40-47 */
-				res.out = vnorm(vadd(rec.normal, randomOnUnitSphere(rng)));
-				break;
-			case CRH_BSDF_METAL: {        /* metal.c:40-55 */
-				v3 reflected = vreflect(vnorm(rec.dir), rec.normal);
-				if (vb > 0.0f) reflected = vadd(reflected, vscale(randomOnUnitSphere(rng), vb));
-				res.out = reflected;
-				break;
-			}
-			case CRH_BSDF_GLASS: {        /* glass.c:41-87 */
-				v3 reflected = vreflect(rec.dir, rec.normal);
-				if (vb > 0.0f) {
-					v3 fuzz = vscale(randomOnUnitSphere(rng), vb);
-					reflected = vadd(reflected, fuzz);
-					refracted = vadd(refracted, fuzz);
-				}
-				res.out = (getDimension(rng) < reflectionProbability) ? reflected : refracted;
-				break;
-			}
-			case CRH_BSDF_TRANSPARENT:    /* transparent.c:40-44 */
-				res.out = rec.dir;
-				break;
-			case CRH_BSDF_EMISSION:       /* emission.c:42-49 */
-				res.out = vnorm(vadd(rec.normal, randomOnUnitSphere(rng)));
-				col = ccoef(vb, col);
-				break;
-			case CRH_BSDF_ISOTROPIC:      /* isotropic.c:40-47 */
-				res.out = vnorm(randomOnUnitSphere(rng));
-				break;
-			default:                      /* background as a surface bsdf never happens; unknown kinds are rejected at upload */
-				break;
+			res.out = reflected;
+			if (kind == CRH_BSDF_GLASS) res.out = (getDimension(rng) < reflectionProbability) ? reflected : refracted;
 		}
+		if (kind == CRH_BSDF_TRANSPARENT) res.out = rec.dir;
+		if (kind == CRH_BSDF_PLASTIC) col = rgba{1.0f, 1.0f, 1.0f, 1.0f};
+		if (kind == CRH_BSDF_EMISSION) col = ccoef(vb, col);
+		/* (background as a surface bsdf never happens; unknown kinds are rejected at upload) */
 		res.r = col.r; res.g = col.g; res.b = col.b;
 		/* unwind pending add frames */
 		for (;;) {
@@ -843,7 +891,9 @@ struct TravHit {
 #define CRH_PARK_FULL 1        /* (measured: the recomputation costs 2-6 %, profiles/r03c_ab_coop_fetch.log) */
 #endif
 #ifdef CRH_PARK_FULL
-enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_SX, PK_SY, PK_SZ, PK_OCT, CRH_PARK_SLOTS };
+/* (the slab offsets ss = -(o * inv) are not parked: three multiplications and three negations of parked values give the same bits back, and the
+ * three LDS words per lane they occupied until round 3 — 3 KB per workgroup — now hold the instance records, cray_hip.hip: CRH_INST_LDS0_MAX) */
+enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_OCT, CRH_PARK_SLOTS };
 #else
 enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, CRH_PARK_SLOTS };
 #endif
@@ -895,7 +945,6 @@ CRH_DEV bool sphereTest(const v3 o, const v3 d, float radius, float bound, float
  * behind it (true: the lane keeps walking); exit walk found the far side -> sample the free flight; anything else -> no hit. */
 template <class Stack, class Cnt, class Port>
 CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
-	(void)stk;
 	const bool found = w.instFound != 0u;
 	const float tWalk = w.hit.t;
 	if (found) {      /* both walks ran on a copy of the record: the closest hit so far comes back */
@@ -904,19 +953,19 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 	w.instFound = 0;
 	if (w.inBlas == BLAS_VOL_ENTRY && found) {
 		port.save(VP_T1, asU32(tWalk));
-		const DInstance *inst = &S.instances[w.curInst];
+		const InstLine inst = instLine(S, stk, w.curInst, 0);
 		const v3 d = w.k.d;
 		{ const uint32_t lit = w.k.oct & CRH_RAY_LITERAL; w.k = makeRayK(alongRay(w.k.o, d, tWalk + 0.0001f), d); w.k.oct |= lit; }
 		w.inBlas = BLAS_VOL_EXIT;
 		w.pA = w.pAe = w.pB = w.pBe = 0;
 		w.node = CRH_NONE;
-		if (CRH_DINST_KIND(inst->kind) == CRH_DINST_MESH_LEAF) {                  /* bvh.c:382-387 */
-			const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
+		if (CRH_DINST_KIND(instKind(inst)) == CRH_DINST_MESH_LEAF) {                  /* bvh.c:382-387 */
+			const f4 n0 = S.nodes[2u * instRoot(inst)], n1 = S.nodes[2u * instRoot(inst) + 1u];
 			float tE;
 			CRH_COUNT(cnt, node_tests, 1);
 			if (intersectNode(n0, n1, w.k, w.hit.t, tE)) { w.pA = CRH_DNODE_FIRST(n1); w.pAe = w.pA + CRH_DNODE_COUNT(n1); }
 		} else {
-			w.node = inst->root;
+			w.node = instRoot(inst);
 		}
 		if (w.pA != w.pAe) { w.phase = PH_TRI; return true; }
 		if (w.node != CRH_NONE) { w.phase = (w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE; return true; }
@@ -926,7 +975,7 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 		float t1 = asF32(port.load(VP_T1));
 		if (t1 < 0.0f) t1 = 0.0f;
 		const float distanceInsideVolume = tWalk;
-		const float hitDistance = -(1.0f / S.instances[w.curInst].density) * em::logf_(port.draw());
+		const float hitDistance = -(1.0f / instDensity(instLine(S, stk, w.curInst, 1))) * em::logf_(port.draw());
 		if (hitDistance < distanceInsideVolume) {
 			w.hit.t = t1 + hitDistance; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -2; w.hit.inst = w.curInst;
 			CRH_COUNT(cnt, inst_hits, 1);
@@ -953,7 +1002,7 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	w.k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
 	w.k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
 	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
-	w.k.ss = v3{asF32(stk.unpark(PK_SX)), asF32(stk.unpark(PK_SY)), asF32(stk.unpark(PK_SZ))};
+	w.k.ss = vscale(vmul(w.k.o, w.k.inv), -1.0f);                    /* makeRayK's own expression on the same values */
 	w.k.oct = stk.unpark(PK_OCT);
 #else
 	{
@@ -1015,10 +1064,19 @@ CRH_DEV void stepNodeLoaded(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port
 	w.node = (inL && inR) ? (swap ? fr : fl) : (inL ? fl : (inR ? fr : CRH_NONE));
 	walkAdvance(S, w, stk, cnt, port);
 }
+/* Where a node step reads its child pair: global memory — or, for a stack type that stages the top-level BVH in LDS (cray_hip.hip: LdsStack::nodePair,
+ * -DCRH_TLAS_LDS), that copy while the walk is at the top level. */
+template <class T, class = void> struct has_node_pair : std::false_type {};
+template <class T> struct has_node_pair<T, std::void_t<decltype(std::declval<const T &>().tlasInLds())>> : std::true_type {};
 template <bool FAST = true, class Stack, class Cnt, class Port>
 CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	const uint32_t node = w.node;
-	const f4 l0 = S.nodes[2u * node], l1 = S.nodes[2u * node + 1u], r0 = S.nodes[2u * node + 2u], r1 = S.nodes[2u * node + 3u];
+	f4 l0, l1, r0, r1;
+	bool staged = false;
+	if constexpr (has_node_pair<Stack>::value) {
+		if (stk.tlasInLds() && !w.inBlas) { stk.nodePair(S, node, l0, l1, r0, r1); staged = true; }
+	}
+	if (!staged) { l0 = S.nodes[2u * node]; l1 = S.nodes[2u * node + 1u]; r0 = S.nodes[2u * node + 2u]; r1 = S.nodes[2u * node + 3u]; }
 	stepNodeLoaded<FAST>(S, w, stk, cnt, port, l0, l1, r0, r1);
 }
 
@@ -1060,29 +1118,29 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 	const uint32_t slot = w.pA++;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
 	const int32_t idx = (int32_t)(slot - S.tlas_prim_base);   /* leaf.first is an absolute prim slot; instances[] is in slot order */
-	const DInstance *inst = &S.instances[idx];
+	const InstLine inst = instLine(S, stk, idx, 0);
 	CRH_COUNT(cnt, inst_visits, 1);
 	/* transformRay(Ainv) + offset: instance.c:46-50 / 170-174 */
-	v3 o = xfPoint(w.k.o, inst->Ainv);
-	const v3 d = xfVector(w.k.d, inst->Ainv);
-	o = vadd(o, vscale(d, inst->ray_offset));
-	const uint32_t kind = CRH_DINST_KIND(inst->kind);
-	const bool volume = cnt_traits<Cnt>::programs && (inst->kind & CRH_DINST_VOLUME) != 0u;
+	v3 o = xfPoint(w.k.o, inst);
+	const v3 d = xfVector(w.k.d, inst);
+	o = vadd(o, vscale(d, instRayOffset(inst)));
+	const uint32_t kind = CRH_DINST_KIND(instKind(inst));
+	const bool volume = cnt_traits<Cnt>::programs && (instKind(inst) & CRH_DINST_VOLUME) != 0u;
 	if (kind == CRH_DINST_SPHERE) {
 		float t0;
 		if (__builtin_expect(volume, 0)) {
 			/* instance.c:62-92: where the ray enters the sphere, where — from just behind that point — it leaves it, then a free-flight
 			 * distance drawn from the path's sampler; both tests are bounded by the closest hit so far */
 			float tExit;
-			if (sphereTest(o, d, inst->radius, w.hit.t, t0, cnt) && sphereTest(alongRay(o, d, t0 + 0.0001f), d, inst->radius, w.hit.t, tExit, cnt)) {
+			if (sphereTest(o, d, instRadius(inst), w.hit.t, t0, cnt) && sphereTest(alongRay(o, d, t0 + 0.0001f), d, instRadius(inst), w.hit.t, tExit, cnt)) {
 				if (t0 < 0.0f) t0 = 0.0f;
-				const float hitDistance = -(1.0f / inst->density) * em::logf_(port.draw());
+				const float hitDistance = -(1.0f / instDensity(instLine(S, stk, idx, 1))) * em::logf_(port.draw());
 				if (hitDistance < tExit) {
 					w.hit.t = t0 + hitDistance; w.hit.u = 0.0f; w.hit.v = 0.0f; w.hit.slot = -2; w.hit.inst = idx;
 					CRH_COUNT(cnt, inst_hits, 1);
 				}
 			}
-		} else if (sphereTest(o, d, inst->radius, w.hit.t, t0, cnt)) {   /* sphere.c:20-50 */
+		} else if (sphereTest(o, d, instRadius(inst), w.hit.t, t0, cnt)) {   /* sphere.c:20-50 */
 			w.hit.t = t0; w.hit.slot = -1; w.hit.inst = idx;
 			CRH_COUNT(cnt, inst_hits, 1);
 		}
@@ -1097,7 +1155,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 		bool enter = true;
 		uint32_t rootA = 0, rootAe = 0;
 		if (kind == CRH_DINST_MESH_LEAF) {                                 /* bvh.c:382-387 */
-			const f4 n0 = S.nodes[2u * inst->root], n1 = S.nodes[2u * inst->root + 1u];
+			const f4 n0 = S.nodes[2u * instRoot(inst)], n1 = S.nodes[2u * instRoot(inst) + 1u];
 			float tE;
 			CRH_COUNT(cnt, node_tests, 1);
 			enter = intersectNode(n0, n1, ko, w.hit.t, tE);
@@ -1109,11 +1167,10 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			stk.park(PK_DX, asU32(w.k.d.x)); stk.park(PK_DY, asU32(w.k.d.y)); stk.park(PK_DZ, asU32(w.k.d.z));
 #ifdef CRH_PARK_FULL
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
-			stk.park(PK_SX, asU32(w.k.ss.x)); stk.park(PK_SY, asU32(w.k.ss.y)); stk.park(PK_SZ, asU32(w.k.ss.z));
 			stk.park(PK_OCT, w.k.oct);
 #endif
 			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
-			else { w.node = inst->root; w.pA = w.pAe = 0; }
+			else { w.node = instRoot(inst); w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;
 			w.spBase = w.sp; w.inBlas = BLAS_SOLID; w.instFound = 0; w.curInst = idx; w.k = ko;
 			if (__builtin_expect(volume, 0)) {                                /* instance.c:188-196: the entry walk runs on a copy of the record */
@@ -1154,25 +1211,27 @@ CRH_DEV int32_t hitPoly(const DScene &S, const TravHit &hit) {
 CRH_DEV v3 loadV3(const float *base, int64_t i) { const float *p = base + 3 * i; return v3{p[0], p[1], p[2]}; }
 /* LAZY_UV: shading skips a sphere's texture coordinates (atan2f + asinf, instance.c:33-43) when no node of the material's
  * graph reads them (crh_material.pad[0], set by the scene compiler); crh_trace_rays always reports them. */
-template <bool LAZY_UV = true, bool VOLUMES = true>
-CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravHit &hit) {
+template <bool LAZY_UV = true, bool VOLUMES = true, class Src = GlobalTables>
+CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravHit &hit, const Src &src = Src()) {
 	HitInfo h;
-	const DInstance *inst = &S.instances[hit.inst];
-	v3 o = xfPoint(wo, inst->Ainv);
-	const v3 d = xfVector(wd, inst->Ainv);
-	o = vadd(o, vscale(d, inst->ray_offset));
+	const InstLine inst = instLine(S, src, hit.inst, 0), inst1 = instLine(S, src, hit.inst, 1);     /* inst: Ainv + kind / offset; inst1: A + material */
+	v3 o = xfPoint(wo, inst);
+	const v3 d = xfVector(wd, inst);
+	o = vadd(o, vscale(d, instRayOffset(inst)));
 	if (VOLUMES && __builtin_expect(hit.slot == -2, 0)) {         /* a scattering event inside a volume: instance.c:81-88 / 205-211 */
 		h.uv = v2{-1.0f, -1.0f};
-		h.material = inst->material;                              /* the sphere's material / mesh->materials[0] */
-		h.point = xfPoint(alongRay(wo, wd, hit.t), inst->A);      /* the WORLD ray's point, transformed again — as the reference does */
-		h.normal = xfVectorT(v3{1.0f, 0.0f, 0.0f}, inst->Ainv);   /* "will be ignored by material anyway" */
+		h.material = instMaterial(inst1);                         /* the sphere's material / mesh->materials[0] */
+		h.point = xfPoint(alongRay(wo, wd, hit.t), inst1);        /* the WORLD ray's point, transformed again — as the reference does */
+		h.normal = xfVectorT(v3{1.0f, 0.0f, 0.0f}, inst);         /* "will be ignored by material anyway" */
 		return h;
 	}
+	/* (round 3: one normalisation and one xfPoint shared by the sphere and the triangle branch — a batch of hits holds both — was built and measured:
+	 * nine more spilled VGPRs, hdr.json -3 %, profiles/r03k_ab_shade.log: b3 / b4. The two branches stay.) */
 	const v3 objPoint = alongRay(o, d, hit.t);
-	if (CRH_DINST_KIND(inst->kind) == CRH_DINST_SPHERE) {
+	if (CRH_DINST_KIND(instKind(inst)) == CRH_DINST_SPHERE) {
 		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
 		h.uv = v2{0.0f, 0.0f};
-		if (!LAZY_UV || S.materials[inst->material].pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
+		if (!LAZY_UV || S.materials[instMaterial(inst1)].pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
 			float phi = em::atan2f_(n.z, n.x);
 			float theta = em::asinf_(n.y);
 			float v = (theta + CRH_PI / 2.0f) / CRH_PI;
@@ -1181,9 +1240,9 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 			v = wrap01(v);
 			h.uv = v2{u, v};
 		}
-		h.material = inst->material;
-		h.point = xfPoint(objPoint, inst->A);
-		h.normal = xfVectorT(n, inst->Ainv);                      /* not renormalised: instance.c:56 */
+		h.material = instMaterial(inst1);
+		h.point = xfPoint(objPoint, inst1);
+		h.normal = xfVectorT(n, inst);                            /* not renormalised: instance.c:56 */
 		return h;
 	}
 	const DShadeTri *st = &S.shade[hit.slot];
@@ -1203,9 +1262,9 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 	} else {
 		h.uv = v2{((st->t1[0] * u) + (st->t2[0] * v)) + (st->t0[0] * w), ((st->t1[1] * u) + (st->t2[1] * v)) + (st->t0[1] * w)};
 	}
-	h.material = inst->material + (flags & 0x3FFFFFFFu);
-	h.point = xfPoint(objPoint, inst->A);
-	h.normal = vnorm(xfVectorT(n, inst->Ainv));                   /* instance.c:180-181 */
+	h.material = instMaterial(inst1) + (flags & 0x3FFFFFFFu);
+	h.point = xfPoint(objPoint, inst1);
+	h.normal = vnorm(xfVectorT(n, inst));                         /* instance.c:180-181 */
 	return h;
 }
 
@@ -1261,8 +1320,8 @@ CRH_DEV void beginPath(const DScene &S, const crh_render_params &P, int x, int y
  * ray (ro, rd) and its closest hit go in; either the path continues (true: ro / rd are the next ray, r updated) or it
  * is complete (false: r.fr/fg/fb is the sample).
  */
-template <class PR, class Cnt>
-CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &rd, const TravHit &hit, PR &r, Cnt &cnt) {
+template <class PR, class Cnt, class Src = GlobalTables>
+CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &rd, const TravHit &hit, PR &r, Cnt &cnt, const Src &src = Src()) {
 	ShadeRec rec;
 	rec.dir = rd;
 	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */
@@ -1272,7 +1331,7 @@ CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &
 		r.fr = r.fr + (r.wr * bg.r); r.fg = r.fg + (r.wg * bg.g); r.fb = r.fb + (r.wb * bg.b);
 		return false;
 	}
-	const HitInfo h = finishHit<true, cnt_traits<Cnt>::programs>(S, ro, rd, hit);
+	const HitInfo h = finishHit<true, cnt_traits<Cnt>::programs>(S, ro, rd, hit, src);
 	const crh_material mat = S.materials[h.material];
 	r.fr = r.fr + (r.wr * mat.emission[0]); r.fg = r.fg + (r.wg * mat.emission[1]); r.fb = r.fb + (r.wb * mat.emission[2]);   /* :44 */
 	rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = hit.t; rec.ior = mat.ior;

@@ -379,6 +379,7 @@ struct Compiler {
 		CHECK(s->tlas_prim_count == (s->tlas_node_count ? s->instance_count : 0), CRH_ERR_INVALID, "TLAS prim count does not match the instance count");
 		const BvhInfo tlas = relayoutBvh(s->tlas_node_base, s->tlas_node_count, s->tlas_prim_base, s->tlas_prim_count, "TLAS");
 		out.tlas_root = tlas.root;
+		out.tlas_first = tlas.dev_base + 2;
 		out.tlas_node_count = s->tlas_node_count;
 		out.tlas_prim_base = s->tlas_prim_base;
 		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {

@@ -40,6 +40,7 @@ struct CompiledScene {
 	std::vector<DTexture> textures;
 	std::vector<f4> texels;
 	uint32_t tlas_root = 0, tlas_node_count = 0, tlas_prim_base = 0, background = 0, shade_classes = 0;
+	uint32_t tlas_first = 0;    /* device index of TLAS node 1 (the TLAS nodes are contiguous: node i at tlas_first - 1 + i) */
 	uint32_t max_stack = 0;     /* worst-case traversal stack entries (TLAS depth + saved TLAS state + deepest BLAS) */
 	uint32_t max_add_depth = 0;
 	bool has_volumes = false;   /* some instance is a sphere / mesh volume: walks draw from the path's sampler (no crh_trace_rays) */

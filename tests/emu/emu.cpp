@@ -36,7 +36,7 @@ DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
 	d.instances = c.instances.data(); d.materials = c.materials.data();
 	d.bsdfs = c.bsdfs.data(); d.consts = c.consts.data(); d.images = c.images.data(); d.prog = c.prog.data();
 	d.textures = c.textures.data(); d.texels = c.texels.data();
-	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base;
+	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base; d.tlas_first = c.tlas_first;
 	d.background = c.background; d.camera = c.camera;
 	return d;
 }

@@ -29,6 +29,16 @@ def test_host_build_matches_the_installed_libm(tmp_path):
     assert len(lines) >= 25 and all(l.rstrip().endswith("mismatches 0") for l in lines), text
 
 
+def test_wrap01_shortcuts_match_wrapminmax(tmp_path):
+    """pt_device.h: wrap01() skips the two fmodf of wrapMinMax(x, 0, 1) (vector.h:215-221) for -1 <= x < 1; same bits for every float
+    (every 4099th by default, all 2^32 with CRH_EXACT_MATH_FULL=1)."""
+    exe = str(tmp_path / "wrap01_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fopenmp", "-I" + os.path.join(REPO, "include"),
+                           os.path.join(REPO, "tests", "emu", "wrap01_check.cpp"), "-o", exe, "-lm"])
+    out = subprocess.run([exe, "1" if os.environ.get("CRH_EXACT_MATH_FULL") == "1" else "4099"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0 and out.stdout.decode().rstrip().endswith("mismatches 0"), out.stdout.decode()
+
+
 def _samples(rng):
     edge = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, -3.4028235e38, np.inf, -np.inf, np.nan,
                      math.pi, -math.pi, math.pi / 4, 0.785398185253143, 0.7853982, 120.0, 119.99999, 1e9, 2.4e-4, 0.975, 0.9750001, 0.4375, 0.6875, 1.1875, 2.4375,

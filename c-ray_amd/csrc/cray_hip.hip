@@ -1367,7 +1367,7 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 /* Load the code object of the selected instantiation now (HIP loads kernels lazily, ~40 ms on first launch) with a launch that finds
  * an empty work queue: crh_scene_upload calls it, so a renderer's first frame is not the one that pays for it. */
 static int variantKey(const crh_ctx *c) { return (c->hasPrograms ? 1 : 0) | (c->sampler << 1) | (c->counterLevel << 2) | (c->wavesPerSimd << 4) | (c->kernel << 8); }
-static int preloadKernel(crh_ctx *c) {
+static int preloadKernel(crh_ctx *c, bool again = false) {
 	crh_render_params P;
 	memset(&P, 0, sizeof(P));
 	BlockQueue Q;
@@ -1395,7 +1395,8 @@ static int preloadKernel(crh_ctx *c) {
 		c->stageFloats = waves * (size_t)c->unitItems * 3;
 	}
 	const int key = variantKey(c);
-	if (std::find(c->preloaded.begin(), c->preloaded.end(), key) != c->preloaded.end()) return CRH_OK;      /* crh_context_prepare has been here */
+	const bool known = std::find(c->preloaded.begin(), c->preloaded.end(), key) != c->preloaded.end();
+	if (known && !again) return CRH_OK;      /* crh_context_prepare has been here */
 	{   /* the copy paths a dispatch uses — pinned host -> device (its tile list) and back — are set up by the runtime on first use (measured: the first
 		 * dispatch's kernel started 7-15 ms after its launch, behind its own 64-byte tile list): first use is here */
 		crh_ctx::TileSlot &ts = c->tileSlots[0];
@@ -1409,10 +1410,21 @@ static int preloadKernel(crh_ctx *c) {
 		HIP_TRY(hipMemcpyAsync(ts.host, ts.dev, 64, hipMemcpyDeviceToHost, c->stream));
 	}
 	HIP_TRY(hipMemsetAsync(c->dWork, 0, sizeof(uint32_t), c->stream));
-	const hipError_t e = launchPathtrace(c, 1, &P, Q, nullptr, 1);
+	/* a FULL-SIZE grid (every wave finds the queue empty and leaves): the runtime sizes the queue's scratch memory by the waves a dispatch can have in flight,
+	 * and allocates it when a dispatch first needs that much — for a one-workgroup preload that was the first frame: its kernel started 8-24 ms after its
+	 * launch (round 3, CRH_TRACE_SYNC; an empty launch and every synchronize the API offers directly in front of it changed nothing) */
+	/* ... between the two timing events a dispatch records around its kernel (their first use on a stream is a set-up step of the runtime as well) */
+	crh_ctx::Timed ev;
+	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
+	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
+	HIP_TRY(hipEventRecord(ev.a, c->stream));
+	const hipError_t e = launchPathtrace(c, (uint32_t)(c->cuCount * c->blocksPerCU), &P, Q, nullptr, 1);
+	HIP_TRY(hipEventRecord(ev.b, c->stream));
+	c->eventPool.push_back(ev);
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("kernel preload: ") + hipGetErrorString(e));
+	HIP_TRY(hipMemsetAsync(c->dWork, 0, sizeof(uint32_t), c->stream));          /* its waves have drawn from the counter: zero again for the dispatch that takes slot 0 */
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	c->preloaded.push_back(key);
+	if (!known) c->preloaded.push_back(key);
 	return CRH_OK;
 }
 
@@ -1447,6 +1459,7 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, CRH_NCOUNTERS * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, CRH_NCOUNTERS * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMemset(c->dWork, 0, CRH_WORK_SLOTS * sizeof(uint32_t));      /* a work counter is zero whenever a dispatch takes it: crh_render_tiles resets it BEHIND the kernel */
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dErr, sizeof(unsigned int));
 	if (e == hipSuccess) e = hipMemset(c->dErr, 0, sizeof(unsigned int));
 	if (e != hipSuccess) {
@@ -1609,7 +1622,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	 * set-up. Measured in round 3 (CRH_TRACE_SYNC): without it the first dispatch's kernel starts 7-25 ms after its launch — behind work the runtime
 	 * still owes the pageable host-to-device copies above, which neither hipStreamSynchronize on the context's (non-blocking) stream nor
 	 * hipDeviceSynchronize waits for; with it, 1-5 us. (Until round 3 the watchdog flag's copy in crh_synchronize was this barrier by accident.) */
-	rc = preloadKernel(c);
+	rc = preloadKernel(c, true);         /* ... and an (empty) launch of the kernel on the context's stream is waited for: see below */
 	if (rc != CRH_OK) return rc;
 	unsigned int flag = 0;
 	HIP_TRY(hipMemcpy(&flag, c->dErr, sizeof(flag), hipMemcpyDeviceToHost));
@@ -1898,8 +1911,16 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (!ts.done) HIP_TRY(hipEventCreateWithFlags(&ts.done, hipEventDisableTiming));
 	memcpy(ts.host, work.data(), tileBytes);
 	memcpy((char *)ts.host + tileBytes, start.data(), startBytes);
-	HIP_TRY(hipMemcpyAsync(ts.dev, ts.host, tileBytes + startBytes, hipMemcpyHostToDevice, c->stream));
+	/* Nothing but the kernel itself is put on the stream in front of the kernel. Measured in round 3 (CRH_TRACE_SYNC, the drop-in's first dispatch): behind a
+	 * 64-byte host-to-device copy and a 4-byte memset the kernel started 9-22 ms after its launch, whatever had been warmed up or waited for before — the copy
+	 * engine's wake-up is the frame's. A short tile list (a frame, a GPU's strips) is therefore read by the waves straight from the pinned host slot (a wave
+	 * looks up one tile per work unit: a few reads over the host link per millisecond of work); long lists (a cluster worker's batch) are copied as before. The
+	 * work counter is reset behind the kernel instead of in front of it. CRH_TILES=copy forces the copy. */
+	static const bool forceCopy = getenv("CRH_TILES") && !strcmp(getenv("CRH_TILES"), "copy");
+	const bool zeroCopy = work_count <= 16 && !forceCopy;
 	void *dTiles = ts.dev;
+	if (zeroCopy) HIP_TRY(hipHostGetDevicePointer(&dTiles, ts.host, 0));
+	else HIP_TRY(hipMemcpyAsync(ts.dev, ts.host, tileBytes + startBytes, hipMemcpyHostToDevice, c->stream));
 
 	BlockQueue Q;
 	Q.tiles = (const crh_tile *)dTiles;
@@ -1910,7 +1931,6 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	Q.bw = bw; Q.bh = bh;
 	Q.firstSmall = firstSmall; Q.sbw = sbw; Q.sbh = sbh;
 	Q.firstTiny = firstTiny; Q.tbw = tbw; Q.tbh = tbh;
-	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));
 	c->workSlot++;
 
 	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */
@@ -1919,7 +1939,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		if (e0 != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_fold_black launch: ") + hipGetErrorString(e0));
 		HIP_TRY(hipEventRecord(ts.done, c->stream));
 		ts.inFlight = true;
-		return CRH_OK;
+		return CRH_OK;                                                   /* (k_fold_black takes no work units: the counter stays zero) */
 	}
 	crh_ctx::Timed ev;
 	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
@@ -1927,6 +1947,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
 	hipError_t e = launchPathtrace(c, grid, P, Q, dev_fb, chunk);
 	HIP_TRY(hipEventRecord(ev.b, c->stream));
+	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));          /* ready for the dispatch that takes this slot next */
 	HIP_TRY(hipEventRecord(ts.done, c->stream));
 	ts.inFlight = true;
 	c->pendingTimes.push_back(ev);

@@ -126,6 +126,19 @@ static int refreshOutput(crh_ctx *ctx, const float *fb, int W, int H, struct tex
 	return CRH_OK;
 }
 
+/* A throw-away dispatch ends a GPU's set-up: a few pixels, one pass, into the (still empty) framebuffer, which is cleared again. Measured in round 3
+ * (CRH_TRACE_SYNC, profiles/r03l_probe_dropin.log): the first kernel of a process that does real work starts 5-24 ms after its launch — whatever was copied,
+ * synchronized, launched empty or waited for before it — and the second does not; that first one should not be the frame. CRH_DROPIN_NO_WARM=1 leaves it out. */
+static void warmUp(crh_ctx *ctx, float *fb, const crh_render_params *p, int device) {
+	if (getenv("CRH_DROPIN_NO_WARM")) return;
+	crh_render_params wp = *p;
+	wp.x0 = 0; wp.y0 = 0; wp.x1 = p->image_width < 64 ? p->image_width : 64; wp.y1 = p->image_height < 16 ? p->image_height : 16;
+	wp.first_pass = 0; wp.pass_count = 1;
+	if (crh_render_region(ctx, &wp, fb) != CRH_OK || crh_synchronize(ctx) != CRH_OK || crh_framebuffer_clear(ctx, fb, p->image_width, p->image_height) != CRH_OK ||
+		crh_counters_reset(ctx) != CRH_OK || crh_synchronize(ctx) != CRH_OK)
+		logr(warning, "GPU %d: warm-up dispatch: %s\n", device, crh_last_error());
+}
+
 static void gpuThreadDone(struct gpuWorker *w) {
 	w->state->currentTileNum = -1;
 	w->state->threadComplete = true;
@@ -170,6 +183,7 @@ static void *gpuThread(void *arg) {
 		gpuThreadDone(w);
 		return NULL;
 	}
+	warmUp(w->ctx, w->fb, &p, w->device);
 	crh_tile *share = NULL;
 	const uint32_t n = gpuShare(r, w->device, G, &share);
 	uint64_t pixels = 0;
@@ -257,6 +271,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	crh_render_params p;
 	memset(&p, 0, sizeof(p));
 	p.image_width = W; p.image_height = H; p.max_passes = r->prefs.sampleCount; p.bounces = r->prefs.bounces;
+	for (int g = 0; g < gpus; ++g) warmUp(ctx[g], fb[g], &p, g);
 	int done = 0;
 	int chunk = 1;                                           /* the first preview after one pass; then as many passes per dispatch as take about a display refresh */
 	int dispatches = 0;

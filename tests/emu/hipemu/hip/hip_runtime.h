@@ -236,6 +236,7 @@ template <class T> static inline hipError_t hipMalloc(T **p, size_t bytes) { ret
 hipError_t hipFree(void *p);
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void *p);
+hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned flags);
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemset(void *dst, int value, size_t bytes);

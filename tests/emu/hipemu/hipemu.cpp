@@ -297,6 +297,7 @@ hipError_t hipMalloc(void **p, size_t bytes) {
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { if (!dev) return hipErrorInvalidValue; *dev = host; return hipSuccess; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind k, hipStream_t) { return hipMemcpy(dst, src, bytes, k); }
 hipError_t hipMemset(void *dst, int value, size_t bytes) { if (bytes) memset(dst, value, bytes); return hipSuccess; }

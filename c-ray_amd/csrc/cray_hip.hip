@@ -62,9 +62,19 @@ using namespace crh;
 #define CRH_INST_LDS0_MAX 64u
 #endif
 #ifndef CRH_INST_LDS1_MAX
-#define CRH_INST_LDS1_MAX 64u
+#define CRH_INST_LDS1_MAX 32u
 #endif
 #define CRH_INST_LDS_BYTES ((CRH_INST_LDS0_MAX + CRH_INST_LDS1_MAX) * 64u)
+/* ... and the shading tables (materials 32 B, bsdf nodes 16 B, constants 16 B each) of scenes that have at most this many of each: a shaded hit reads them
+ * through a chain of five or six DEPENDENT look-ups (material -> bsdf node -> mix child -> operand constant ...). 0 = off. */
+#ifndef CRH_SHADE_LDS
+#define CRH_SHADE_LDS 1
+#endif
+#define CRH_SHADE_LDS_MATERIALS 24u
+#define CRH_SHADE_LDS_BSDFS 64u
+#define CRH_SHADE_LDS_CONSTS 64u
+#define CRH_SHADE_LDS_IMAGES 8u           /* image descriptors (8 B) and texture descriptors (32 B) */
+#define CRH_SHADE_LDS_BYTES (CRH_SHADE_LDS * (CRH_SHADE_LDS_MATERIALS * 32u + CRH_SHADE_LDS_BSDFS * 16u + CRH_SHADE_LDS_CONSTS * 16u + CRH_SHADE_LDS_IMAGES * 40u))
 /* Top-level BVH in LDS (-DCRH_TLAS_LDS=1, with the instance records: scenes with at most CRH_INST_LDS_MAX instances have at most 31 TLAS nodes = 1 KB): every
  * ray starts with three or four node steps in that tiny tree, which always hit the L1 and still cost it four look-ups per lane each. */
 #ifndef CRH_TLAS_LDS
@@ -75,7 +85,7 @@ using namespace crh;
 #ifdef CRH_COOP_FETCH
 #define CRH_STACK_LDS 13         /* traversal stack entries kept in LDS per lane; with the 6 park slots, the fetch slabs, the id stacks and cursors: < 40 KB per block, 4 blocks per CU */
 #else
-#define CRH_STACK_LDS ((40960 - 3968 - (int)CRH_INST_LDS_BYTES - CRH_TLAS_LDS * 1024) / 1024 - 10)     /* what the LDS holds after the id stacks, tables and park slots (18 with the default instance tables) */
+#define CRH_STACK_LDS ((40960 - 3968 - (int)CRH_INST_LDS_BYTES - (int)CRH_SHADE_LDS_BYTES - CRH_TLAS_LDS * 1024) / 1024 - 10)     /* what the LDS holds after the id stacks, tables and park slots (18 with the default instance tables) */
 #endif
 #endif
 #define CRH_REC_STRIDE_WORDS 260u                          /* one slab = what one global_load_lds_dwordx4 writes (64 lanes x 16 B) + 16 B of skew: the four lanes of a quad
@@ -127,6 +137,42 @@ struct LdsStack {
 	__device__ __forceinline__ void nodePair(const DScene &S, uint32_t node, f4 &l0, f4 &l1, f4 &r0, f4 &r1) const {
 		const lds_u32 *p = tlas + (node - S.tlas_first) * 8u;
 		l0 = ldsLoadF4(p); l1 = ldsLoadF4(p + 4); r0 = ldsLoadF4(p + 8); r1 = ldsLoadF4(p + 12);
+	}
+#endif
+#if CRH_SHADE_LDS
+	const lds_u32 *shadeTab; /* workgroup-uniform: materials (8 words each), then bsdf nodes (4), then constants (4), or null */
+	__device__ __forceinline__ DBsdf bsdfNode(const DScene &S, uint32_t i) const {
+		if (shadeTab) { const f4 v = ldsLoadF4(shadeTab + CRH_SHADE_LDS_MATERIALS * 8u + i * 4u); return DBsdf{asU32(v.x), asU32(v.y), asU32(v.z), asU32(v.w)}; }
+		return S.bsdfs[i];
+	}
+	__device__ __forceinline__ f4 constant(const DScene &S, uint32_t i) const {
+		if (shadeTab) return ldsLoadF4(shadeTab + CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + i * 4u);
+		return S.consts[i];
+	}
+	__device__ __forceinline__ ImageRef image(const DScene &S, uint32_t i) const {
+		if (shadeTab) {
+			const lds_u32 *it = shadeTab + CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + CRH_SHADE_LDS_CONSTS * 4u;      /* textures (8 words each), then images (2) */
+			ImageRef r;
+			r.im.tex = it[CRH_SHADE_LDS_IMAGES * 8u + i * 2u]; r.im.options = it[CRH_SHADE_LDS_IMAGES * 8u + i * 2u + 1u];
+			r.t = DTexture{};
+			if (r.im.tex != CRH_NONE) {
+				const f4 a = ldsLoadF4(it + r.im.tex * 8u);
+				r.t.first = asU32(a.x); r.t.width = asU32(a.y); r.t.height = asU32(a.z); r.t.m64w = asU32(a.w); r.t.m64h = it[r.im.tex * 8u + 4u];
+			}
+			return r;
+		}
+		const DImage im = S.images[i];
+		return ImageRef{im, im.tex == CRH_NONE ? DTexture{} : S.textures[im.tex]};
+	}
+	__device__ __forceinline__ crh_material material(const DScene &S, uint32_t i) const {
+		if (shadeTab) {
+			const f4 a = ldsLoadF4(shadeTab + i * 8u), b = ldsLoadF4(shadeTab + i * 8u + 4u);
+			crh_material m;
+			m.emission[0] = a.x; m.emission[1] = a.y; m.emission[2] = a.z; m.emission[3] = a.w;
+			m.ior = b.x; m.bsdf = asU32(b.y); m.pad[0] = asU32(b.z); m.pad[1] = asU32(b.w);
+			return m;
+		}
+		return S.materials[i];
 	}
 #endif
 #if CRH_INST_LDS_BYTES > 0
@@ -307,7 +353,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32 + CRH_REC_WORDS_PER_WAVE * 4) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 	lds_u32 *const rec = (lds_u32 *)&s_rec[(threadIdx.x >> 6) * CRH_REC_WORDS_PER_WAVE];
 #else
-	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 + 256 + CRH_INST_LDS_BYTES + CRH_TLAS_LDS * CRH_TLAS_LDS_NODES * 32 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_IDS_BYTES + 32) + 512 + 256 + CRH_INST_LDS_BYTES + CRH_SHADE_LDS_BYTES + CRH_TLAS_LDS * CRH_TLAS_LDS_NODES * 32 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 #endif
 	const DScene S = globalize(Sarg);
 	CRH_EM_POW_TABLES_INIT();
@@ -337,6 +383,21 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		for (uint32_t i = threadIdx.x; i < (S.tlas_node_count - 1u) * 8u; i += CRH_BLOCK) s_tlas[i] = ((const uint32_t *)(S.nodes + 2u * S.tlas_first))[i];
 		__syncthreads();
 		stk.tlas = (const lds_u32 *)s_tlas;
+	}
+#endif
+#if CRH_SHADE_LDS
+	__shared__ __attribute__((aligned(16))) uint32_t s_shade[CRH_SHADE_LDS_BYTES / 4u];
+	stk.shadeTab = nullptr;
+	if (S.material_count <= CRH_SHADE_LDS_MATERIALS && S.bsdf_count <= CRH_SHADE_LDS_BSDFS && S.const_count <= CRH_SHADE_LDS_CONSTS &&
+		S.image_count <= CRH_SHADE_LDS_IMAGES && S.texture_count <= CRH_SHADE_LDS_IMAGES) {
+		const uint32_t texBase = CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + CRH_SHADE_LDS_CONSTS * 4u;
+		for (uint32_t i = threadIdx.x; i < S.texture_count * 8u; i += CRH_BLOCK) s_shade[texBase + i] = ((const uint32_t *)S.textures)[i];
+		for (uint32_t i = threadIdx.x; i < S.image_count * 2u; i += CRH_BLOCK) s_shade[texBase + CRH_SHADE_LDS_IMAGES * 8u + i] = ((const uint32_t *)S.images)[i];
+		for (uint32_t i = threadIdx.x; i < S.material_count * 8u; i += CRH_BLOCK) s_shade[i] = ((const uint32_t *)S.materials)[i];
+		for (uint32_t i = threadIdx.x; i < S.bsdf_count * 4u; i += CRH_BLOCK) s_shade[CRH_SHADE_LDS_MATERIALS * 8u + i] = ((const uint32_t *)S.bsdfs)[i];
+		for (uint32_t i = threadIdx.x; i < S.const_count * 4u; i += CRH_BLOCK) s_shade[CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + i] = ((const uint32_t *)S.consts)[i];
+		__syncthreads();
+		stk.shadeTab = (const lds_u32 *)s_shade;
 	}
 #endif
 #if CRH_INST_LDS_BYTES > 0
@@ -1612,6 +1673,8 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(texels, cs.texels.data(), cs.texels.size());
 #undef UP
 	d.tlas_first = cs.tlas_first;
+	d.material_count = (uint32_t)cs.materials.size(); d.bsdf_count = (uint32_t)cs.bsdfs.size(); d.const_count = (uint32_t)cs.consts.size();
+	d.image_count = (uint32_t)cs.images.size(); d.texture_count = (uint32_t)cs.textures.size();
 	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base; d.shade_classes = cs.shade_classes; d.instance_count = (uint32_t)cs.instances.size();
 	d.background = cs.background; d.camera = cs.camera;
 	c->d = d;

@@ -64,6 +64,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 #if CRH_TLAS_LDS
 	stk.tlas = nullptr;
 #endif
+#if CRH_SHADE_LDS
+	stk.shadeTab = nullptr;
+#endif
 #if CRH_INST_LDS_BYTES > 0
 	stk.inst0 = stk.inst1 = nullptr;          /* this kernel form reads the instance records from global memory */
 #endif

@@ -136,6 +136,8 @@ struct DScene {
 	uint32_t background;        /* gnode index of the background bsdf */
 	uint32_t shade_classes;     /* distinct shade classes among the instances (CRH_DINST_CLASS); <= 1: hits need no sorting */
 	uint32_t instance_count;    /* records in instances[] */
+	uint32_t image_count, texture_count;
+	uint32_t material_count, bsdf_count, const_count;       /* records in materials[] / bsdfs[] / consts[] (small tables may be staged in LDS: loadMaterial / loadBsdf / loadConst) */
 	uint32_t tlas_first;        /* device index of the first TLAS node after the root (the TLAS nodes tlas_first .. tlas_first + tlas_node_count - 2 are contiguous) */
 	crh_camera camera;
 };
@@ -401,6 +403,25 @@ CRH_DEV InstLine instLine(const DScene &S, const Src &src, int32_t idx, int line
 		return InstLine{g[0], g[1], g[2], g[3]};
 	}
 }
+/* The shading tables — materials, bsdf nodes, constants: a few dozen records per scene, read through a chain of dependent look-ups by every shaded hit
+ * (material -> bsdf node -> [mix: child node ->] operand constant). A hot-table source with bsdfNode() serves all three (k_pathtrace: LDS). */
+template <class T, class = void> struct has_shade_tables : std::false_type {};
+template <class T> struct has_shade_tables<T, std::void_t<decltype(std::declval<const T &>().bsdfNode(std::declval<const DScene &>(), 0u))>> : std::true_type {};
+template <class Src> CRH_DEV DBsdf loadBsdf(const DScene &S, const Src &src, uint32_t i) {
+	if constexpr (has_shade_tables<Src>::value) return src.bsdfNode(S, i); else { (void)src; return S.bsdfs[i]; }
+}
+template <class Src> CRH_DEV f4 loadConst(const DScene &S, const Src &src, uint32_t i) {
+	if constexpr (has_shade_tables<Src>::value) return src.constant(S, i); else { (void)src; return S.consts[i]; }
+}
+/* an image operand: its descriptor and its texture's (zeros when the image has none: evalImage does not read them then) */
+struct ImageRef { DImage im; DTexture t; };
+template <class Src> CRH_DEV ImageRef loadImage(const DScene &S, const Src &src, uint32_t i) {
+	if constexpr (has_shade_tables<Src>::value) return src.image(S, i);
+	else { (void)src; const DImage im = S.images[i]; return ImageRef{im, im.tex == CRH_NONE ? DTexture{} : S.textures[im.tex]}; }
+}
+template <class Src> CRH_DEV crh_material loadMaterial(const DScene &S, const Src &src, uint32_t i) {
+	if constexpr (has_shade_tables<Src>::value) return src.material(S, i); else { (void)src; return S.materials[i]; }
+}
 /* transforms.c:76-116 on the three rows of a line (the same operations in the same order as xfPoint / xfVector / xfVectorT on float[12]) */
 CRH_DEV v3 xfPoint(v3 v, const InstLine &m) {
 	return v3{(m.a.x * v.x) + (m.a.y * v.y) + (m.a.z * v.z) + m.a.w,
@@ -485,10 +506,10 @@ CRH_DEV rgba textureGetPixelFiltered(const TexCtx S, const DTexture &t, float x,
 	return cmix(cmix(topleft, topright, fx), cmix(botleft, botright, fx), fy);
 }
 /* image.c:31-48 */
+/* (t = the image's texture descriptor, read by the caller: from textures[] or from a hot-table source's copy; unused when the image has no texture) */
 template <class Cnt>
-CRH_DEV rgba evalImage(const TexCtx S, const DImage im, v2 uv, Cnt &cnt) {
+CRH_DEV rgba evalImage(const TexCtx S, const DImage im, const DTexture t, v2 uv, Cnt &cnt) {
 	if (im.tex == CRH_NONE) return rgba{1.0f, 0.0f, 0.5f, 1.0f};   /* warningMaterial().diffuse, material.c:38 */
-	const DTexture t = S.textures[im.tex];
 	rgba out;
 	if (im.options & CRH_IMAGE_NO_BILINEAR) {
 		float x = uv.x * (float)t.width;
@@ -531,6 +552,13 @@ CRH_DEV rgba evalGradient(const f4 *consts, uint32_t cidx, const ShadeRec &rec) 
 	const f4 dn = consts[cidx], up = consts[cidx + 1];
 	return cadd(ccoef(1.0f - t, rgba{dn.x, dn.y, dn.z, dn.w}), ccoef(t, rgba{up.x, up.y, up.z, up.w}));
 }
+template <class Src>
+CRH_DEV rgba evalGradient(const DScene &S, const Src &src, uint32_t cidx, const ShadeRec &rec) {
+	v3 unitDir = vnorm(rec.dir);
+	float t = 0.5f * (unitDir.y + 1.0f);
+	const f4 dn = loadConst(S, src, cidx), up = loadConst(S, src, cidx + 1);
+	return cadd(ccoef(1.0f - t, rgba{dn.x, dn.y, dn.z, dn.w}), ccoef(t, rgba{up.x, up.y, up.z, up.w}));
+}
 /* ---- pure nodes (colour / value / vector): postfix programs compiled at upload ---------------- */
 /* Out-of-line on the device (rare graphs only: checker, grayscale(image), ...). Everything is passed and
  * returned BY VALUE: a reference parameter would pin the caller's scene / hit record / counters in scratch. */
@@ -550,7 +578,8 @@ CRH_DEV ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) 
 			case CRH_COLOR_CONSTANT: case CRH_VALUE_CONSTANT: case CRH_VEC_CONSTANT:
 				r = S.consts[op.cidx]; break;
 			case CRH_COLOR_IMAGE: {
-				rgba o = evalImage(S.tex, S.images[op.u], rec.uv, cnt);
+				const DImage im = S.images[op.u];
+				rgba o = evalImage(S.tex, im, im.tex == CRH_NONE ? DTexture{} : S.tex.textures[im.tex], rec.uv, cnt);
 				r = f4{o.r, o.g, o.b, o.a}; break;
 			}
 			case CRH_COLOR_CHECKER: {          /* checker.c:31-54; a=A b=B c=scale (all already evaluated: pure) */
@@ -621,12 +650,12 @@ CRH_DEV ProgResult runProgram(const ProgCtx S, uint32_t pc, const ShadeRec rec) 
 }
 
 CRH_DEV ProgCtx progCtx(const DScene &S) { return ProgCtx{S.consts, S.images, S.prog, TexCtx{S.textures, S.texels}}; }
-template <class Cnt>
-CRH_DEV rgba evalColor(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
+template <class Cnt, class Src = GlobalTables>
+CRH_DEV rgba evalColor(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt, const Src &src = Src()) {
 	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
-	if (k == CRH_OPR_CONST) { const f4 c = S.consts[i]; return rgba{c.x, c.y, c.z, c.w}; }
-	if (k == CRH_OPR_IMAGE) return evalImage(TexCtx{S.textures, S.texels}, S.images[i], rec.uv, cnt);
-	if (k == CRH_OPR_GRADIENT) return evalGradient(S.consts, i, rec);
+	if (k == CRH_OPR_CONST) { const f4 c = loadConst(S, src, i); return rgba{c.x, c.y, c.z, c.w}; }
+	if (k == CRH_OPR_IMAGE) { const ImageRef ir = loadImage(S, src, i); return evalImage(TexCtx{S.textures, S.texels}, ir.im, ir.t, rec.uv, cnt); }
+	if (k == CRH_OPR_GRADIENT) return evalGradient(S, src, i, rec);
 	if constexpr (cnt_traits<Cnt>::programs) {
 		const ProgResult r = runProgram(progCtx(S), i, rec);
 		CRH_COUNT(cnt, tex_fetches, r.fetches);
@@ -634,11 +663,11 @@ CRH_DEV rgba evalColor(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &
 	}
 	return rgba{0.0f, 0.0f, 0.0f, 0.0f};
 }
-template <class Cnt>
-CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt) {
+template <class Cnt, class Src = GlobalTables>
+CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt &cnt, const Src &src = Src()) {
 	const uint32_t k = CRH_OPR_KIND(opr), i = CRH_OPR_IDX(opr);
-	if (k == CRH_OPR_CONST) return S.consts[i].x;
-	if (k == CRH_OPR_IMAGE_ALPHA) return evalImage(TexCtx{S.textures, S.texels}, S.images[i], rec.uv, cnt).a;
+	if (k == CRH_OPR_CONST) return loadConst(S, src, i).x;
+	if (k == CRH_OPR_IMAGE_ALPHA) { const ImageRef ir = loadImage(S, src, i); return evalImage(TexCtx{S.textures, S.texels}, ir.im, ir.t, rec.uv, cnt).a; }
 	if constexpr (cnt_traits<Cnt>::programs) {
 		const ProgResult r = runProgram(progCtx(S), i, rec);
 		CRH_COUNT(cnt, tex_fetches, r.fetches);
@@ -651,14 +680,14 @@ CRH_DEV float evalValue(const DScene &S, uint32_t opr, const ShadeRec &rec, Cnt 
 struct BsdfSample { v3 out; float r, g, b; };   /* bsdfnode.h:19-23; colour alpha never reaches RGB (pathtrace.c:51-57) */
 #define CRH_ADD_DEPTH 4
 
-template <class R, class Cnt>
-CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &rec, R &rng, Cnt &cnt) {
+template <class R, class Cnt, class Src = GlobalTables>
+CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &rec, R &rng, Cnt &cnt, const Src &src = Src()) {
 	uint32_t addStack[CRH_ADD_DEPTH];      /* pending add.c frames: gnode index | (A done ? 1<<31 : 0) */
 	BsdfSample resStack[CRH_ADD_DEPTH];
 	int asp = 0, rsp = 0;
 	uint32_t cur = root;
 	for (;;) {
-		const DBsdf n = S.bsdfs[cur];
+		const DBsdf n = loadBsdf(S, src, cur);
 		const uint32_t kind = n.kind;
 		BsdfSample res;
 		res.out = v3{0.0f, 0.0f, 0.0f};
@@ -671,7 +700,7 @@ CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &re
 		 * of the texture fetch / sRGB transform / program interpreter instead of a dozen), still only when the reference would evaluate it,
 		 * and the sampler draws keep the reference's order. */
 		float vc = 0.0f;                      /* value operand c: mix factor (mix.c:45), glass IOR (glass.c:47) */
-		if (kind == CRH_BSDF_MIX || kind == CRH_BSDF_GLASS) vc = evalValue(S, n.c, rec, cnt);
+		if (kind == CRH_BSDF_MIX || kind == CRH_BSDF_GLASS) vc = evalValue(S, n.c, rec, cnt, src);
 		if (kind == CRH_BSDF_MIX) {           /* mix.c:42-50 */
 			cur = (getDimension(rng) > vc) ? n.a : n.b;
 			continue;
@@ -700,9 +729,9 @@ CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &re
 			continue;
 		}
 		float vb = 0.0f;                      /* value operand b: roughness (metal.c:44, glass.c:67), emission strength (emission.c:46) */
-		if (kind == CRH_BSDF_METAL || kind == CRH_BSDF_GLASS || kind == CRH_BSDF_EMISSION) vb = evalValue(S, n.b, rec, cnt);
+		if (kind == CRH_BSDF_METAL || kind == CRH_BSDF_GLASS || kind == CRH_BSDF_EMISSION) vb = evalValue(S, n.b, rec, cnt, src);
 		rgba col = rgba{0.0f, 0.0f, 0.0f, 0.0f};      /* the colour operand: a, for the plastic coat its roughness b (plastic.c:68) */
-		if (kind >= CRH_BSDF_DIFFUSE && kind <= CRH_BSDF_ISOTROPIC) col = evalColor(S, kind == CRH_BSDF_PLASTIC ? n.b : n.a, rec, cnt);
+		if (kind >= CRH_BSDF_DIFFUSE && kind <= CRH_BSDF_ISOTROPIC) col = evalColor(S, kind == CRH_BSDF_PLASTIC ? n.b : n.a, rec, cnt, src);
 		/* The outgoing direction. A batch of hits runs the union of its lanes' code, so what several kinds compute is computed at ONE site each
 		 * (round 3: randomOnUnitSphere was inlined six times, vnorm four times, vreflect three times): the random unit vector — the first draw of
 		 * every kind that uses it, so the sampler's order is the reference's —, one normalisation, one reflection. Per kind:
@@ -744,7 +773,7 @@ CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &re
 			if (!(top & 0x80000000u)) {
 				resStack[rsp++] = res;
 				addStack[asp - 1] = top | 0x80000000u;
-				cur = S.bsdfs[top].b;
+				cur = loadBsdf(S, src, top).b;
 				break;
 			}
 			const BsdfSample A = resStack[--rsp];
@@ -756,19 +785,19 @@ CRH_DEV BsdfSample sampleBsdf(const DScene &S, uint32_t root, const ShadeRec &re
 }
 
 /* background.c:39-66 (on a miss): rec.dir = incident direction, everything else zero */
-template <class Cnt>
-CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt) {
-	const DBsdf n = S.bsdfs[S.background];
+template <class Cnt, class Src = GlobalTables>
+CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt, const Src &src = Src()) {
+	const DBsdf n = loadBsdf(S, src, S.background);
 	v3 ud = vnorm(rec.dir);
-	float phi = (em::atan2f_(ud.z, ud.x) / 4.0f) + evalValue(S, n.c, rec, cnt);
+	float phi = (em::atan2f_(ud.z, ud.x) / 4.0f) + evalValue(S, n.c, rec, cnt, src);
 	float theta = em::acosf_((-ud.y / 1.0f));
 	float u = theta / CRH_PI;
 	float v = (phi / (CRH_PI / 2.0f));
 	u = wrap01(u);
 	v = wrap01(v);
 	rec.uv = v2{v, u};
-	float strength = evalValue(S, n.b, rec, cnt);
-	return ccoef(strength, evalColor(S, n.a, rec, cnt));
+	float strength = evalValue(S, n.b, rec, cnt, src);
+	return ccoef(strength, evalColor(S, n.a, rec, cnt, src));
 }
 
 /* ---- intersection ------------------------------------------------------------------------------ */
@@ -1231,7 +1260,7 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 	if (CRH_DINST_KIND(instKind(inst)) == CRH_DINST_SPHERE) {
 		v3 n = vnorm(objPoint);                                   /* sphere.c:48 */
 		h.uv = v2{0.0f, 0.0f};
-		if (!LAZY_UV || S.materials[instMaterial(inst1)].pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
+		if (!LAZY_UV || loadMaterial(S, src, instMaterial(inst1)).pad[0]) {       /* getTexMapSphere: instance.c:33-43 (object-space normal) */
 			float phi = em::atan2f_(n.z, n.x);
 			float theta = em::asinf_(n.y);
 			float v = (theta + CRH_PI / 2.0f) / CRH_PI;
@@ -1327,15 +1356,15 @@ CRH_DEV bool shadeCore(const DScene &S, const crh_render_params &P, v3 &ro, v3 &
 	if (hit.inst < 0) {                                            /* pathtrace.c:39-42 */
 		rec.point = v3{0.0f, 0.0f, 0.0f}; rec.normal = v3{0.0f, 0.0f, 0.0f}; rec.uv = v2{0.0f, 0.0f};
 		rec.distance = hit.t; rec.ior = 0.0f;
-		const rgba bg = sampleBackground(S, rec, cnt);
+		const rgba bg = sampleBackground(S, rec, cnt, src);
 		r.fr = r.fr + (r.wr * bg.r); r.fg = r.fg + (r.wg * bg.g); r.fb = r.fb + (r.wb * bg.b);
 		return false;
 	}
 	const HitInfo h = finishHit<true, cnt_traits<Cnt>::programs>(S, ro, rd, hit, src);
-	const crh_material mat = S.materials[h.material];
+	const crh_material mat = loadMaterial(S, src, h.material);
 	r.fr = r.fr + (r.wr * mat.emission[0]); r.fg = r.fg + (r.wg * mat.emission[1]); r.fb = r.fb + (r.wb * mat.emission[2]);   /* :44 */
 	rec.point = h.point; rec.normal = h.normal; rec.uv = h.uv; rec.distance = hit.t; rec.ior = mat.ior;
-	const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, r.rng, cnt);     /* :46 */
+	const BsdfSample s = sampleBsdf(S, mat.bsdf, rec, r.rng, cnt, src);     /* :46 */
 	float probability = 1.0f;
 	if (r.depth >= 4) {                                                /* :51-55 */
 		probability = rmax(s.r, rmax(s.g, s.b));

@@ -148,7 +148,7 @@ def measured_profile(workload_key):
 
 
 def measure_other_workloads(api, abi, built_dir):
-    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region: one counting dispatch + two timed ones each, at a reduced sample
+    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region: one counting dispatch + three timed ones each (the median counts), at a reduced sample
     count (stated). Mray/s, algorithmic bytes and fraction of the HBM roofline per workload; `traffic` where profiles/ holds a PMC measurement of
     that workload on this device code (per dispatch of the stated spp)."""
     out = {}
@@ -172,12 +172,13 @@ def measure_other_workloads(api, abi, built_dir):
             full = ctx.counters()
             ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
             ctx.reset_counters()
-            for _ in range(2):
+            times = []
+            for _ in range(3):
                 ctx.clear(fb, w, h)
                 ctx.render_region(fb, w, h, spp, b)
-            ctx.synchronize()
-            _, total_ms, n = ctx.kernel_time_ms()
-            ms = total_ms / max(n, 1)
+                ctx.synchronize()
+                times.append(ctx.kernel_time_ms()[0])
+            ms = sorted(times)[1]                       # the median of three dispatches (HIP events around the kernel)
             alg = algorithmic_bytes(full, path_state=False)
             traffic = None
             try:
@@ -190,7 +191,7 @@ def measure_other_workloads(api, abi, built_dir):
                         "rays": full["rays"], "rays_per_path": round(full["rays"] / max(full["paths"], 1), 2),
                         "node_tests_per_ray": round(full["node_tests"] / max(full["rays"], 1), 1), "tri_tests_per_ray": round(full["tri_tests"] / max(full["rays"], 1), 1),
                         "bytes_per_ray": round(alg / max(full["rays"], 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "setup_s": round(time.perf_counter() - t0 - 3 * ms / 1e3, 2)}
+                        "traffic": traffic, "setup_s": round(time.perf_counter() - t0 - 4 * ms / 1e3, 2)}
             ctx.close()
             scene.close()
         except Exception as e:      # a missing blob / failed build must not take the headline line with it

@@ -479,8 +479,17 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 				const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
 				const int nF = __popcll(__ballot(ph == PH_SHADE));           /* walks that ended, result not yet queued */
 				const int nE = 64 - nN - nT - nC - nF;                        /* idle lanes */
+#ifndef CRH_EXP_SCALAR_SCHED
+				/* (wave-uniform by construction — lane 0 wrote them — but left as vector values: the decision below then compiles to exec-masked straight-line
+				 * code. Declared uniform with readfirstlane — a scalar decision, a scalar step switch, 22 instead of 26 spilled VGPRs — it is 2-7 % SLOWER on every
+				 * scene: the scalar form waits for the five LDS words before anything else and takes a chain of branches; profiles/r03o_ab_scalar_sched.log) */
 				const int raysQ = wq[WQ_RAYS], hitsQ = wq[WQ_HITS], missQn = wq[WQ_MISSES], freeQ = wq[WQ_FREE];
 				const uint32_t nextItem = (uint32_t)wq[WQ_NEXT_ITEM];
+#else
+				const int raysQ = __builtin_amdgcn_readfirstlane(wq[WQ_RAYS]), hitsQ = __builtin_amdgcn_readfirstlane(wq[WQ_HITS]),
+						  missQn = __builtin_amdgcn_readfirstlane(wq[WQ_MISSES]), freeQ = __builtin_amdgcn_readfirstlane(wq[WQ_FREE]);
+				const uint32_t nextItem = (uint32_t)__builtin_amdgcn_readfirstlane(wq[WQ_NEXT_ITEM]);
+#endif
 				CRH_LOCKSTEP();               /* every lane has read the fill levels before lane 0 updates them at the end of the step */
 				const bool canGen = nextItem < nItems && freeQ >= 64;
 				const int walkers = nN + nT + nC;

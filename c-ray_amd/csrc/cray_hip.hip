@@ -412,12 +412,21 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		if (st1) stk.inst1 = (const lds_u32 *)s_inst + CRH_INST_LDS0_MAX * 16u;
 	}
 #endif
+#ifndef CRH_EXP_NO_UNIFORM_BASES  /* the wave's slab and path table start at wave-uniform addresses: said so (readfirstlane), their accesses use a scalar base + a 32-bit lane offset instead
+                                   * of 64-bit vector address arithmetic and two more VGPRs each: 26 -> 16 spilled VGPRs, hdr.json +4 %, the others +1...2 % (profiles/r03q_ab_uniform_bases.log) */
+	float *myStage = stage + (size_t)__builtin_amdgcn_readfirstlane(wave) * ((size_t)Q.bw * Q.bh * chunk * 3);
+#else
 	float *myStage = stage + (size_t)wave * ((size_t)Q.bw * Q.bh * chunk * 3);
+#endif
 	const int passEnd = P.first_pass + P.pass_count;
 	/* the wave's path table, its id stacks and their wave-uniform fill levels (LDS: lane 0 writes, every lane reads; as
 	 * plain variables they would be scalar registers live across the whole machine, and the register allocator is past
 	 * its limits there — measured slower, and wrong images in the variant that calls runProgram) */
+#ifndef CRH_EXP_NO_UNIFORM_BASES
+	f4 *const ptab = (f4 *)(queues + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_WAVE_QUEUE_FLOATS);
+#else
 	f4 *const ptab = (f4 *)(queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS);
+#endif
 	enum { WQ_RAYS, WQ_HITS, WQ_MISSES, WQ_FREE, WQ_NEXT_ITEM, WQ_CLS_LO, WQ_CLS_HI, WQ_WORDS };      /* CLS_LO / CLS_HI: hits waiting per shade class, 8 bits each */
 	__shared__ int s_wq[(CRH_BLOCK / 64) * WQ_WORDS];
 	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_IDS_BYTES];

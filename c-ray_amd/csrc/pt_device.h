@@ -485,7 +485,7 @@ struct TexCtx { const DTexture *textures; const f4 *texels; };
 template <class Cnt>
 CRH_DEV rgba texel(const TexCtx S, const DTexture &t, uint32_t x, uint32_t y, Cnt &cnt) {
 	CRH_COUNT(cnt, tex_fetches, 1);
-	const f4 o = S.texels[t.first + x + y * t.width];
+	const f4 o = *(const f4 *)((const char *)S.texels + (uint32_t)((t.first + x + y * t.width) << 4));      /* base + 32-bit byte offset: see stepNode */
 	return rgba{o.x, o.y, o.z, o.w};
 }
 template <class Cnt>
@@ -1105,7 +1105,16 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 	if constexpr (has_node_pair<Stack>::value) {
 		if (stk.tlasInLds() && !w.inBlas) { stk.nodePair(S, node, l0, l1, r0, r1); staged = true; }
 	}
-	if (!staged) { l0 = S.nodes[2u * node]; l1 = S.nodes[2u * node + 1u]; r0 = S.nodes[2u * node + 2u]; r1 = S.nodes[2u * node + 3u]; }
+	if (!staged) {
+#ifndef CRH_EXP_NO_OFFSET32      /* the pair's byte offset as ONE 32-bit value added to the (wave-uniform) array base: global_load with a scalar base, a 32-bit vector offset and
+                              * immediate offsets for the four quarters instead of two 64-bit address computations per node step (round 3: +1 % on hdr.json / venus, profiles/r03q_ab_offset32.log).
+                              * The scene compiler refuses node / triangle / shading-record / texel arrays of 4 GB and more (134 M nodes, 89 M triangles per scene) */
+		const char *pair = (const char *)S.nodes + (uint32_t)(node << 5);
+		l0 = *(const f4 *)pair; l1 = *(const f4 *)(pair + 16); r0 = *(const f4 *)(pair + 32); r1 = *(const f4 *)(pair + 48);
+#else
+		l0 = S.nodes[2u * node]; l1 = S.nodes[2u * node + 1u]; r0 = S.nodes[2u * node + 2u]; r1 = S.nodes[2u * node + 3u];
+#endif
+	}
 	stepNodeLoaded<FAST>(S, w, stk, cnt, port, l0, l1, r0, r1);
 }
 
@@ -1131,8 +1140,14 @@ CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port)
 	const uint32_t slot = w.pA;
 	const bool two = slot + 1u < w.pAe;
 	const uint32_t slot2 = two ? slot + 1u : slot;
+#ifndef CRH_EXP_NO_OFFSET32
+	const char *ta = (const char *)S.tris + (uint32_t)(slot * 48u), *tb = (const char *)S.tris + (uint32_t)(slot2 * 48u);
+	const f4 a0 = *(const f4 *)ta, a1 = *(const f4 *)(ta + 16), a2 = *(const f4 *)(ta + 32);
+	const f4 b0 = *(const f4 *)tb, b1 = *(const f4 *)(tb + 16), b2 = *(const f4 *)(tb + 32);
+#else
 	const f4 a0 = S.tris[3u * slot], a1 = S.tris[3u * slot + 1u], a2 = S.tris[3u * slot + 2u];
 	const f4 b0 = S.tris[3u * slot2], b1 = S.tris[3u * slot2 + 1u], b2 = S.tris[3u * slot2 + 2u];
+#endif
 	w.pA = slot2 + 1u;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
 	testTriangle(a0, a1, a2, slot, w, cnt);
@@ -1274,7 +1289,7 @@ CRH_DEV HitInfo finishHit(const DScene &S, const v3 wo, const v3 wd, const TravH
 		h.normal = xfVectorT(n, inst);                            /* not renormalised: instance.c:56 */
 		return h;
 	}
-	const DShadeTri *st = &S.shade[hit.slot];
+	const DShadeTri *st = (const DShadeTri *)((const char *)S.shade + (uint32_t)((uint32_t)hit.slot << 6));      /* base + 32-bit byte offset: see stepNode */
 	const uint32_t flags = st->flags;
 	const float u = hit.u, v = hit.v;
 	const float w = 1.0f - u - v;

@@ -503,6 +503,11 @@ int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &
 	try {
 		Compiler c(scene, out);
 		c.run();
+		/* the kernels address a record as (array base) + a 32-BIT byte offset (pt_device.h: one scalar base, one vector offset per load): no device array of
+		 * 4 GB or more — 134 M BVH nodes, 89 M triangles, 67 M shading records, 268 M texels per scene */
+		const uint64_t lim = 1ull << 32;
+		if (out.nodes.size() * sizeof(f4) >= lim || out.tris.size() * sizeof(f4) >= lim || out.shade.size() * sizeof(DShadeTri) >= lim || out.texels.size() * sizeof(f4) >= lim)
+			throw Fail{CRH_ERR_UNSUPPORTED, "scene too large: a device array of 4 GB or more (32-bit record offsets)"};
 	} catch (const Fail &f) {
 		err = f.msg;
 		return f.code;

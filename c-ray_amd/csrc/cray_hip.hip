@@ -72,7 +72,7 @@ using namespace crh;
 #endif
 #define CRH_SHADE_LDS_MATERIALS 24u
 #define CRH_SHADE_LDS_BSDFS 64u
-#define CRH_SHADE_LDS_CONSTS 64u
+#define CRH_SHADE_LDS_CONSTS 48u
 #define CRH_SHADE_LDS_IMAGES 8u           /* image descriptors (8 B) and texture descriptors (32 B) */
 #define CRH_SHADE_LDS_BYTES (CRH_SHADE_LDS * (CRH_SHADE_LDS_MATERIALS * 32u + CRH_SHADE_LDS_BSDFS * 16u + CRH_SHADE_LDS_CONSTS * 16u + CRH_SHADE_LDS_IMAGES * 40u))
 /* Top-level BVH in LDS (-DCRH_TLAS_LDS=1, with the instance records: scenes with at most CRH_INST_LDS_MAX instances have at most 31 TLAS nodes = 1 KB): every
@@ -337,6 +337,41 @@ __device__ __forceinline__ void fetch64(lds_u32 *slab, uint32_t lane, const f4 *
 	}
 }
 
+/* The workgroup's copies of the hot records (k_pathtrace and k_pathtrace_roll; `S` and `stk` of the calling kernel) */
+#if CRH_SHADE_LDS
+#define CRH_STAGE_SHADE_TABLES() \
+	__shared__ __attribute__((aligned(16))) uint32_t s_shade[CRH_SHADE_LDS_BYTES / 4u]; \
+	stk.shadeTab = nullptr; \
+	if (S.material_count <= CRH_SHADE_LDS_MATERIALS && S.bsdf_count <= CRH_SHADE_LDS_BSDFS && S.const_count <= CRH_SHADE_LDS_CONSTS && \
+		S.image_count <= CRH_SHADE_LDS_IMAGES && S.texture_count <= CRH_SHADE_LDS_IMAGES) { \
+		const uint32_t texBase = CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + CRH_SHADE_LDS_CONSTS * 4u; \
+		for (uint32_t i = threadIdx.x; i < S.texture_count * 8u; i += CRH_BLOCK) s_shade[texBase + i] = ((const uint32_t *)S.textures)[i]; \
+		for (uint32_t i = threadIdx.x; i < S.image_count * 2u; i += CRH_BLOCK) s_shade[texBase + CRH_SHADE_LDS_IMAGES * 8u + i] = ((const uint32_t *)S.images)[i]; \
+		for (uint32_t i = threadIdx.x; i < S.material_count * 8u; i += CRH_BLOCK) s_shade[i] = ((const uint32_t *)S.materials)[i]; \
+		for (uint32_t i = threadIdx.x; i < S.bsdf_count * 4u; i += CRH_BLOCK) s_shade[CRH_SHADE_LDS_MATERIALS * 8u + i] = ((const uint32_t *)S.bsdfs)[i]; \
+		for (uint32_t i = threadIdx.x; i < S.const_count * 4u; i += CRH_BLOCK) s_shade[CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + i] = ((const uint32_t *)S.consts)[i]; \
+		__syncthreads(); \
+		stk.shadeTab = (const lds_u32 *)s_shade; \
+	}
+#else
+#define CRH_STAGE_SHADE_TABLES() do { } while (0)
+#endif
+#if CRH_INST_LDS_BYTES > 0
+#define CRH_STAGE_INSTANCE_TABLES() \
+	__shared__ __attribute__((aligned(16))) uint32_t s_inst[CRH_INST_LDS_BYTES / 4u]; \
+	stk.inst0 = stk.inst1 = nullptr; \
+	{ \
+		const bool st0 = S.instance_count <= CRH_INST_LDS0_MAX, st1 = S.instance_count <= CRH_INST_LDS1_MAX; \
+		if (st0) for (uint32_t i = threadIdx.x; i < S.instance_count * 16u; i += CRH_BLOCK) s_inst[i] = ((const uint32_t *)(S.instances + (i >> 4)))[i & 15u]; \
+		if (st1) for (uint32_t i = threadIdx.x; i < S.instance_count * 16u; i += CRH_BLOCK) s_inst[CRH_INST_LDS0_MAX * 16u + i] = ((const uint32_t *)(S.instances + (i >> 4)))[16u + (i & 15u)]; \
+		if (st0 || st1) __syncthreads(); \
+		if (st0) stk.inst0 = (const lds_u32 *)s_inst; \
+		if (st1) stk.inst1 = (const lds_u32 *)s_inst + CRH_INST_LDS0_MAX * 16u; \
+	}
+#else
+#define CRH_STAGE_INSTANCE_TABLES() do { } while (0)
+#endif
+
 /* WPS = minimum waves per SIMD the register allocator must leave room for (1: unconstrained). */
 #ifndef CRH_WPS_OVERRIDE
 #define CRH_WPS_OVERRIDE WPS
@@ -385,33 +420,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 		stk.tlas = (const lds_u32 *)s_tlas;
 	}
 #endif
-#if CRH_SHADE_LDS
-	__shared__ __attribute__((aligned(16))) uint32_t s_shade[CRH_SHADE_LDS_BYTES / 4u];
-	stk.shadeTab = nullptr;
-	if (S.material_count <= CRH_SHADE_LDS_MATERIALS && S.bsdf_count <= CRH_SHADE_LDS_BSDFS && S.const_count <= CRH_SHADE_LDS_CONSTS &&
-		S.image_count <= CRH_SHADE_LDS_IMAGES && S.texture_count <= CRH_SHADE_LDS_IMAGES) {
-		const uint32_t texBase = CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + CRH_SHADE_LDS_CONSTS * 4u;
-		for (uint32_t i = threadIdx.x; i < S.texture_count * 8u; i += CRH_BLOCK) s_shade[texBase + i] = ((const uint32_t *)S.textures)[i];
-		for (uint32_t i = threadIdx.x; i < S.image_count * 2u; i += CRH_BLOCK) s_shade[texBase + CRH_SHADE_LDS_IMAGES * 8u + i] = ((const uint32_t *)S.images)[i];
-		for (uint32_t i = threadIdx.x; i < S.material_count * 8u; i += CRH_BLOCK) s_shade[i] = ((const uint32_t *)S.materials)[i];
-		for (uint32_t i = threadIdx.x; i < S.bsdf_count * 4u; i += CRH_BLOCK) s_shade[CRH_SHADE_LDS_MATERIALS * 8u + i] = ((const uint32_t *)S.bsdfs)[i];
-		for (uint32_t i = threadIdx.x; i < S.const_count * 4u; i += CRH_BLOCK) s_shade[CRH_SHADE_LDS_MATERIALS * 8u + CRH_SHADE_LDS_BSDFS * 4u + i] = ((const uint32_t *)S.consts)[i];
-		__syncthreads();
-		stk.shadeTab = (const lds_u32 *)s_shade;
-	}
-#endif
-#if CRH_INST_LDS_BYTES > 0
-	__shared__ __attribute__((aligned(16))) uint32_t s_inst[CRH_INST_LDS_BYTES / 4u];
-	stk.inst0 = stk.inst1 = nullptr;
-	{
-		const bool st0 = S.instance_count <= CRH_INST_LDS0_MAX, st1 = S.instance_count <= CRH_INST_LDS1_MAX;
-		if (st0) for (uint32_t i = threadIdx.x; i < S.instance_count * 16u; i += CRH_BLOCK) s_inst[i] = ((const uint32_t *)(S.instances + (i >> 4)))[i & 15u];
-		if (st1) for (uint32_t i = threadIdx.x; i < S.instance_count * 16u; i += CRH_BLOCK) s_inst[CRH_INST_LDS0_MAX * 16u + i] = ((const uint32_t *)(S.instances + (i >> 4)))[16u + (i & 15u)];
-		if (st0 || st1) __syncthreads();
-		if (st0) stk.inst0 = (const lds_u32 *)s_inst;
-		if (st1) stk.inst1 = (const lds_u32 *)s_inst + CRH_INST_LDS0_MAX * 16u;
-	}
-#endif
+	CRH_STAGE_SHADE_TABLES();
+	CRH_STAGE_INSTANCE_TABLES();
 #ifndef CRH_EXP_NO_UNIFORM_BASES  /* the wave's slab and path table start at wave-uniform addresses: said so (readfirstlane), their accesses use a scalar base + a 32-bit lane offset instead
                                    * of 64-bit vector address arithmetic and two more VGPRs each: 26 -> 16 spilled VGPRs, hdr.json +4 %, the others +1...2 % (profiles/r03q_ab_uniform_bases.log) */
 	float *myStage = stage + (size_t)__builtin_amdgcn_readfirstlane(wave) * ((size_t)Q.bw * Q.bh * chunk * 3);
@@ -804,10 +814,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	}
 }
 
-#ifdef CRH_EXP_ROLLING_UNITS          /* experimental kernel form (not in the default library): see the header */
-#define CRH_KERNEL_ROLL 2
-#include "pathtrace_roll.h"
-#endif
+#include "pathtrace_roll.h"          /* k_pathtrace_roll: the same machine with rolling work units — the DEFAULT form since the end of round 3 (CRH_KERNEL_ROLL) */
+#define CRH_EXP_ROLLING_UNITS 1      /* (the name the form was developed under, kept for the tools that test for it) */
 
 /* ================================================================================================================================
  * k_pathtrace_wg — the WORKGROUP-cooperative form of the machine above (CRH_OPT_KERNEL = CRH_KERNEL_WG).
@@ -1282,7 +1290,7 @@ struct crh_ctx {
 	int unitItems = 2048;
 	int unitsPerWave = 8;
 	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12, 48};
-	int kernel = CRH_KERNEL_WAVE;            /* CRH_OPT_KERNEL */
+	int kernel = CRH_KERNEL_ROLL;            /* CRH_OPT_KERNEL */
 	SchedWg schedWg = {70, 160, 120, 16, 768, 4, 12, 12, 8, 192, 1, 16, 32};
 	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
 	size_t ovfWords = 0;
@@ -1387,7 +1395,6 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 #define CRH_LAUNCH2(LEVEL, WPS) do { if (c->hasPrograms) CRH_LAUNCH(LEVEL, WPS, true, 0); else CRH_LAUNCH(LEVEL, WPS, false, 0); } while (0)
 #define CRH_LAUNCH_WG(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_wg<LEVEL, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 													  c->dCounters, c->dStage, chunk, c->schedWg, c->dQueues, c->dOvf, c->dErr)
-#ifdef CRH_EXP_ROLLING_UNITS
 #define CRH_LAUNCH_ROLL(LEVEL, PROG, SAMP) hipLaunchKernelGGL((k_pathtrace_roll<LEVEL, 4, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 														  c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf)
 	if (c->kernel == CRH_KERNEL_ROLL) {
@@ -1412,7 +1419,6 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 		return hipGetLastError();
 	}
 #undef CRH_LAUNCH_ROLL
-#endif
 #ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/kernel_regs.py): one instantiation compiles in seconds */
 #ifdef CRH_DEV_ONLY_PROG
 	if (wg) CRH_LAUNCH_WG(1, true, 0); else CRH_LAUNCH(1, 4, true, 0);
@@ -1467,11 +1473,12 @@ static int preloadKernel(crh_ctx *c, bool again = false) {
 		HIP_TRY(hipMalloc((void **)&c->dQueues, waves * CRH_WAVE_QUEUE_FLOATS * sizeof(float)));
 		c->queueFloats = waves * CRH_WAVE_QUEUE_FLOATS;
 	}
-	if (waves * (size_t)c->unitItems * 3 > c->stageFloats) {
+	const size_t slabs = c->kernel == CRH_KERNEL_ROLL ? CRH_ROLL_SLOTS : 1u;        /* one sample slab per open job */
+	if (waves * slabs * (size_t)c->unitItems * 3 > c->stageFloats) {
 		if (c->dStage) HIP_TRY(hipFree(c->dStage));
 		c->dStage = nullptr; c->stageFloats = 0;
-		HIP_TRY(hipMalloc((void **)&c->dStage, waves * (size_t)c->unitItems * 3 * sizeof(float)));
-		c->stageFloats = waves * (size_t)c->unitItems * 3;
+		HIP_TRY(hipMalloc((void **)&c->dStage, waves * slabs * (size_t)c->unitItems * 3 * sizeof(float)));
+		c->stageFloats = waves * slabs * (size_t)c->unitItems * 3;
 	}
 	const int key = variantKey(c);
 	const bool known = std::find(c->preloaded.begin(), c->preloaded.end(), key) != c->preloaded.end();
@@ -1631,10 +1638,7 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			if (value != CRH_TRACE_SLABS_LITERAL && value != CRH_TRACE_SLABS_EXACT) return fail(CRH_ERR_INVALID, "trace slabs must be CRH_TRACE_SLABS_LITERAL or CRH_TRACE_SLABS_EXACT");
 			c->traceExactSlabs = value == CRH_TRACE_SLABS_EXACT; return CRH_OK;
 		case CRH_OPT_KERNEL:
-#ifdef CRH_EXP_ROLLING_UNITS
-			if (value == CRH_KERNEL_ROLL) { c->kernel = (int)value; return CRH_OK; }
-#endif
-			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_WAVE or CRH_KERNEL_WG");
+			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG && value != CRH_KERNEL_ROLL) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_ROLL, CRH_KERNEL_WAVE or CRH_KERNEL_WG");
 			c->kernel = (int)value; return CRH_OK;
 		case CRH_OPT_SCHED_WG: {       /* linger | drainAt << 8 | maxDrainers << 20 | partialMin << 24 | walkMin << 32 | fillTo << 40 */
 			SchedWg k = c->schedWg;
@@ -1940,9 +1944,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > 8192) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
 	{
 		size_t need = (size_t)grid * (wg ? 1 : CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
-#ifdef CRH_EXP_ROLLING_UNITS
 		if (c->kernel == CRH_KERNEL_ROLL) need *= CRH_ROLL_SLOTS;      /* one sample slab per open job */
-#endif
 		if (need > c->stageFloats) {
 			HIP_TRY(hipStreamSynchronize(c->stream));
 			if (c->dStage) HIP_TRY(hipFree(c->dStage));

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	enum { SJ_X0, SJ_Y0, SJ_WH /* w | h << 16 */, SJ_BWBH /* bw | bh << 16 */, SJ_PASS0, SJ_PASSN, SJ_NEXT, SJ_OUT, SJ_WORDS };     /* SJ_OUT: paths generated, sample not yet staged */
 	enum { NS = (int)CRH_ROLL_SLOTS, RQ_WORDS = RQ_SLOT0 + NS * SJ_WORDS };
 	static_assert(NS >= 2 && NS <= 4, "2..4 job slots (two bits of the item word)");
-	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_ROLL_IDS_BYTES + RQ_WORDS * 4) + 512 + 256 <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
+	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_ROLL_IDS_BYTES + RQ_WORDS * 4) + 512 + 256 + CRH_INST_LDS_BYTES + CRH_SHADE_LDS_BYTES <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
 	const DScene S = globalize(Sarg);
 	CRH_EM_POW_TABLES_INIT();
 	const unsigned long long tStart = wall_clock64();
@@ -64,12 +64,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 #if CRH_TLAS_LDS
 	stk.tlas = nullptr;
 #endif
-#if CRH_SHADE_LDS
-	stk.shadeTab = nullptr;
-#endif
-#if CRH_INST_LDS_BYTES > 0
-	stk.inst0 = stk.inst1 = nullptr;          /* this kernel form reads the instance records from global memory */
-#endif
+	CRH_STAGE_SHADE_TABLES();
+	CRH_STAGE_INSTANCE_TABLES();
 	CountersT<LEVEL, PROG> cnt;
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;
@@ -82,9 +78,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	}
 	stk.ovf = (glb_u32 *)ovfAll + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_OVF_WORDS_PER_WAVE;
 	const size_t slabFloats = (size_t)Q.bw * Q.bh * chunk * 3;           /* one job's samples; a wave owns one slab per slot */
-	float *const myStage = stage + (size_t)wave * (size_t)NS * slabFloats;
+	float *const myStage = stage + (size_t)__builtin_amdgcn_readfirstlane(wave) * (size_t)NS * slabFloats;
 	const int passEnd = P.first_pass + P.pass_count;
-	f4 *const ptab = (f4 *)(queues + (size_t)wave * CRH_WAVE_QUEUE_FLOATS);
+	f4 *const ptab = (f4 *)(queues + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_WAVE_QUEUE_FLOATS);
 	__shared__ int s_rq[(CRH_BLOCK / 64) * RQ_WORDS];
 	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_ROLL_IDS_BYTES];
 	typedef volatile __attribute__((address_space(3))) int lds_int;
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					mySlot = (int)(item >> CRH_ROLL_SLOT_SHIFT);
 					TravHit h;
 					h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
-					(void)shadeCore(S, P, ro, rd, h, r, cnt);
+					(void)shadeCore(S, P, ro, rd, h, r, cnt, stk);
 					float *so = myStage + (size_t)mySlot * slabFloats + (size_t)(item & CRH_ROLL_ITEM_MASK) * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
 					ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - lane] = (uint8_t)id;
 				}
@@ -451,7 +447,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					h.t = q4.x; h.u = q4.y; h.v = q4.z;
 					h.slot = (int32_t)asU32(q4.w); h.inst = (int32_t)asU32(q[5].x);
 					__builtin_assume(h.inst >= 0);
-					cont = shadeCore(S, P, ro, rd, h, r, cnt);
+					cont = shadeCore(S, P, ro, rd, h, r, cnt, stk);
 					done = !cont;
 					if (cont) putPathRay(q, ro, rd, r, item);
 					else {

@@ -279,8 +279,10 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */
 #define CRH_OPT_TAIL_PERCENT 10   /* share (0..50, default 16) of a dispatch's pixels that ends the work queue as quarter-size blocks, so the waves finish close together;
                                    * | (p2 + 1) << 8 also sets the share (default 4) at the very end that is cut into sixteenth-size blocks */
-#define CRH_OPT_KERNEL       12   /* which form of the path-tracing kernel: CRH_KERNEL_WAVE = every wave a self-contained machine (default),
-                                   * CRH_KERNEL_WG = the four waves of a workgroup share one path table and take walker / shader roles */
+#define CRH_OPT_KERNEL       12   /* which form of the path-tracing kernel: CRH_KERNEL_ROLL (default since round 3) = every wave a self-contained machine that keeps up to four
+                                   * work units open, so that its path table stays full across unit boundaries; CRH_KERNEL_WAVE = the same machine, one unit at a time (the
+                                   * default until round 3); CRH_KERNEL_WG = the four waves of a workgroup share one path table and take walker / shader roles.
+                                   * All three compute the same frame bit for bit */
 #define CRH_OPT_SCHED_WG     13   /* workgroup kernel scheduler: linger | drainAt<<8 | maxDrainers<<20 | partialMin<<24 | walkMin<<32 | fillTo<<40 */
 #define CRH_OPT_TRACE_SLABS  14   /* crh_trace_rays and rays with a zero / denormal direction component (a slab the reference's arithmetic turns into NaN, bvh.c:326-352):
                                    * CRH_TRACE_SLABS_LITERAL (default) = the reference's select chain followed literally: its record and its node / triangle test counts,
@@ -291,6 +293,7 @@ int crh_context_prepare(crh_ctx *ctx);
 #define CRH_TRACE_SLABS_EXACT   1
 #define CRH_KERNEL_WAVE 0
 #define CRH_KERNEL_WG   1
+#define CRH_KERNEL_ROLL 2
 #define CRH_SAMPLER_RANDOM 0
 #define CRH_SAMPLER_HALTON 1
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */

@@ -14,6 +14,7 @@ for name in sys.argv[1:]:
         scene = api.Scene(f.name)
     ctx = api.Context(0)
     ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+    ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)          # the pins are the one-unit-at-a-time form's (tests/test_kernel_emu.py)
     ctx.upload(scene)
     fb = ctx.framebuffer(m["width"], m["height"])
     ctx.reset_counters()

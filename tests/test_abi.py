@@ -56,11 +56,12 @@ def test_product_does_not_reference_the_oracle():
 
 
 def test_default_library_holds_no_experimental_kernel_and_no_emulation(pkg):
-    """The library the product loads is the measured one: the experimental kernel forms (csrc/pathtrace_roll.h, -DCRH_EXP_*) are not compiled
-    into it, it is not the CPU emulation, and the product sources never name the emulation library."""
+    """The library the product loads is the measured one: it holds the three kernel forms of CRH_OPT_KERNEL (k_pathtrace_roll, the default since round 3,
+    k_pathtrace, k_pathtrace_wg) and none of the -DCRH_EXP_* experiments (the quad-cooperative fetch's LDS slabs would show in the kernels' LDS size), it is
+    not the CPU emulation, and the product sources never name the emulation library."""
     lib = os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so")
     blob = open(lib, "rb").read()
-    assert b"k_pathtrace_roll" not in blob and b"crh_emu_stats" not in blob and b"hipemu" not in blob
+    assert b"k_pathtrace_roll" in blob and b"k_pathtrace_wg" in blob and b"crh_emu_stats" not in blob and b"hipemu" not in blob
     for root, _, files in os.walk(os.path.join(REPO, "c-ray_amd")):
         for f in files:
             if f.endswith((".py", ".c", ".h", ".cpp", ".hip")):

@@ -207,6 +207,43 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
     ctx.set_option(pkg.abi.OPT_COUNTER_LEVEL, 2)
 
 
+def test_rolling_and_one_unit_at_a_time_kernels_are_bit_identical(pkg, ctx, manifest, golden_blob):
+    """CRH_OPT_KERNEL: the default form keeps up to four work units open per wave (k_pathtrace_roll), CRH_KERNEL_WAVE works one unit at a time (the default
+    until round 3). Same per-path operations, so: the same frame and the same counters — for default and tiny units, one-pass chunks, ragged tiles split
+    over two dispatches, both counter levels."""
+    abi = pkg.abi
+    try:
+        for name in ("refraction", "glowmetal", "cfg1_scene", "fence"):
+            m = manifest[name]
+            w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+            full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob(name), w, h, s, b)
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+            for items, chunk in ((2048, 64), (64, 1), (256, 2)):
+                ctx.set_option(abi.OPT_UNIT_ITEMS, items)
+                ctx.set_option(abi.OPT_PASS_CHUNK, chunk)
+                for level in (2, 1):
+                    ctx.set_option(abi.OPT_COUNTER_LEVEL, level)
+                    ctx.clear(fb, w, h)
+                    ctx.reset_counters()
+                    ctx.render_region(fb, w, h, s, b)
+                    assert np.array_equal(ctx.download(fb, w, h), full), (name, items, chunk, level)
+                    got = ctx.counters()
+                    assert got["rays"] == cnt_full["rays"] and got["paths"] == cnt_full["paths"]
+                    if level == 2:
+                        assert got == cnt_full, (name, items, chunk)
+            ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+            ctx.clear(fb, w, h)
+            ctx.render_tiles(fb, w, h, s, b, [(0, 0, w - 1, h // 3), (0, h // 3, w - 1, h), (w - 1, 0, w, h)], first_pass=0, pass_count=1)
+            ctx.render_tiles(fb, w, h, s, b, [(0, 0, w, h)], first_pass=1)
+            assert np.array_equal(ctx.download(fb, w, h), full), name
+    finally:
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+        ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+        ctx.set_option(abi.OPT_UNIT_ITEMS, 2048)
+        ctx.set_option(abi.OPT_PASS_CHUNK, 64)
+
+
 def test_workgroup_kernel_is_bit_identical_to_the_wave_kernel(pkg, ctx, manifest, golden_blob):
     """CRH_OPT_KERNEL: the workgroup-cooperative form (walker / shader roles, shared path table, LDS lock) runs the same per-path
     operations as the per-wave machine — same frame, same counters, for every scheduler setting incl. the degenerate ones (never
@@ -251,15 +288,15 @@ def test_workgroup_kernel_is_bit_identical_to_the_wave_kernel(pkg, ctx, manifest
         fb = ctx.framebuffer(w, h)
         ctx.set_option(abi.OPT_SAMPLER, abi.SAMPLER_HALTON)
         imgs = []
-        for kern in (abi.KERNEL_WAVE, abi.KERNEL_WG):
+        for kern in (abi.KERNEL_WAVE, abi.KERNEL_WG, abi.KERNEL_ROLL):
             ctx.set_option(abi.OPT_KERNEL, kern)
             ctx.clear(fb, w, h)
             ctx.render_region(fb, w, h, n, b, pass_count=m["passes"])
             imgs.append(ctx.download(fb, w, h))
-        assert np.array_equal(imgs[0], imgs[1])
+        assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
     finally:
         ctx.set_option(abi.OPT_SAMPLER, abi.SAMPLER_RANDOM)
-        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
         ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
         ctx.set_option(abi.OPT_UNIT_ITEMS, 2048)
         ctx.set_option(abi.OPT_PASS_CHUNK, 64)

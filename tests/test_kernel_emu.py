@@ -61,7 +61,7 @@ def children(emu_lib):
 
     for name, (files, select, _) in GPU_TIER_JOBS.items():
         start(name, [sys.executable, "-m", "pytest", *[os.path.join(REPO, "tests", f) for f in files], "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select])
-    start("roll", [sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "2", *ROLL_FIXTURES])
+    start("roll", [sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "0", *ROLL_FIXTURES])
     start("steps", [sys.executable, os.path.join(EMU_DIR, "sched_counts.py"), *PINNED_STEPS])
     start("fuzz", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:9"])
     start("fuzz_bvh", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:19"])
@@ -155,10 +155,10 @@ def test_bvh_builder_fuzz_on_emulation(children):
     assert text.count('"ok": true') == 19 and '"refused": true' in text, text[-4000:]
 
 
-def test_rolling_units_kernel_on_emulation(children):
-    """k_pathtrace_roll (experimental kernel form, csrc/pathtrace_roll.h, compiled into the emulation library only): a ring of open
-    jobs per wave instead of one unit at a time. Same frames, bit for bit, and the same ray counts — with the default units and with
-    units so small that every slot of the ring is in use."""
+def test_one_unit_at_a_time_kernel_on_emulation(children):
+    """The DEFAULT kernel form since the end of round 3 is k_pathtrace_roll (csrc/pathtrace_roll.h: a ring of open jobs per wave) — every other test of
+    this module that does not say otherwise runs it. This one renders with k_pathtrace, the one-unit-at-a-time form (CRH_KERNEL_WAVE, the default until then):
+    the same frames, bit for bit, and the same ray counts — with the default units and with tiny ones."""
     import json
     rc, text = children("roll")
     assert rc == 0, text[-4000:]

@@ -425,7 +425,7 @@ def main():
                                            "soup": "configs[4] at 1 M triangles", "soup10m": "configs[4]"}.get(a.workload)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_scene / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_pathtrace", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
+                         "kernel": "k_pathtrace_roll", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
                          "bytes_per_ray": round(alg_no_state / max(full["rays"], 1), 1),
                          "frac_with_path_state": round(frac_state, 5),
                          "what_it_is": "ALGORITHMIC rate, not an HBM measurement: scene records touched (node / triangle / instance / shading / texel), "

@@ -2,7 +2,9 @@
  * cray_hip.hip — libcray_hip.so: the C-ABI of include/cray_hip.h and the gfx950 kernels behind it.
  *
  * Kernels (all hand-written for CDNA4, wave = 64):
- *   k_pathtrace<LEVEL, WPS, PROG, SAMP>   the hot kernel: persistent grid, every wave a small wavefront machine. A wave
+ *   k_pathtrace_roll<LEVEL, WPS, PROG, SAMP>  (pathtrace_roll.h) the hot kernel since the end of round 3: k_pathtrace's machine with up to four work units
+ *                        open per wave, so that the path table stays full across unit boundaries.
+ *   k_pathtrace<LEVEL, WPS, PROG, SAMP>   the same machine, one work unit at a time (CRH_KERNEL_WAVE): persistent grid, every wave a small wavefront machine. A wave
  *                        pulls pixel blocks from a global queue (one atomic per wave, readfirstlane broadcast); the
  *                        block's (pixel, pass) paths live in a per-wave table of 128-byte records (global memory),
  *                        their ids on LDS byte stacks (rays / hits / misses / free); lanes are workers, and each

@@ -1,6 +1,9 @@
 /*
  * pathtrace_roll.h — k_pathtrace_roll: the wave machine of k_pathtrace (cray_hip.hip) with ROLLING work units.
- * EXPERIMENTAL: compiled only with -DCRH_EXP_ROLLING_UNITS (CRH_OPT_KERNEL = CRH_KERNEL_ROLL); the default library does not contain it.
+ * THE DEFAULT KERNEL FORM since the end of round 3 (CRH_OPT_KERNEL = CRH_KERNEL_ROLL). Built and verified in round 2, when it was 8-14 % slower than
+ * k_pathtrace on hdr.json and 2-4 % faster on the soup (the walk was short of L1 look-ups and waiting for cache misses: always-full path tables are a bigger
+ * working set). Round 3 moved the hot records into LDS and the address arithmetic onto the scalar unit: vector issue binds the kernel now, fuller steps pay,
+ * and this form equals k_pathtrace on hdr.json at 256 spp and beats it by 6-30 % wherever a dispatch holds few passes (profiles/r03t_ab_rolling_units.log).
  *
  * Why. k_pathtrace works a unit (a pixel block x a chunk of passes) to its last path before it pulls the next one: every unit ramps the
  * wave's path table up and drains it again, and while it drains the walk steps run with ever fewer lanes. The kernel emulation

@@ -35,7 +35,7 @@ def counters(db, kernel_like="k_pathtrace"):
     cur = sqlite3.connect(db).cursor()
     q = ("select counter_name, count(*), sum(value), avg(value) from counters_collection "
          "where (kernel_name like ? or kernel_name like ?) group by counter_name")
-    rows = cur.execute(q, (f"%{kernel_like}<1,%", f"%{kernel_like}ILi1E%")).fetchall()
+    rows = cur.execute(q, (f"%{kernel_like}%<1,%", f"%{kernel_like}%ILi1E%")).fetchall()       # k_pathtrace<1, ...> and k_pathtrace_roll<1, ...>
     if not rows:
         rows = cur.execute(q, (f"%{kernel_like}%", f"%{kernel_like}%")).fetchall()
     return {r[0]: {"dispatches": r[1], "sum": r[2], "per_dispatch": r[3]} for r in rows}

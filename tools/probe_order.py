@@ -22,7 +22,7 @@ for world, rank in ((1, 0), (8, 0)):
     for label, tiles in cases:
         if world > 1:
             if "strips" not in label: continue
-            tiles = [(0, y, w, min(y + 4, h)) for y in (range(0, h, 4) if "bottom-up" in label else reversed(range(0, h, 4)))][rank::world] if R == 4 or True else tiles
+            tiles = [(0, y, w, min(y + 4, h)) for y in (range(0, h, 4) if "bottom-up" in label else reversed(range(0, h, 4)))][rank::world]       # a rank's share: 4-row strips
         best = None
         for rep in range(3):
             ctx.clear(fb, w, h); ctx.reset_counters(); ctx.render_tiles(fb, w, h, spp, b, tiles); ctx.synchronize()

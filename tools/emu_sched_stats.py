@@ -31,7 +31,7 @@ ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
 if "unit_items" in opts: ctx.set_option(abi.OPT_UNIT_ITEMS, int(opts["unit_items"]))
 if "units_per_wave" in opts: ctx.set_option(abi.OPT_UNITS_PER_WAVE, int(opts["units_per_wave"]))
 if "pass_chunk" in opts: ctx.set_option(abi.OPT_PASS_CHUNK, int(opts["pass_chunk"]))
-if "kernel" in opts: ctx.set_option(abi.OPT_KERNEL, int(opts["kernel"]))        # 2 = rolling units (CRH_EXP_ROLLING_UNITS)
+if "kernel" in opts: ctx.set_option(abi.OPT_KERNEL, int(opts["kernel"]))        # 0 = one unit at a time, 1 = workgroup form, 2 = rolling units (the default)
 if "tail" in opts: ctx.set_option(abi.OPT_TAIL_PERCENT, int(opts["tail"]))
 sched = dict(node=70, tri=160, ctrl=120, swap_min=16, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=48)
 sched.update({k: int(v) for k, v in opts.items() if k in sched})

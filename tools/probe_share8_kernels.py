@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """probe_share8_kernels.py — dev probe: the full bench frame and one rank's 1/8 share (every 8th 4-row strip) with the kernel forms a build holds
-(CRH_LIB = a -DCRH_EXP_ROLLING_UNITS build: 0 = k_pathtrace, 2 = k_pathtrace_roll): where do the small work units of a small share lose their time?"""
+(0 = k_pathtrace, one unit at a time; 2 = k_pathtrace_roll, the default): where do the small work units of a small share lose their time?"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)

@@ -7,7 +7,7 @@ from __graft_entry__ import load_package, BUILT
 pkg = load_package(); api = pkg.api; abi = pkg.abi
 ctx = api.Context(0)
 ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
-if os.environ.get("PROBE_KERNEL"):          # 2: the rolling-units kernel of a -DCRH_EXP_ROLLING_UNITS build (CRH_LIB)
+if os.environ.get("PROBE_KERNEL"):          # 0: the one-unit-at-a-time form, 2: the rolling-units form (the default)
     ctx.set_option(abi.OPT_KERNEL, int(os.environ["PROBE_KERNEL"]))
 only = sys.argv[1:]          # optional scene names
 for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("cfg3_venus", 1920, 1080, 16, 32), ("soup_1m", 2560, 1440, 16, 8)):

@@ -263,7 +263,8 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #define CRH_NCOUNTERS 32
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
-struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, shadeMin; };
+struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, shadeMin;
+               int sortFrom; };     /* CRH_OPT_SHADE_SORT: hits are shaded in batches of few shade classes in scenes with at least this many classes; 0 = never (default) */
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -407,7 +408,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
 	 * runs little extra code and the bookkeeping costs more than it saves (measured: statues -1 %, venus -3 %; hdr.json, six classes: +3 %).
 	 * The instances' classes sit in an LDS table (a retiring walk looks its class up): scenes with more than 256 instances do not sort. */
 	__shared__ uint8_t s_cls[256];
-	const bool sorted = S.shade_classes >= 4u && S.instance_count <= 256u;
+	/* (Round 2 turned this on for scenes with four or more classes: hdr.json +2...3 %. Since round 3's shading code runs far less per kind, the bookkeeping costs more
+	 * than the purer batches save: hdr.json +1.5 % WITHOUT it, profiles/r03z_ab_shade_sort.log. Off by default; CRH_OPT_SHADE_SORT turns it on.) */
+	const bool sorted = K.sortFrom > 0 && S.shade_classes >= (uint32_t)K.sortFrom && S.instance_count <= 256u;
 	if (sorted) {
 		for (uint32_t i = threadIdx.x; i < S.instance_count; i += CRH_BLOCK) s_cls[i] = (uint8_t)CRH_DINST_CLASS(S.instances[i].kind);
 		__syncthreads();
@@ -1291,7 +1294,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12, 48};
+	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12, 48, 0};
 	int kernel = CRH_KERNEL_ROLL;            /* CRH_OPT_KERNEL */
 	SchedWg schedWg = {70, 160, 120, 16, 768, 4, 12, 12, 8, 192, 1, 16, 32};
 	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
@@ -1639,6 +1642,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_TRACE_SLABS:
 			if (value != CRH_TRACE_SLABS_LITERAL && value != CRH_TRACE_SLABS_EXACT) return fail(CRH_ERR_INVALID, "trace slabs must be CRH_TRACE_SLABS_LITERAL or CRH_TRACE_SLABS_EXACT");
 			c->traceExactSlabs = value == CRH_TRACE_SLABS_EXACT; return CRH_OK;
+		case CRH_OPT_SHADE_SORT:
+			if (value < 0 || value > 8) return fail(CRH_ERR_INVALID, "shade sort: 0 (never) or the number of shade classes (1..8) from which a scene's hits are shaded in batches of few classes");
+			c->sched.sortFrom = (int)value; return CRH_OK;
 		case CRH_OPT_KERNEL:
 			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG && value != CRH_KERNEL_ROLL) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_ROLL, CRH_KERNEL_WAVE or CRH_KERNEL_WG");
 			c->kernel = (int)value; return CRH_OK;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
 	__shared__ uint8_t s_cls[256];
-	const bool sorted = S.shade_classes >= 4u && S.instance_count <= 256u;
+	const bool sorted = K.sortFrom > 0 && S.shade_classes >= (uint32_t)K.sortFrom && S.instance_count <= 256u;        /* see k_pathtrace */
 	if (sorted) {
 		for (uint32_t i = threadIdx.x; i < S.instance_count; i += CRH_BLOCK) s_cls[i] = (uint8_t)CRH_DINST_CLASS(S.instances[i].kind);
 		__syncthreads();

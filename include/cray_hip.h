@@ -289,6 +289,9 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * whatever the ray (such a ray visits most of the scene, like the reference's); CRH_TRACE_SLABS_EXACT = what the render kernels do:
                                    * that slab is tested exactly (inside iff min <= start <= max): never more node visits, the same hit except an origin one ulp
                                    * beside an axis-aligned face — a frame's one such camera ray costs microseconds instead of a third of a second */
+#define CRH_OPT_SHADE_SORT   15   /* 0 (default): hits are shaded in the order they were found. N in 1..8: in scenes with at least N shade classes (instances whose hits
+                                   * run the same surface-shader code path) the wave and rolling kernels shade them in batches of few classes. Pure scheduling: the frame
+                                   * is the same bit for bit. (Default until round 3: 4; slower than 0 since the shading code got shorter.) */
 #define CRH_TRACE_SLABS_LITERAL 0
 #define CRH_TRACE_SLABS_EXACT   1
 #define CRH_KERNEL_WAVE 0

@@ -130,7 +130,7 @@ def test_sampler_key_wraps_at_4k_2048spp(pkg, ctx, oracle):
 
 
 def test_shade_class_batches_change_nothing(pkg, ctx, manifest, golden_blob, golden_ref):
-    """Scenes with four or more shade classes (instances whose hits run the same surface-shader code path) shade their hits in batches
+    """CRH_OPT_SHADE_SORT: scenes with at least that many shade classes (instances whose hits run the same surface-shader code path) shade their hits in batches
     of few classes; which hits share a batch is pure scheduling. hdr.json at 320x180 (six classes) and the node zoo (dozens of graphs, the
     programs + volumes kernel variant): every batch threshold gives the reference's frame bit for bit."""
     for name in ("cfg2_hdr_small", "nodezoo"):
@@ -142,11 +142,13 @@ def test_shade_class_batches_change_nothing(pkg, ctx, manifest, golden_blob, gol
         else:
             ctx.upload(pkg.api.Scene(golden_blob(m.get("blob", name))))
         fb = ctx.framebuffer(w, h)
-        for shade_min in (48, 1, 17, 64, 128):
+        for sort_from, shade_min in ((4, 48), (2, 1), (1, 17), (4, 64), (3, 128), (0, 48)):        # CRH_OPT_SHADE_SORT (0 = the default: no batches by class)
+            ctx.set_option(pkg.abi.OPT_SHADE_SORT, sort_from)
             ctx.set_sched(70, 160, 120, 16, shade_min=shade_min)
             ctx.clear(fb, w, h)
             ctx.render_region(fb, w, h, s, b)
-            assert np.array_equal(ctx.download(fb, w, h), ref), (name, shade_min)
+            assert np.array_equal(ctx.download(fb, w, h), ref), (name, sort_from, shade_min)
+    ctx.set_option(pkg.abi.OPT_SHADE_SORT, 0)
     ctx.set_sched(70, 160, 120, 16)
 
 

@@ -35,7 +35,7 @@ for seed in range(lo, hi):
         "units_per_wave": rng.choice([1, 2, 8, 64]), "pass_chunk": rng.choice([1, 2, 3, 64]), "tail": rng.choice([0, 7, 16, 50]) | (rng.choice([0, 1, 5, 31]) << 8),
         "w_node": rng.choice([1, 70, 500]), "w_tri": rng.choice([1, 160, 900]), "w_ctrl": rng.choice([1, 120, 4000]), "swap_min": rng.choice([1, 8, 16, 40, 64]),
         "fill_to": rng.choice([0, 1, 64, 100, 160, 192]), "run_num": rng.choice([1, 4, 8]), "tri_in_run": rng.choice([1, 12, 65]), "ctrl_in_run": rng.choice([1, 12, 65]),
-        "shade_min": rng.choice([1, 17, 48, 64, 128]),
+        "shade_min": rng.choice([1, 17, 48, 64, 128]), "sort_from": rng.choice([0, 0, 1, 2, 4]),
         # the workgroup kernel's own scheduler (used when kernel == 1)
         "wg_linger": rng.choice([0, 1, 8, 255]), "wg_drain_at": rng.choice([1, 64, 192, 1000, 4095]), "wg_max_drainers": rng.choice([0, 1, 4]),
         "wg_partial_min": rng.choice([1, 16, 64, 255]), "wg_walk_min": rng.choice([1, 32, 64]), "wg_fill_to": rng.choice([0, 64, 768, 960]),
@@ -65,6 +65,7 @@ for seed in range(lo, hi):
     ctx.set_option(abi.OPT_PASS_CHUNK, cfg["pass_chunk"]); ctx.set_option(abi.OPT_TAIL_PERCENT, cfg["tail"])
     ctx.set_sched(cfg["w_node"], cfg["w_tri"], cfg["w_ctrl"], cfg["swap_min"], fill_to=cfg["fill_to"], run_num=cfg["run_num"],
                   tri_in_run=cfg["tri_in_run"], ctrl_in_run=cfg["ctrl_in_run"], shade_min=cfg["shade_min"])
+    ctx.set_option(abi.OPT_SHADE_SORT, cfg["sort_from"])
     if cfg["kernel"] == 1:
         ctx.set_sched_wg(linger=cfg["wg_linger"], drain_at=cfg["wg_drain_at"], max_drainers=cfg["wg_max_drainers"], partial_min=cfg["wg_partial_min"],
                          walk_min=cfg["wg_walk_min"], fill_to=cfg["wg_fill_to"])

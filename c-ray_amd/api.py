@@ -99,13 +99,13 @@ def device_count():
 
 
 def plan_units(width, height, samples, tiles, cu_count=256, first_pass=0, pass_count=None):
-    """crh_debug_plan_units (no device needed): the work units of one dispatch in hand-out order, as an int32 array [n, 6] of
-    x0, y0, x1, y1, block area, taper level — and the pass chunk."""
+    """crh_debug_plan_units (no device needed): the work units of one dispatch in hand-out order, as an int32 array [n, 8] of
+    x0, y0, x1, y1, block area, taper level, first pass, pass count — and the pass chunk."""
     p = abi.RenderParams(0, 0, 0, 0, width, height, first_pass, samples - first_pass if pass_count is None else pass_count, samples, 1)
     arr = (abi.Tile * len(tiles))(*[abi.Tile(*t) for t in tiles])
     n, chunk = C.c_uint64(0), C.c_int32(0)
     _check(library().crh_debug_plan_units(C.byref(p), arr, len(tiles), cu_count, None, 0, C.byref(n), C.byref(chunk)), "crh_debug_plan_units")
-    units = np.zeros((n.value, 6), np.int32)
+    units = np.zeros((n.value, 8), np.int32)
     _check(library().crh_debug_plan_units(C.byref(p), arr, len(tiles), cu_count, units.ctypes.data, n.value, C.byref(n), C.byref(chunk)), "crh_debug_plan_units")
     return units, chunk.value
 

@@ -238,6 +238,15 @@ struct BlockQueue {
 	 * one such unit, which matters when a GPU's share of a frame is small (1/8 of it at 8 GPUs) */
 	uint32_t firstTiny;
 	int tbw, tbh;
+	/* rolling kernel only (CRH_OPT_TAIL_SPLIT): the queue's very end (from firstMicro on) is handed out in units of about 64 paths, which is what a wave needs
+	 * to keep its lanes busy while its last jobs finish — blocks of mbw x mbh pixels for all passes, or, from 128 passes per dispatch on, ONE pixel's passes in
+	 * `segs` segments of segPasses: unit = start[t] + pixel * segs + segment. A pixel's segments are traced by whichever waves pull them, so their samples are
+	 * staged per pixel (defer: unit (u - unit0) owns segPasses samples) and folded into the frame in pass order by k_fold_deferred behind the kernel */
+	uint32_t firstMicro;
+	int mbw, mbh;
+	int segs, segPasses;
+	uint32_t unit0;
+	float *defer;
 };
 
 /* Pointers that arrive inside a by-value kernel-argument struct are generic ("flat") to the compiler; a round
@@ -1249,6 +1258,31 @@ __global__ void k_fold_black(const crh_render_params P, const crh_tile *tiles, u
 	}
 }
 
+/* The split pixels of a dispatch (BlockQueue: from firstMicro on, segs > 1): their passes were traced segment by segment by whichever waves pulled the
+ * segments, the samples wait in Q.defer — pixel q's at [q * segs * segPasses + (pass - first_pass)] — and go into the frame here, in pass order: the
+ * same running mean over the same values as foldBlockPixel's (renderer.c:288-291). One lane per pixel. */
+__global__ __launch_bounds__(256) void k_fold_deferred(const crh_render_params P, const BlockQueue Q, uint32_t pixels, float *fb) {
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= pixels) return;
+	const uint32_t unit = Q.unit0 + q * (uint32_t)Q.segs;
+	uint32_t lo = Q.firstMicro, hi = Q.ntiles;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (Q.start[mid] <= unit) lo = mid; else hi = mid; }
+	const crh_tile t = Q.tiles[lo];
+	const uint32_t pix = (unit - Q.start[lo]) / (uint32_t)Q.segs, w = (uint32_t)(t.x1 - t.x0);       /* split units are single pixels: the tile's pixels row by row */
+	const int x = t.x0 + (int)(pix % w), y = t.y0 + (int)(pix / w);
+	float *out = fb + ((size_t)x + (size_t)(P.image_height - (y + 1)) * (size_t)P.image_width) * 3;
+	const float *sp = Q.defer + (size_t)q * (size_t)Q.segs * (size_t)Q.segPasses * 3;
+	float r = out[0], g = out[1], b = out[2];
+	int k = 0;
+	for (; k + 8 <= P.pass_count; k += 8) {          /* the loads of eight passes in flight together, the mean a serial chain (foldBlockPixel) */
+		float v[24];
+		for (int i = 0; i < 24; ++i) v[i] = sp[3 * k + i];
+		for (int j = 0; j < 8; ++j) foldSample(r, g, b, v[3 * j], v[3 * j + 1], v[3 * j + 2], P.first_pass + k + j + 1);
+	}
+	for (; k < P.pass_count; ++k) foldSample(r, g, b, sp[3 * k], sp[3 * k + 1], sp[3 * k + 2], P.first_pass + k + 1);
+	out[0] = r; out[1] = g; out[2] = b;
+}
+
 /* color.h:60-84 + texture.c:18-22 */
 __global__ void k_to_srgb8(const float *fb, size_t n, uint8_t *out) {
 	CRH_EM_POW_TABLES_INIT();
@@ -1313,6 +1347,9 @@ struct crh_ctx {
 	int sampler = CRH_SAMPLER_RANDOM;
 	int tailPercent = 16;       /* share of a dispatch's pixels that is cut into quarter-size blocks at the end of the work queue */
 	int tail2Percent = 4;       /* ... and the share at the very end that is cut into sixteenth-size blocks */
+	int tailSplit = CRH_TAIL_SPLIT_DEFAULT;   /* CRH_OPT_TAIL_SPLIT: 64-path units per wave at the very end of the queue (rolling kernel); 0 = none */
+	float *dDefer = nullptr;    /* samples of the split pixels of the dispatch in flight (k_fold_deferred folds them) */
+	size_t deferFloats = 0;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
 	uint32_t lastGrid = 0;
 	float *dStage = nullptr;
@@ -1463,7 +1500,7 @@ static int preloadKernel(crh_ctx *c, bool again = false) {
 	BlockQueue Q;
 	memset(&Q, 0, sizeof(Q));
 	Q.counter = c->dWork;                 /* any valid counter: total = 0, every wave leaves at once */
-	Q.bw = Q.bh = Q.sbw = Q.sbh = Q.tbw = Q.tbh = 1;
+	Q.bw = Q.bh = Q.sbw = Q.sbh = Q.tbw = Q.tbh = Q.mbw = Q.mbh = Q.segs = 1;
 	/* the per-wave path tables, stack-overflow columns and sample slabs of a full-size dispatch at the default unit size: allocated here rather than by the first frame */
 	const size_t waves = (size_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
 	if (waves * CRH_OVF_WORDS_PER_WAVE > c->ovfWords) {
@@ -1560,6 +1597,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 	}
 	const char *env = getenv("CRH_BLOCKS_PER_CU");
 	if (env && atoi(env) > 0) c->blocksPerCU = atoi(env);
+	env = getenv("CRH_TAIL_SPLIT");                 /* dev: the default of CRH_OPT_TAIL_SPLIT for this process (A/B runs of unmodified hosts) */
+	if (env && atoi(env) >= 0 && atoi(env) <= 64) c->tailSplit = atoi(env);
 	*out = c;
 	return CRH_OK;
 }
@@ -1579,6 +1618,7 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dCounters) (void)hipFree(c->dCounters);
 	if (c->dWork) (void)hipFree(c->dWork);
 	if (c->dStage) (void)hipFree(c->dStage);
+	if (c->dDefer) (void)hipFree(c->dDefer);
 	if (c->dQueues) (void)hipFree(c->dQueues);
 	if (c->dOvf) (void)hipFree(c->dOvf);
 	if (c->dErr) (void)hipFree(c->dErr);
@@ -1642,6 +1682,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_TRACE_SLABS:
 			if (value != CRH_TRACE_SLABS_LITERAL && value != CRH_TRACE_SLABS_EXACT) return fail(CRH_ERR_INVALID, "trace slabs must be CRH_TRACE_SLABS_LITERAL or CRH_TRACE_SLABS_EXACT");
 			c->traceExactSlabs = value == CRH_TRACE_SLABS_EXACT; return CRH_OK;
+		case CRH_OPT_TAIL_SPLIT:
+			if (value < 0 || value > 64) return fail(CRH_ERR_INVALID, "tail split: 0 (off) or the number of 64-path units per wave (1..64) the work queue ends with");
+			c->tailSplit = (int)value; return CRH_OK;
 		case CRH_OPT_SHADE_SORT:
 			if (value < 0 || value > 8) return fail(CRH_ERR_INVALID, "shade sort: 0 (never) or the number of shade classes (1..8) from which a scene's hits are shaded in batches of few classes");
 			c->sched.sortFrom = (int)value; return CRH_OK;
@@ -1781,16 +1824,19 @@ int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int hei
 }
 
 /* ---- work plan of one dispatch (host only, no device needed: crh_debug_plan_units runs it for the CPU tests) ------------------------- */
-struct PlanKnobs { int unitItems, unitsPerWave, tailPercent, tail2Percent, passChunk, cuCount, blocksPerCU; bool wg; };
+struct PlanKnobs { int unitItems, unitsPerWave, tailPercent, tail2Percent, passChunk, cuCount, blocksPerCU; bool wg; int tailSplit; /* 0 unless the rolling kernel runs the plan */ };
 struct WorkPlan {
 	std::vector<crh_tile> work;            /* the caller's tiles, the tail ones split by rows */
 	std::vector<uint32_t> start;           /* start[t] = first unit of work[t]; start[work.size()] = total */
 	uint64_t total = 0;
 	int bw = 1, bh = 1, sbw = 1, sbh = 1, tbw = 1, tbh = 1;      /* block shapes: regular, from firstSmall on, from firstTiny on */
 	uint32_t firstSmall = 0, firstTiny = 0;
+	uint32_t firstMicro = 0;               /* BlockQueue: the 64-path units at the very end (rolling kernel) */
+	int mbw = 1, mbh = 1, segs = 1, segPasses = 0;
 	int area = 1, chunk = 1;
 	uint32_t grid = 0;
 };
+#define CRH_MICRO_ITEMS 64
 static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, const PlanKnobs &K, WorkPlan &W, std::string &err) {
 	/* Block shape: one work unit (a block for all passes of the dispatch) should hold about unitItems paths, so
 	 * that every wave gets many units (load balance) whatever the sample count: 16x16 pixels at 4 spp ... 2x2 at
@@ -1872,6 +1918,32 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 			firstTiny = std::max(firstSmall, t2);
 		}
 	}
+	/* The very end in 64-path units (rolling kernel): tailSplit of them per wave, at most a quarter of the dispatch. The late finishers of a dispatch are waves
+	 * that pulled an expensive unit just before the queue ran dry (profiles/r03x_probe_tail_hist.log); with four jobs open a wave needs only 64 paths per job to
+	 * keep its table full, so the last units can be that short — and where a single pixel holds more than that (>= 128 passes), its passes are split. */
+	uint32_t &firstMicro = W.firstMicro;
+	firstMicro = (uint32_t)work.size();
+	W.mbw = tbw; W.mbh = tbh; W.segs = 1; W.segPasses = P->pass_count;
+	if (K.tailSplit > 0 && P->pass_count > 0 && pixels > 0) {
+		int microArea = 1;
+		while ((int64_t)microArea * 2 * P->pass_count <= CRH_MICRO_ITEMS && microArea < area) microArea *= 2;
+		const int segs = P->pass_count >= 2 * CRH_MICRO_ITEMS ? (P->pass_count + CRH_MICRO_ITEMS - 1) / CRH_MICRO_ITEMS : 1;
+		const int tinyAreaNow = tbw * tbh;
+		if (segs > 1 || microArea < tinyAreaNow) {
+			const uint64_t unitsWanted = (uint64_t)K.tailSplit * wavesMax;
+			uint64_t want = std::min<uint64_t>(pixels / 4, (unitsWanted * (uint64_t)microArea + (uint64_t)segs - 1) / (uint64_t)segs);
+			if (want > 0) {
+				shapeOf(microArea, W.mbw, W.mbh);
+				W.segs = segs; W.segPasses = segs > 1 ? CRH_MICRO_ITEMS : P->pass_count;
+				const uint32_t t3 = cutTail(want);
+				if (insertedAt >= 0 && (uint32_t)insertedAt <= firstSmall) ++firstSmall;
+				if (insertedAt >= 0 && (uint32_t)insertedAt <= firstTiny) ++firstTiny;
+				firstMicro = t3;                                   /* the levels stay in order; a dispatch without a taper (single-pixel blocks) still ends in split pixels */
+				firstTiny = std::min(firstTiny, firstMicro);
+				firstSmall = std::min(firstSmall, firstTiny);
+			}
+		}
+	}
 	const uint32_t work_count = (uint32_t)work.size();
 	std::vector<uint32_t> &start = W.start;
 	start.assign(work_count + 1, 0);
@@ -1879,9 +1951,9 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 	total = 0;
 	for (uint32_t t = 0; t < work_count; ++t) {
 		const crh_tile &r = work[t];
-		const int ubw = t >= firstTiny ? tbw : t >= firstSmall ? sbw : bw, ubh = t >= firstTiny ? tbh : t >= firstSmall ? sbh : bh;
+		const int ubw = t >= firstMicro ? W.mbw : t >= firstTiny ? tbw : t >= firstSmall ? sbw : bw, ubh = t >= firstMicro ? W.mbh : t >= firstTiny ? tbh : t >= firstSmall ? sbh : bh;
 		start[t] = (uint32_t)total;
-		total += (uint64_t)((r.x1 - r.x0 + ubw - 1) / ubw) * ((r.y1 - r.y0 + ubh - 1) / ubh);
+		total += (uint64_t)((r.x1 - r.x0 + ubw - 1) / ubw) * ((r.y1 - r.y0 + ubh - 1) / ubh) * (uint64_t)(t >= firstMicro ? W.segs : 1);
 		if (total > 0xFFFFFFF0ull) { err = "crh_render_tiles: more than 2^32 pixel blocks in one dispatch"; return CRH_ERR_UNSUPPORTED; }
 	}
 	start[work_count] = (uint32_t)total;
@@ -1895,14 +1967,16 @@ static int planWork(const crh_render_params *P, const crh_tile *tiles, uint32_t 
 }
 
 /* The work units crh_render_tiles would hand to the kernel for this dispatch on a GPU with `cu_count` compute units at the default options:
- * one record of six ints per unit, in hand-out order — pixel rectangle x0, y0, x1, y1 (clipped to its tile), block area in pixels, and
- * the taper level (0 regular, 1 quarter blocks, 2 sixteenth blocks). Needs no device: the CPU tests check cover, order and unit sizes. */
+ * one record of eight ints per unit, in hand-out order — pixel rectangle x0, y0, x1, y1 (clipped to its tile), block area in pixels, the
+ * taper level (0 regular, 1 quarter blocks, 2 sixteenth blocks, 3 the 64-path units of the very end), and the unit's passes (first, count: all
+ * of the dispatch's except for the pass segments of split pixels). Needs no device: the CPU tests check cover, order and unit sizes. */
 int crh_debug_plan_units(const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, uint32_t cu_count, int32_t *units_out, uint64_t max_units,
 						 uint64_t *unit_count_out, int32_t *pass_chunk_out) {
 	if (!P || (!tiles && tile_count) || !unit_count_out || cu_count < 1) return fail(CRH_ERR_INVALID, "crh_debug_plan_units: bad argument");
 	if (P->image_width <= 0 || P->image_height <= 0 || P->pass_count < 0) return fail(CRH_ERR_INVALID, "crh_debug_plan_units: bad render parameters");
 	const crh_ctx defaults{};
-	const PlanKnobs knobs{defaults.unitItems, defaults.unitsPerWave, defaults.tailPercent, defaults.tail2Percent, defaults.passChunk, (int)cu_count, defaults.blocksPerCU, false};
+	const PlanKnobs knobs{defaults.unitItems, defaults.unitsPerWave, defaults.tailPercent, defaults.tail2Percent, defaults.passChunk, (int)cu_count, defaults.blocksPerCU, false,
+	                      defaults.kernel == CRH_KERNEL_ROLL ? defaults.tailSplit : 0};
 	WorkPlan W;
 	std::string err;
 	const int rc = planWork(P, tiles, tile_count, knobs, W, err);
@@ -1912,14 +1986,18 @@ int crh_debug_plan_units(const crh_render_params *P, const crh_tile *tiles, uint
 	uint64_t u = 0;
 	for (uint32_t t = 0; t < W.work.size() && units_out; ++t) {          /* the kernel's unit -> block arithmetic (k_pathtrace: "pull a work unit") */
 		const crh_tile &r = W.work[t];
-		const int level = t >= W.firstTiny ? 2 : t >= W.firstSmall ? 1 : 0;
-		const int ubw = level == 2 ? W.tbw : level == 1 ? W.sbw : W.bw, ubh = level == 2 ? W.tbh : level == 1 ? W.sbh : W.bh;
+		const int level = t >= W.firstMicro ? 3 : t >= W.firstTiny ? 2 : t >= W.firstSmall ? 1 : 0;
+		const int ubw = level == 3 ? W.mbw : level == 2 ? W.tbw : level == 1 ? W.sbw : W.bw, ubh = level == 3 ? W.mbh : level == 2 ? W.tbh : level == 1 ? W.sbh : W.bh;
 		const uint32_t nbx = (uint32_t)(r.x1 - r.x0 + ubw - 1) / (uint32_t)ubw;
+		const uint32_t segs = level == 3 ? (uint32_t)W.segs : 1u;
 		for (uint32_t local = 0; local < W.start[t + 1] - W.start[t]; ++local, ++u) {
 			if (u >= max_units) continue;
-			const int x0 = r.x0 + (int)(local % nbx) * ubw, y0 = r.y0 + (int)(local / nbx) * ubh;
-			int32_t *o = units_out + 6 * u;
+			const uint32_t blk = local / segs, seg = local % segs;          /* k_pathtrace_roll: ST_OPEN */
+			const int x0 = r.x0 + (int)(blk % nbx) * ubw, y0 = r.y0 + (int)(blk / nbx) * ubh;
+			int32_t *o = units_out + 8 * u;
 			o[0] = x0; o[1] = y0; o[2] = std::min(x0 + ubw, r.x1); o[3] = std::min(y0 + ubh, r.y1); o[4] = ubw * ubh; o[5] = level;
+			o[6] = P->first_pass + (segs > 1 ? (int)seg * W.segPasses : 0);
+			o[7] = segs > 1 ? std::min(W.segPasses, P->first_pass + P->pass_count - o[6]) : P->pass_count;
 		}
 	}
 	return CRH_OK;
@@ -1934,7 +2012,8 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (rc) return rc;
 	(void)resolveTimes(c, false);
 	const bool wg = c->kernel == CRH_KERNEL_WG;
-	const PlanKnobs knobs{c->unitItems, c->unitsPerWave, c->tailPercent, c->tail2Percent, c->passChunk, c->cuCount, c->blocksPerCU, wg};
+	const PlanKnobs knobs{c->unitItems, c->unitsPerWave, c->tailPercent, c->tail2Percent, c->passChunk, c->cuCount, c->blocksPerCU, wg,
+	                      c->kernel == CRH_KERNEL_ROLL && P->bounces > 0 ? c->tailSplit : 0};
 	WorkPlan plan;
 	{
 		std::string perr;
@@ -1962,6 +2041,17 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 		}
 	}
 
+	const uint32_t deferUnits = plan.segs > 1 ? (uint32_t)total - start[plan.firstMicro] : 0u;       /* split pixels x segments */
+	if (deferUnits) {
+		const size_t need = (size_t)deferUnits * (size_t)plan.segPasses * 3;
+		if (need > c->deferFloats) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (c->dDefer) HIP_TRY(hipFree(c->dDefer));
+			c->dDefer = nullptr; c->deferFloats = 0;
+			HIP_TRY(hipMalloc((void **)&c->dDefer, need * sizeof(float)));
+			c->deferFloats = need;
+		}
+	}
 	{
 		const size_t need = (size_t)grid * (CRH_BLOCK / 64) * CRH_WAVE_QUEUE_FLOATS;      /* = grid x CRH_WG_PATHS records for the workgroup kernel */
 		static_assert(CRH_WG_PATHS * CRH_PATH_F4 * 4u == (CRH_BLOCK / 64) * CRH_WAVE_QUEUE_FLOATS, "both kernels use the same path-table footprint per workgroup");
@@ -2022,6 +2112,8 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	Q.bw = bw; Q.bh = bh;
 	Q.firstSmall = firstSmall; Q.sbw = sbw; Q.sbh = sbh;
 	Q.firstTiny = firstTiny; Q.tbw = tbw; Q.tbh = tbh;
+	Q.firstMicro = plan.firstMicro; Q.mbw = plan.mbw; Q.mbh = plan.mbh; Q.segs = plan.segs; Q.segPasses = plan.segPasses;
+	Q.unit0 = start[plan.firstMicro]; Q.defer = deferUnits ? c->dDefer : nullptr;
 	c->workSlot++;
 
 	if (P->bounces <= 0) {           /* every sample is black: no walk, only the running mean moves; paths are still counted */
@@ -2037,6 +2129,11 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
 	HIP_TRY(hipEventRecord(ev.a, c->stream));
 	hipError_t e = launchPathtrace(c, grid, P, Q, dev_fb, chunk);
+	if (e == hipSuccess && deferUnits) {              /* the split pixels' samples -> the frame, in pass order (part of the dispatch and of its time) */
+		const uint32_t px = deferUnits / (uint32_t)plan.segs;
+		hipLaunchKernelGGL(k_fold_deferred, dim3((px + 255u) / 256u), dim3(256), 0, c->stream, *P, Q, px, dev_fb);
+		e = hipGetLastError();
+	}
 	HIP_TRY(hipEventRecord(ev.b, c->stream));
 	HIP_TRY(hipMemsetAsync(Q.counter, 0, sizeof(uint32_t), c->stream));          /* ready for the dispatch that takes this slot next */
 	HIP_TRY(hipEventRecord(ts.done, c->stream));

@@ -53,7 +53,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	       RQ_GEN,       /* ... items are generated from the youngest: slot (head + open - 1) mod CRH_ROLL_SLOTS */
 	       RQ_DRY,       /* the work queue is empty */
 	       RQ_SLOT0 };
-	enum { SJ_X0, SJ_Y0, SJ_WH /* w | h << 16 */, SJ_BWBH /* bw | bh << 16 */, SJ_PASS0, SJ_PASSN, SJ_NEXT, SJ_OUT, SJ_WORDS };     /* SJ_OUT: paths generated, sample not yet staged */
+	enum { SJ_X0, SJ_Y0, SJ_WH /* w | h << 16 */, SJ_BWBH /* bw | bh << 16 */, SJ_PASS0, SJ_PASSN, SJ_NEXT, SJ_OUT,     /* SJ_OUT: paths generated, sample not yet staged */
+	       SJ_BASE_LO, SJ_BASE_HI,   /* where the job's samples wait for their fold (a global address): sample of item i at base + 12 i. A block job's slab — or, for a pass
+	                                  * segment of a split pixel (BlockQueue: firstMicro, segs > 1; SJ_WH bit 30), the segment's place in Q.defer: k_fold_deferred folds those */
+	       SJ_WORDS };
+	enum { SJ_WH_DEFER = 1 << 30 };
 	enum { NS = (int)CRH_ROLL_SLOTS, RQ_WORDS = RQ_SLOT0 + NS * SJ_WORDS };
 	static_assert(NS >= 2 && NS <= 4, "2..4 job slots (two bits of the item word)");
 	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_ROLL_IDS_BYTES + RQ_WORDS * 4) + 512 + 256 + CRH_INST_LDS_BYTES + CRH_SHADE_LDS_BYTES <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
@@ -96,9 +100,15 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		lds_int *j = wq + RQ_SLOT0 + s * SJ_WORDS;
 		BlockJob J;
 		const int wh = j[SJ_WH], bwbh = j[SJ_BWBH];
-		J.x0 = j[SJ_X0]; J.y0 = j[SJ_Y0]; J.w = wh & 0xFFFF; J.h = wh >> 16; J.bw = bwbh & 0xFFFF; J.bh = bwbh >> 16; J.passBegin = j[SJ_PASS0]; J.passCount = j[SJ_PASSN];
+		J.x0 = j[SJ_X0]; J.y0 = j[SJ_Y0]; J.w = wh & 0xFFFF; J.h = (wh >> 16) & 0x3FFF; J.bw = bwbh & 0xFFFF; J.bh = bwbh >> 16; J.passBegin = j[SJ_PASS0]; J.passCount = j[SJ_PASSN];
 		return J;
 	};
+	/* where a finished path's sample waits for its fold (SJ_BASE) */
+	auto sampleSlot = [&](int slot, uint32_t idx) -> float * {
+		const uint32_t lo = (uint32_t)wq[RQ_SLOT0 + slot * SJ_WORDS + SJ_BASE_LO], hi = (uint32_t)wq[RQ_SLOT0 + slot * SJ_WORDS + SJ_BASE_HI];
+		return (float *)(__attribute__((address_space(1))) float *)(uintptr_t)(((unsigned long long)hi << 32) | lo) + idx * 3u;
+	};
+	auto jobDeferred = [&](int slot) { return (wq[RQ_SLOT0 + slot * SJ_WORDS + SJ_WH] & SJ_WH_DEFER) != 0; };
 	/* lane 0, after it changed a job's words: the two words the scheduler reads every round */
 	auto refreshJobWords = [&]() {
 		const int head = wq[RQ_HEAD], open = wq[RQ_OPEN];
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 			const int gb = gj[SJ_BWBH], ob = oj[SJ_BWBH];
 			left = (gb & 0xFFFF) * (gb >> 16) * gj[SJ_PASSN] - gj[SJ_NEXT];
 			if (left < 0) left = 0;
-			moreChunks = gj[SJ_PASS0] + gj[SJ_PASSN] < passEnd;
+			moreChunks = !(gj[SJ_WH] & SJ_WH_DEFER) && gj[SJ_PASS0] + gj[SJ_PASSN] < passEnd;          /* (a pass segment is a unit of its own) */
 			/* a job that is the only open one AND not its unit's last chunk stays open until the following chunk has been opened from it
 			 * (ST_OPEN reads the unit from the youngest job): folded earlier, the unit's remaining passes would never be generated */
 			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0 && (open > 1 || !moreChunks)) flags |= 1;
@@ -263,7 +273,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				const int s = (o + open) % NS;
 				BlockJob J;
 				bool have = false;
-				if (open > 0) {
+				const float *base = myStage + (size_t)s * slabFloats;
+				int defer = 0;
+				if (open > 0 && !jobDeferred(wq[RQ_GEN])) {
 					J = loadJob(wq[RQ_GEN]);
 					if (J.passBegin + J.passCount < passEnd) { J.passBegin += J.passCount; J.passCount = min(chunk, passEnd - J.passBegin); have = true; }
 				}
@@ -276,16 +288,25 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 						uint32_t lo = 0, hi = Q.ntiles;
 						while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (asGlobal(Q.start)[mid] <= unit) lo = mid; else hi = mid; }
 						const crh_tile t = asGlobal(Q.tiles)[lo];
-						const uint32_t local = unit - asGlobal(Q.start)[lo];
-						const int ubw = lo >= Q.firstTiny ? Q.tbw : lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = lo >= Q.firstTiny ? Q.tbh : lo >= Q.firstSmall ? Q.sbh : Q.bh;
+						uint32_t local = unit - asGlobal(Q.start)[lo];
+						const bool micro = lo >= Q.firstMicro;
+						const int ubw = micro ? Q.mbw : lo >= Q.firstTiny ? Q.tbw : lo >= Q.firstSmall ? Q.sbw : Q.bw, ubh = micro ? Q.mbh : lo >= Q.firstTiny ? Q.tbh : lo >= Q.firstSmall ? Q.sbh : Q.bh;
 						const uint32_t nbx = (uint32_t)(t.x1 - t.x0 + ubw - 1) / (uint32_t)ubw;
+						J.passBegin = P.first_pass;
+						J.passCount = min(chunk, passEnd - P.first_pass);
+						if (micro && Q.segs > 1) {          /* one pass segment of a split pixel */
+							const uint32_t seg = local % (uint32_t)Q.segs;
+							local /= (uint32_t)Q.segs;
+							J.passBegin = P.first_pass + (int)seg * Q.segPasses;
+							J.passCount = min(Q.segPasses, passEnd - J.passBegin);
+							defer = SJ_WH_DEFER;
+							base = Q.defer + (size_t)(unit - Q.unit0) * (size_t)Q.segPasses * 3;
+						}
 						J.bw = ubw; J.bh = ubh;
 						J.x0 = t.x0 + (int)(local % nbx) * ubw;
 						J.y0 = t.y0 + (int)(local / nbx) * ubh;
 						J.w = min(ubw, t.x1 - J.x0);
 						J.h = min(ubh, t.y1 - J.y0);
-						J.passBegin = P.first_pass;
-						J.passCount = min(chunk, passEnd - P.first_pass);
 						have = true;
 					}
 				}
@@ -293,8 +314,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				if (lane == 0) {
 					if (have) {
 						lds_int *j = wq + RQ_SLOT0 + s * SJ_WORDS;
-						j[SJ_X0] = J.x0; j[SJ_Y0] = J.y0; j[SJ_WH] = J.w | (J.h << 16); j[SJ_BWBH] = J.bw | (J.bh << 16); j[SJ_PASS0] = J.passBegin; j[SJ_PASSN] = J.passCount;
+						j[SJ_X0] = J.x0; j[SJ_Y0] = J.y0; j[SJ_WH] = J.w | (J.h << 16) | defer; j[SJ_BWBH] = J.bw | (J.bh << 16); j[SJ_PASS0] = J.passBegin; j[SJ_PASSN] = J.passCount;
 						j[SJ_NEXT] = 0; j[SJ_OUT] = 0;
+						j[SJ_BASE_LO] = (int)(uint32_t)(uintptr_t)base; j[SJ_BASE_HI] = (int)(uint32_t)((uintptr_t)base >> 32);
 						wq[RQ_OPEN] = open + 1; wq[RQ_GEN] = s;
 					} else {
 						wq[RQ_DRY] = 1;
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					TravHit h;
 					h.t = q[4].x; h.u = h.v = 0.0f; h.slot = -1; h.inst = -1;
 					(void)shadeCore(S, P, ro, rd, h, r, cnt, stk);
-					float *so = myStage + (size_t)mySlot * slabFloats + (size_t)(item & CRH_ROLL_ITEM_MASK) * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+					float *so = sampleSlot(mySlot, item & CRH_ROLL_ITEM_MASK); so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
 					ids[CRH_IDS_FREE_END - 1u - (uint32_t)freeQ - lane] = (uint8_t)id;
 				}
 				int fin[NS];
@@ -368,7 +390,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				const BlockJob J = loadJob(o);
 				__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
 				const float *slab = myStage + (size_t)o * slabFloats;
-				for (uint32_t pix = lane; pix < (uint32_t)(J.bw * J.bh); pix += 64u) foldBlockPixel(P, J, pix, slab, fb);
+				if (!jobDeferred(o)) {          /* (a pass segment's samples are folded behind the kernel) */
+					for (uint32_t pix = lane; pix < (uint32_t)(J.bw * J.bh); pix += 64u) foldBlockPixel(P, J, pix, slab, fb);
+				}
 				__threadfence_block();                 /* ... and read before a later job overwrites them */
 				CRH_LOCKSTEP();          /* every lane has read the ring's words */
 				if (lane == 0) { wq[RQ_HEAD] = (o + 1) % NS; wq[RQ_OPEN] = open - 1; refreshJobWords(); }
@@ -455,7 +479,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					if (cont) putPathRay(q, ro, rd, r, item);
 					else {
 						mySlot = (int)(item >> CRH_ROLL_SLOT_SHIFT);
-						float *so = myStage + (size_t)mySlot * slabFloats + (size_t)(item & CRH_ROLL_ITEM_MASK) * 3; so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
+						float *so = sampleSlot(mySlot, item & CRH_ROLL_ITEM_MASK); so[0] = r.fr; so[1] = r.fg; so[2] = r.fb;
 					}
 				}
 				const unsigned long long cm = __ballot(cont), dm = __ballot(done);

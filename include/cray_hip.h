@@ -299,6 +299,12 @@ int crh_context_prepare(crh_ctx *ctx);
 #define CRH_KERNEL_ROLL 2
 #define CRH_SAMPLER_RANDOM 0
 #define CRH_SAMPLER_HALTON 1
+#define CRH_OPT_TAIL_SPLIT   16   /* rolling kernel: the work queue ENDS with this many units per wave (0..64; 0 = none) of about 64 paths — blocks of 64 / passes pixels, or, from
+                                   * 128 passes per dispatch on, single pixels whose passes are split into segments of 64: whichever waves pull the segments trace them, the
+                                   * samples are staged per pixel and folded into the frame in pass order behind the kernel (k_fold_deferred) — the same frame bit for bit.
+                                   * What it is for: the waves that finish last hold a unit they pulled just before the queue ran dry; with four jobs open a wave keeps its
+                                   * lanes busy on 64-path jobs, so the last units can be that short, and a pixel's passes need not be one wave's */
+#define CRH_TAIL_SPLIT_DEFAULT 4
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);
@@ -372,8 +378,9 @@ enum crh_math_function { CRH_MATH_SINF = 0, CRH_MATH_COSF, CRH_MATH_SINCOSF_SIN,
                          CRH_MATH_ATANF, CRH_MATH_ACOSF, CRH_MATH_ASINF, CRH_MATH_TANF, CRH_MATH_POWF, CRH_MATH_ATAN2F };
 int crh_debug_eval_math(crh_ctx *ctx, int function, const float *x_host, const float *y_host, uint64_t n, float *out_host);
 /* Debug / test entry that needs NO device: the work units crh_render_tiles would hand to the kernel for this dispatch on a GPU with
- * cu_count compute units, at the default options, in hand-out order. units_out (may be NULL): six ints per unit — the pixel rectangle
- * x0, y0, x1, y1 (clipped to its tile), the block area in pixels, the taper level (0 regular, 1 quarter blocks, 2 sixteenth blocks). */
+ * cu_count compute units, at the default options, in hand-out order. units_out (may be NULL): eight ints per unit — the pixel rectangle
+ * x0, y0, x1, y1 (clipped to its tile), the block area in pixels, the taper level (0 regular, 1 quarter blocks, 2 sixteenth blocks, 3 the 64-path
+ * units of CRH_OPT_TAIL_SPLIT), the unit's first pass and pass count (the dispatch's, except for the pass segments of split pixels). */
 int crh_debug_plan_units(const crh_render_params *params, const crh_tile *tiles, uint32_t tile_count, uint32_t cu_count, int32_t *units_out,
 						 uint64_t max_units, uint64_t *unit_count_out, int32_t *pass_chunk_out);
 

@@ -246,6 +246,46 @@ def test_rolling_and_one_unit_at_a_time_kernels_are_bit_identical(pkg, ctx, mani
         ctx.set_option(abi.OPT_PASS_CHUNK, 64)
 
 
+def test_split_pixels_fold_in_pass_order(pkg, ctx, manifest, golden_blob):
+    """CRH_OPT_TAIL_SPLIT: the rolling kernel's work queue ends with 64-path units — from 128 passes per dispatch on these are pass SEGMENTS of single pixels, traced
+    by whichever waves pull them, their samples staged per pixel and folded behind the kernel (k_fold_deferred). The frame is the one-unit-at-a-time kernel's
+    bit for bit: a ragged last segment (160 = 64 + 64 + 32), pass ranges (the second dispatch continues the running mean of the first; 30 passes are not split),
+    tile lists with ragged edges, every number of split units per wave, both counter levels; with fewer passes the last units are small blocks (no pixel split)."""
+    abi = pkg.abi
+    try:
+        for name, w, h, s in (("refraction", 48, 30, 160), ("glowmetal", 37, 19, 257), ("cfg1_scene", 64, 40, 24)):
+            b = manifest[name]["bounces"]
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+            full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob(name), w, h, s, b)
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+            for split in (4, 0, 1, 64):
+                for level in (2, 1):
+                    ctx.set_option(abi.OPT_TAIL_SPLIT, split)
+                    ctx.set_option(abi.OPT_COUNTER_LEVEL, level)
+                    ctx.clear(fb, w, h)
+                    ctx.reset_counters()
+                    ctx.render_region(fb, w, h, s, b)
+                    assert np.array_equal(ctx.download(fb, w, h), full), (name, split, level)
+                    got = ctx.counters()
+                    assert got["rays"] == cnt_full["rays"] and got["paths"] == cnt_full["paths"], (name, split, level)
+            ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+            ctx.set_option(abi.OPT_TAIL_SPLIT, 8)
+            ctx.clear(fb, w, h)
+            first = max(1, s - 30)
+            ctx.render_tiles(fb, w, h, s, b, [(0, 0, w - 1, h // 3), (0, h // 3, w - 1, h), (w - 1, 0, w, h)], first_pass=0, pass_count=first)
+            ctx.render_tiles(fb, w, h, s, b, [(0, 0, w, h)], first_pass=first)
+            assert np.array_equal(ctx.download(fb, w, h), full), name
+            tiles = pkg.tiles.quantize_image(w, h, 16, 16, pkg.tiles.ORDER_FROM_MIDDLE)
+            ctx.clear(fb, w, h)
+            for r in range(3):
+                ctx.render_tiles(fb, w, h, s, b, pkg.tiles.tiles_for_rank(tiles, r, 3))
+            assert np.array_equal(ctx.download(fb, w, h), full), name
+    finally:
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+        ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+        ctx.set_option(abi.OPT_TAIL_SPLIT, abi.TAIL_SPLIT_DEFAULT)
+
+
 def test_workgroup_kernel_is_bit_identical_to_the_wave_kernel(pkg, ctx, manifest, golden_blob):
     """CRH_OPT_KERNEL: the workgroup-cooperative form (walker / shader roles, shared path table, LDS lock) runs the same per-path
     operations as the per-wave machine — same frame, same counters, for every scheduler setting incl. the degenerate ones (never

@@ -36,7 +36,7 @@ def emu_lib():
 GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of tests that must run and pass)
     "trace_rays": (["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6),
     "frames": (["test_gpu_parity.py"], "test_image_parity_vs_reference", 6),
-    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths", 7),
+    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths", 8),
     "rare_and_wg": (["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"], "test_gpu_node_zoo or test_gpu_volumes", 3),          # (test_gpu_volumes renders with both kernel forms;
     # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
@@ -64,6 +64,7 @@ def children(emu_lib):
     start("roll", [sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "0", *ROLL_FIXTURES])
     start("steps", [sys.executable, os.path.join(EMU_DIR, "sched_counts.py"), *PINNED_STEPS])
     start("fuzz", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:9"])
+    start("fuzz_split", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_split.py"), "--seeds", "0:8"])
     start("fuzz_bvh", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:19"])
     start("fuzz_rays", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_rays.py"), "--seeds", "0:6"])
 
@@ -127,7 +128,7 @@ def test_k_pathtrace_frames_on_emulation(children):
 
 
 def test_schedules_decompositions_and_edge_cases_on_emulation(children):
-    """Shade-class batches, tiles / pass chunks / unit sizes / taper levels, the Halton sampler, empty / ragged / single-pixel dispatches,
+    """Shade-class batches, tiles / pass chunks / unit sizes / taper levels, split pixels (pass segments folded behind the kernel), the Halton sampler, empty / ragged / single-pixel dispatches,
     bounces <= 0 (k_fold_black), degenerate rays, k_to_srgb8, the error paths of the C-ABI."""
     run_gpu_tier_on_emulation(children, "schedules")
 
@@ -192,6 +193,15 @@ def test_schedule_fuzz_on_emulation(children):
     rc, text = children("fuzz")
     assert rc == 0, text[-4000:]
     assert text.count('"ok": true') == 9, text[-4000:]
+
+
+def test_split_pixel_fuzz_on_emulation(children):
+    """tools/emu_fuzz_split.py, eight seeded cases with 128..330 passes per pixel: the rolling kernel ends its work queue with pass segments of single pixels
+    (CRH_OPT_TAIL_SPLIT), staged per pixel and folded behind the kernel — random device sizes, split units per wave, unit sizes, tile covers and pass ranges give
+    the one-unit-at-a-time kernel's frame bit for bit and its ray count."""
+    rc, text = children("fuzz_split")
+    assert rc == 0, text[-4000:]
+    assert text.count('"ok": true') == 8, text[-4000:]
 
 
 def test_adversarial_rays_on_emulation(children):

@@ -1,25 +1,36 @@
 """CPU tier for the HOST logic that cuts a dispatch into work units (cray_hip.hip: planWork, through crh_debug_plan_units — no device
-needed): every pixel of every tile belongs to exactly one unit, units are handed out in list order with the small ones last, block shapes
-respect the tiles, and a unit never holds too few paths to fill a wave's path table."""
+needed): every pass of every pixel of every tile belongs to exactly one unit, units are handed out in list order with the small ones last, block
+shapes respect the tiles, a block unit never holds too few paths to fill a wave's path table, and the queue ends with the rolling kernel's 64-path units
+(CRH_OPT_TAIL_SPLIT: small blocks, or pass segments of single pixels)."""
 import numpy as np
 import pytest
 
 
-def cover(units, width, height):
-    img = np.zeros((height, width), np.int32)
-    for x0, y0, x1, y1, _, _ in units:
-        img[y0:y1, x0:x1] += 1
-    return img
+def cover(units, width, height, passes=None):
+    """How often a pixel is covered — counted in passes and divided by the dispatch's (a split pixel's segments add up to 1)."""
+    img = np.zeros((height, width), np.int64)
+    passes = passes or int(units[:, 7].max())
+    for x0, y0, x1, y1, _, _, _, n in units:
+        img[y0:y1, x0:x1] += n
+    assert (img % passes == 0).all()
+    return img // passes
 
 
 def test_full_frame_region_at_256_spp(pkg):
     units, chunk = pkg.api.plan_units(1280, 720, 256, [(0, 0, 1280, 720)])
     assert (cover(units, 1280, 720) == 1).all()
     area, level = units[:, 4], units[:, 5]
-    assert (np.diff(level) >= 0).all(), "regular blocks first, then quarter blocks, then sixteenth blocks"
+    assert (np.diff(level) >= 0).all(), "regular blocks first, then quarter blocks, then sixteenth blocks, then the 64-path units"
     assert set(area[level == 0]) == {8} and set(area[level == 1]) == {2} and set(area[level == 2]) == {1}    # 8 px x 256 spp = 2048 paths
     px = (units[:, 2] - units[:, 0]) * (units[:, 3] - units[:, 1])
-    assert 0.10 < px[level >= 1].sum() / (1280 * 720) < 0.22 and 0.02 < px[level == 2].sum() / (1280 * 720) < 0.07
+    blocks = level < 3
+    assert 0.10 < px[(level >= 1) & blocks].sum() / (1280 * 720) < 0.22 and 0.02 < px[level == 2].sum() / (1280 * 720) < 0.07
+    assert (units[blocks, 6] == 0).all() and (units[blocks, 7] == 256).all()
+    # the very end: single pixels in four segments of 64 passes, a pixel's segments next to each other and in pass order; about four units per wave
+    split = units[level == 3]
+    assert len(split) % 4 == 0 and 3 * 4096 <= len(split) <= 6 * 4096
+    assert (split[:, 4] == 1).all() and (split[:, 7] == 64).all() and (split[:, 6].reshape(-1, 4) == [0, 64, 128, 192]).all()
+    assert (split[:, :4].reshape(-1, 4, 4) == split[::4, None, :4]).all()
     assert chunk == 256
     # bottom-up, row by row: the first unit sits at the frame's origin
     assert tuple(units[0, :2]) == (0, 0)
@@ -32,6 +43,8 @@ def test_units_never_hold_fewer_paths_than_fill_a_wave(pkg):
     assert (cover(units, 3840, 2160) == 1).all()
     area, level = units[:, 4], units[:, 5]
     assert set(area[level == 0]) == {128} and set(area[level == 1]) == {64} and set(area[level == 2]) == {32}
+    assert set(area[level == 3]) == {8} and (units[:, 7] == 8).all()         # the rolling kernel's last units: 8 px x 8 passes, no pixel is split
+    assert 3 * 4096 <= (level == 3).sum() <= 6 * 4096
     assert chunk == 8
 
 
@@ -70,6 +83,9 @@ def test_small_dispatches_shrink_their_blocks_to_keep_every_wave_fed(pkg):
     assert len(units) == 33 * 7 and chunk == 1                      # 231 pixels for 4096 waves: single pixels
     units, _ = pkg.api.plan_units(1280, 720, 256, [(0, y, 1280, y + 4) for y in range(0, 720, 32)])      # an eighth of the frame
     assert units[:, 4].max() <= 2
+    img = cover(units, 1280, 720)
+    assert all((img[y:y + 4] == 1).all() for y in range(0, 720, 32)) and img.sum() == 23 * 4 * 1280
+    assert 0.03 < ((units[:, 5] == 3).sum() / 4) / (23 * 4 * 1280) <= 0.25, "split pixels: a few units per wave, at most a quarter of the share"
 
 
 def test_bad_dispatches_are_refused(pkg):

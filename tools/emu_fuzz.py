@@ -50,6 +50,7 @@ for seed in range(lo, hi):
     rng.shuffle(rects)
     cuts = sorted(set([0, s] + [rng.randrange(0, s + 1) for _ in range(rng.choice([0, 1, 2]))]))
     cfg["tiles"] = len(rects); cfg["pass_cuts"] = cuts
+    cfg["tail_split"] = rng.choice([0, 1, 4, 64])          # (the rolling kernel's 64-path units at the end of the queue; pass segments of split pixels: tools/emu_fuzz_split.py)
     os.environ["HIPEMU_CUS"] = str(cfg["cus"])
     pkg = load_package(); api, abi = pkg.api, pkg.abi
     t0 = time.time()
@@ -66,6 +67,7 @@ for seed in range(lo, hi):
     ctx.set_sched(cfg["w_node"], cfg["w_tri"], cfg["w_ctrl"], cfg["swap_min"], fill_to=cfg["fill_to"], run_num=cfg["run_num"],
                   tri_in_run=cfg["tri_in_run"], ctrl_in_run=cfg["ctrl_in_run"], shade_min=cfg["shade_min"])
     ctx.set_option(abi.OPT_SHADE_SORT, cfg["sort_from"])
+    ctx.set_option(abi.OPT_TAIL_SPLIT, cfg["tail_split"])
     if cfg["kernel"] == 1:
         ctx.set_sched_wg(linger=cfg["wg_linger"], drain_at=cfg["wg_drain_at"], max_drainers=cfg["wg_max_drainers"], partial_min=cfg["wg_partial_min"],
                          walk_min=cfg["wg_walk_min"], fill_to=cfg["wg_fill_to"])

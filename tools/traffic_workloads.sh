@@ -7,10 +7,11 @@ TAG=${1:-r03}
 cd "$(dirname "$0")/.." || exit 1
 R=$(pwd); OUT=$R/gpurun_out/traffic_$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp
-[ -f /tmp/crh_soup_10m.blob ] || python tools/make_soup_blob.py 10000000 /tmp/crh_soup_10m.blob > "$OUT/soup10m_build.json" 2>&1
+[ -n "$SKIP_SOUP10M" ] || [ -f /tmp/crh_soup_10m.blob ] || python tools/make_soup_blob.py 10000000 /tmp/crh_soup_10m.blob > "$OUT/soup10m_build.json" 2>&1      # (SKIP_SOUP10M=1: a short call)
 cd /tmp || exit 1
 while read -r key scene w h spp b; do
 	[ -z "$key" ] && continue
+	[ -n "$SKIP_SOUP10M" ] && [ "$key" = soup10m ] && continue
 	d=$OUT/$key; mkdir -p "$d"
 	echo "$spp" > "$d/spp"
 	timeout 120 rocprofv3 --pmc FETCH_SIZE -d "$d" -o fetch -- python "$R/tools/render_once.py" $scene $w $h $spp $b > "$d/fetch.log" 2>&1

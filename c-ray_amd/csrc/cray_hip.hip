@@ -1974,7 +1974,8 @@ int crh_debug_plan_units(const crh_render_params *P, const crh_tile *tiles, uint
 						 uint64_t *unit_count_out, int32_t *pass_chunk_out) {
 	if (!P || (!tiles && tile_count) || !unit_count_out || cu_count < 1) return fail(CRH_ERR_INVALID, "crh_debug_plan_units: bad argument");
 	if (P->image_width <= 0 || P->image_height <= 0 || P->pass_count < 0) return fail(CRH_ERR_INVALID, "crh_debug_plan_units: bad render parameters");
-	const crh_ctx defaults{};
+	crh_ctx defaults{};
+	if (const char *env = getenv("CRH_TAIL_SPLIT")) { if (atoi(env) >= 0 && atoi(env) <= 64) defaults.tailSplit = atoi(env); }       /* like crh_context_create */
 	const PlanKnobs knobs{defaults.unitItems, defaults.unitsPerWave, defaults.tailPercent, defaults.tail2Percent, defaults.passChunk, (int)cu_count, defaults.blocksPerCU, false,
 	                      defaults.kernel == CRH_KERNEL_ROLL ? defaults.tailSplit : 0};
 	WorkPlan W;

@@ -65,6 +65,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	CRH_EM_POW_TABLES_INIT();
 	const unsigned long long tStart = wall_clock64();
 	uint32_t unitsDone = 0;
+#ifdef CRH_EXP_ABS_TIMES       /* dev probe (tools/probe_finish.py, a variant library): when — on the chip-wide clock — a wave starts, first finds the work queue empty, and ends */
+	unsigned long long tDry = 0;
+#endif
 	LdsStack stk;
 	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
 	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
@@ -321,6 +324,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					} else {
 						wq[RQ_DRY] = 1;
 					}
+#ifdef CRH_EXP_ABS_TIMES
+					if (!have && !tDry) tDry = wall_clock64();
+#endif
 					refreshJobWords();
 				}
 				__threadfence_block();
@@ -514,8 +520,14 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		}
 	}
 	if (waveStats && lane == 0) {
+#ifdef CRH_EXP_ABS_TIMES
+		const unsigned long long tEnd = wall_clock64();
+		waveStats[2 * wave] = tStart;
+		waveStats[2 * wave + 1] = (((tDry ? tDry : tEnd) - tStart) << 32) | ((tEnd - tStart) & 0xFFFFFFFFull);
+#else
 		waveStats[2 * wave] = wall_clock64() - tStart;
 		waveStats[2 * wave + 1] = unitsDone;
+#endif
 	}
 	const bool lead = (lane == 0);
 	uint32_t v;

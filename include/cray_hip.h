@@ -299,12 +299,13 @@ int crh_context_prepare(crh_ctx *ctx);
 #define CRH_KERNEL_ROLL 2
 #define CRH_SAMPLER_RANDOM 0
 #define CRH_SAMPLER_HALTON 1
-#define CRH_OPT_TAIL_SPLIT   16   /* rolling kernel: the work queue ENDS with this many units per wave (0..64; 0 = none) of about 64 paths — blocks of 64 / passes pixels, or, from
-                                   * 128 passes per dispatch on, single pixels whose passes are split into segments of 64: whichever waves pull the segments trace them, the
-                                   * samples are staged per pixel and folded into the frame in pass order behind the kernel (k_fold_deferred) — the same frame bit for bit.
-                                   * What it is for: the waves that finish last hold a unit they pulled just before the queue ran dry; with four jobs open a wave keeps its
-                                   * lanes busy on 64-path jobs, so the last units can be that short, and a pixel's passes need not be one wave's */
-#define CRH_TAIL_SPLIT_DEFAULT 4
+#define CRH_OPT_TAIL_SPLIT   16   /* rolling kernel: the work queue ENDS with this many units per wave (0..64; 0 = none, the default) of about 64 paths — blocks of 64 / passes
+                                   * pixels, or, from 128 passes per dispatch on, single pixels whose passes are split into segments of 64: whichever waves pull the segments
+                                   * trace them, the samples are staged per pixel and folded into the frame in pass order behind the kernel (k_fold_deferred) — the same frame
+                                   * bit for bit. Built to bring the last waves of a dispatch in earlier (a pixel's passes need not be one wave's); measured: it does not —
+                                   * the finish line is the drain of the waves' path tables, not the size of the last units (profiles/r03zb_probe_tail_split.log).
+                                   * The environment variable CRH_TAIL_SPLIT sets a process's default (A/B runs of unmodified hosts) */
+#define CRH_TAIL_SPLIT_DEFAULT 0
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);

@@ -1,7 +1,8 @@
 """CPU tier for the HOST logic that cuts a dispatch into work units (cray_hip.hip: planWork, through crh_debug_plan_units — no device
 needed): every pass of every pixel of every tile belongs to exactly one unit, units are handed out in list order with the small ones last, block
-shapes respect the tiles, a block unit never holds too few paths to fill a wave's path table, and the queue ends with the rolling kernel's 64-path units
-(CRH_OPT_TAIL_SPLIT: small blocks, or pass segments of single pixels)."""
+shapes respect the tiles, a block unit never holds too few paths to fill a wave's path table, and — with CRH_OPT_TAIL_SPLIT (off by default; the plan's debug
+entry takes the process default from CRH_TAIL_SPLIT like a context does) — the queue ends with the rolling kernel's 64-path units: small blocks, or pass
+segments of single pixels."""
 import numpy as np
 import pytest
 
@@ -16,7 +17,18 @@ def cover(units, width, height, passes=None):
     return img // passes
 
 
-def test_full_frame_region_at_256_spp(pkg):
+@pytest.fixture
+def tail_split(monkeypatch):
+    monkeypatch.setenv("CRH_TAIL_SPLIT", "4")
+
+
+def test_the_default_plan_has_no_split_units(pkg):
+    units, chunk = pkg.api.plan_units(1280, 720, 256, [(0, 0, 1280, 720)])
+    assert (cover(units, 1280, 720) == 1).all() and units[:, 5].max() == 2 and (units[:, 6] == 0).all() and (units[:, 7] == 256).all() and chunk == 256
+    assert set(units[units[:, 5] == 2, 4]) == {1}
+
+
+def test_full_frame_region_at_256_spp(pkg, tail_split):
     units, chunk = pkg.api.plan_units(1280, 720, 256, [(0, 0, 1280, 720)])
     assert (cover(units, 1280, 720) == 1).all()
     area, level = units[:, 4], units[:, 5]
@@ -36,7 +48,7 @@ def test_full_frame_region_at_256_spp(pkg):
     assert tuple(units[0, :2]) == (0, 0)
 
 
-def test_units_never_hold_fewer_paths_than_fill_a_wave(pkg):
+def test_units_never_hold_fewer_paths_than_fill_a_wave(pkg, tail_split):
     """8 passes at 4K: 128-pixel blocks (every wave gets >= 8 units); the tail's blocks stop at 64 px (512 paths) and 32 px (256 paths),
     not at a quarter (32 px) and a sixteenth (8 px = 64 paths) of the block."""
     units, chunk = pkg.api.plan_units(3840, 2160, 8, [(0, 0, 3840, 2160)])
@@ -77,7 +89,7 @@ def test_the_reference_tile_lists_are_covered_once_in_list_order(order, pkg):
     assert (idx >= 0).all() and (np.diff(idx) >= 0).all()
 
 
-def test_small_dispatches_shrink_their_blocks_to_keep_every_wave_fed(pkg):
+def test_small_dispatches_shrink_their_blocks_to_keep_every_wave_fed(pkg, tail_split):
     units, chunk = pkg.api.plan_units(33, 7, 1, [(0, 0, 33, 7)])
     assert (cover(units, 33, 7) == 1).all()
     assert len(units) == 33 * 7 and chunk == 1                      # 231 pixels for 4096 waves: single pixels

@@ -56,9 +56,20 @@ def golden_ref(manifest):
     return get
 
 
+def locked_make(cmd):
+    """`make` behind a file lock: with pytest-xdist several workers reach a session fixture at once, and two makes in one directory corrupt each other's objects."""
+    import fcntl
+    with open(os.path.join(REPO, "tests", ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(cmd)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 @pytest.fixture(scope="session")
 def oracle():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"])
+    locked_make(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"])
     import oracle_py
     return oracle_py
 
@@ -67,7 +78,7 @@ def oracle():
 def emu(oracle):
     """ctypes handle of the host emulation of the device lane code (tests/emu, test infrastructure)."""
     import ctypes as C
-    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "tests", "emu")])
+    locked_make(["make", "-s", "-C", os.path.join(REPO, "tests", "emu")])
     abi = oracle.abi
     L = C.CDLL(os.path.join(REPO, "tests", "emu", "libcray_emu.so"))
     L.emu_render_region.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RenderParams), C.c_void_p, C.POINTER(abi.Counters),

@@ -29,7 +29,8 @@ EMU_LIB = os.path.join(EMU_DIR, "libcray_hip_emu.so")
 
 @pytest.fixture(scope="module")
 def emu_lib():
-    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libcray_hip_emu.so"])
+    from conftest import locked_make          # (several xdist workers may get here at once)
+    locked_make(["make", "-s", "-C", EMU_DIR, "libcray_hip_emu.so"])
     return EMU_LIB
 
 

@@ -17,7 +17,7 @@ ap.add_argument("--fixtures", default="refraction,glowmetal,volumes,fence")
 a = ap.parse_args()
 lo, hi = (int(v) for v in a.seeds.split(":"))
 fixtures = a.fixtures.split(",")
-os.environ["CRH_LIB"] = os.path.join(REPO, "tests", "emu", "libcray_hip_emu.so")
+os.environ["CRH_LIB"] = os.environ.get("FUZZ_LIB") or os.path.join(REPO, "tests", "emu", "libcray_hip_emu.so")       # FUZZ_LIB: an emulation build with an experiment's macro
 os.environ["CRH_ALLOW_EMULATION"] = "1"
 sys.path.insert(0, REPO)
 import numpy as np

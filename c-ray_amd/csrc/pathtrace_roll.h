@@ -163,7 +163,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 			 * (ST_OPEN reads the unit from the youngest job): folded earlier, the unit's remaining passes would never be generated */
 			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0 && (open > 1 || !moreChunks)) flags |= 1;
 		}
+#if defined(CRH_EXP_ENDGAME) && defined(CRH_EXP_ENDGAME_OPEN)       /* ... and holds at most CRH_EXP_ENDGAME_OPEN jobs open: what a wave has committed itself to when the queue runs dry is what it finishes late with */
+		if (open < NS && (moreChunks || (!CRH_RQ_IS_DRY(wq[RQ_DRY]) && open < ((wq[RQ_DRY] & 2) ? (int)(CRH_EXP_ENDGAME_OPEN) : NS)))) flags |= 2;       /* (the cap is on NEW units: a unit's next chunk is always opened) */
+#else
 		if (open < NS && (!CRH_RQ_IS_DRY(wq[RQ_DRY]) || moreChunks)) flags |= 2;
+#endif
 #ifdef CRH_EXP_ENDGAME         /* dev experiment (a variant library): once the work queue holds fewer than CRH_EXP_ENDGAME units per wave, a wave keeps at most CRH_EXP_ENDGAME_FILL paths
                                 * in flight (RQ_DRY bit 1 -> RQ_FLAGS bit 2): a path's bounce takes one turn of the table, so a smaller table finishes the last long paths sooner */
 		if (wq[RQ_DRY] & 2) flags |= 4;

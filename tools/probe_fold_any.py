@@ -6,6 +6,10 @@ import hashlib, json, os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("cfg2_hdr", 1280, 720, 256, 8), ("cfg4_statues", 3840, 2160, 4, 30), ("soup_1m", 2560, 1440, 16, 8), ("cfg3_venus", 1920, 1080, 16, 32)]
 UNITS = [2048, 1024, 512, 256]
+if os.environ.get("PFA_CASES"):          # e.g. PFA_CASES=cfg2_hdr,cfg4_statues ; PFA_UNITS=2048,512
+    CASES = [c for c in CASES if c[0] in os.environ["PFA_CASES"].split(",")]
+if os.environ.get("PFA_UNITS"):
+    UNITS = [int(v) for v in os.environ["PFA_UNITS"].split(",")]
 if os.environ.get("PFA_CHILD"):
     sys.path.insert(0, REPO)
     from __graft_entry__ import load_package, BUILT
@@ -22,7 +26,7 @@ if os.environ.get("PFA_CHILD"):
                 ms = ctx.kernel_time_ms()[0]; ws = ctx.wave_stats()
                 if best is None or ms < best[0]: best = (ms, float(ws[:, 0].mean() / 1e5))
             return best
-        for items in (UNITS if name == "cfg2_hdr" else UNITS[:3:2]):
+        for items in (UNITS if name == "cfg2_hdr" or os.environ.get("PFA_UNITS") else UNITS[:3:2]):
             ctx.set_option(abi.OPT_UNIT_ITEMS, items)
             full = run(pkg.render.owned_tiles(w, h, 64, 64, 1, 0, 1))
             md5 = hashlib.md5(ctx.download(fb, w, h).tobytes()).hexdigest()
@@ -36,7 +40,7 @@ vnames = (os.environ.get("VARIANTS") or "fold_any").split(",")
 vpath = lambda n: n if os.path.sep in n else os.path.join(REPO, "c-ray_amd", "_lib", "variants", n if n.endswith(".so") else n + ".so")
 libs = [("product", os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so"))] + [(os.path.basename(vpath(n))[:-3], vpath(n)) for n in vnames]
 res = {}
-for tag, lib in libs * 2:                     # each library twice, alternating (the later numbers count: warm clocks)
+for tag, lib in libs * (1 if os.environ.get("PFA_ONCE") else 2):                     # each library twice, alternating (the later numbers count: warm clocks); PFA_ONCE=1: once
     r = subprocess.run([sys.executable, __file__], env=dict(os.environ, CRH_LIB=lib, PFA_CHILD="1"), capture_output=True, text=True, timeout=200)
     line = [l for l in r.stdout.splitlines() if l.startswith("PFA_RESULT ")]
     if not line:

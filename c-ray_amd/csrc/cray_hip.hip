@@ -2376,7 +2376,11 @@ int crh_debug_wave_stats(crh_ctx *c, uint64_t *out, uint32_t max_waves) {
 	if (!c || !c->dWaveStats || !out) return fail(CRH_ERR_INVALID, "wave stats not enabled");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
+#ifdef CRH_EXP_ABS_TIMES          /* tools/probe_finish.py: the rolling kernel writes a second record per wave behind the first ones */
+	const uint32_t n = std::min<uint32_t>(max_waves, 2 * c->lastGrid * (CRH_BLOCK / 64));
+#else
 	const uint32_t n = std::min<uint32_t>(max_waves, c->lastGrid * (CRH_BLOCK / 64));
+#endif
 	HIP_TRY(hipMemcpy(out, c->dWaveStats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	return (int)n;
 }

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	uint32_t unitsDone = 0;
 #ifdef CRH_EXP_ABS_TIMES       /* dev probe (tools/probe_finish.py, a variant library): when — on the chip-wide clock — a wave starts, first finds the work queue empty, and ends */
 	unsigned long long tDry = 0;
+	bool snapDone = false;          /* ... and what it holds at the first scheduling round (checked every 16th) at which the work counter has passed the last unit: waveStats[2 * (waves + wave)] */
 #endif
 	LdsStack stk;
 	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
@@ -191,6 +192,29 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	uint32_t guard = 0;                 /* experimental kernel: a wave that spins without finishing gives up (incomplete frame, never a hung GPU) */
 	for (;;) {
 		if (++guard > 60000000u) break;
+#ifdef CRH_EXP_ABS_TIMES
+		if (waveStats && !snapDone && (guard & 15u) == 0u) {
+			uint32_t handedOut = 0;
+			if (lane == 0) handedOut = __hip_atomic_load((uint32_t *)Q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			handedOut = __builtin_amdgcn_readfirstlane(handedOut);
+			if (handedOut >= Q.total) {
+				snapDone = true;
+				if (lane == 0) {
+					const int head = wq[RQ_HEAD], open = wq[RQ_OPEN];
+					unsigned long long notGenerated = 0, notStaged = 0;
+					for (int k = 0; k < open; ++k) {
+						lds_int *oj = wq + RQ_SLOT0 + ((head + k) % NS) * SJ_WORDS;
+						const int ob = oj[SJ_BWBH], items = (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN];
+						notGenerated += (unsigned long long)max(items - oj[SJ_NEXT], 0);
+						notStaged += (unsigned long long)oj[SJ_OUT];
+					}
+					const size_t waves = (size_t)gridDim.x * (CRH_BLOCK / 64u);
+					waveStats[2 * (waves + wave)] = ((wall_clock64() - tStart) << 32) | (notGenerated & 0xFFFFFFFFull);
+					waveStats[2 * (waves + wave) + 1] = ((unsigned long long)open << 48) | ((unsigned long long)((int)CRH_PATHS - wq[RQ_FREE]) << 32) | (notStaged & 0xFFFFFFFFull);
+				}
+			}
+		}
+#endif
 		const uint32_t ph = w.phase;
 		TablePort<SAMP> port{ptab + myPath * CRH_PATH_F4};
 		const int nN = __popcll(__ballot(ph == PH_NODE)), nT = __popcll(__ballot(ph == PH_TRI)), nC = __popcll(__ballot(ph == PH_CTRL || ph == PH_NODE_SLOW));
@@ -622,6 +646,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		const unsigned long long tEnd = wall_clock64();
 		waveStats[2 * wave] = tStart;
 		waveStats[2 * wave + 1] = (((tDry ? tDry : tEnd) - tStart) << 32) | ((tEnd - tStart) & 0xFFFFFFFFull);
+		if (!snapDone) { const size_t waves = (size_t)gridDim.x * (CRH_BLOCK / 64u); waveStats[2 * (waves + wave)] = 0; waveStats[2 * (waves + wave) + 1] = 0; }
 #else
 		waveStats[2 * wave] = wall_clock64() - tStart;
 		waveStats[2 * wave + 1] = unitsDone;

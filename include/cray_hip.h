@@ -303,7 +303,7 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * pixels, or, from 128 passes per dispatch on, single pixels whose passes are split into segments of 64: whichever waves pull the segments
                                    * trace them, the samples are staged per pixel and folded into the frame in pass order behind the kernel (k_fold_deferred) — the same frame
                                    * bit for bit. Built to bring the last waves of a dispatch in earlier (a pixel's passes need not be one wave's); measured: it does not —
-                                   * the last waves are working off expensive units they pulled just before the queue ran dry (profiles/r03zb_probe_finish.log).
+                                   * the last waves are those whose path table is full when the queue runs dry: draining it takes ~1.4 ms (DESIGN.md §6, r03zb_probe_finish*).
                                    * The environment variable CRH_TAIL_SPLIT sets a process's default (A/B runs of unmodified hosts) */
 #define CRH_TAIL_SPLIT_DEFAULT 0
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */

@@ -35,6 +35,47 @@
 #define CRH_ROLL_SLOT_SHIFT 30u                /* item word of a path record: slot of its job << 30 | item index inside the job */
 #define CRH_ROLL_ITEM_MASK 0x3FFFFFFFu
 
+#ifdef CRH_EXP_COOP_FOLD
+/* dev experiment (a variant library; DESIGN.md 7: a work unit costs its wave ~25 us in OPEN + FOLD, profiles/r03zb_probe_step_clocks_units.log). foldBlockPixel gives every pixel of the block to
+ * one lane, which fetches eight passes per round trip: a 2-pixel block of 256 passes keeps two lanes busy for 32 dependent round trips while 62 wait. Here the WHOLE wave fetches: with P pixels
+ * (rounded up to a power of two, at most 32) lane l serves pixel l % P as helper l / P, every helper loads eight passes of its pixel per round, and the pixel's fold lane (helper 0) pulls them
+ * out of the helpers' registers in pass order (ds_bpermute): the same running mean over the same values in the same order, in 64 / P times fewer round trips. All 64 lanes call this together. */
+__device__ __forceinline__ void foldBlockCoop(const crh_render_params &P, const BlockJob &J, const float *stage, float *fb, uint32_t lane) {
+	uint32_t pp = 1;
+	while (pp < (uint32_t)(J.bw * J.bh)) pp <<= 1;
+	const uint32_t helpers = 64u / pp, pix = lane & (pp - 1u), me = lane / pp;
+	const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
+	const bool valid = pix < (uint32_t)(J.bw * J.bh) && px < J.w && py < J.h;
+	const int x = J.x0 + px, y = J.y0 + py;
+	float *out = fb + ((size_t)(valid ? x : 0) + (size_t)(P.image_height - ((valid ? y : 0) + 1)) * (size_t)P.image_width) * 3;
+	float r = 0.0f, g = 0.0f, b = 0.0f;
+	const bool folder = valid && me == 0u;
+	if (folder) { r = out[0]; g = out[1]; b = out[2]; }
+	const float *sp = stage + (size_t)pix * (size_t)J.passCount * 3;
+	for (int base = 0; base < J.passCount; base += (int)helpers * 8) {
+		float s[24];
+		const int mine = base + (int)me * 8;
+#pragma unroll
+		for (int i = 0; i < 24; ++i) s[i] = (valid && mine + i / 3 < J.passCount) ? sp[3 * mine + i] : 0.0f;
+		const uint32_t used = min(helpers, (uint32_t)((J.passCount - base + 7) / 8));          /* helpers that hold passes of this round (wave-uniform: every lane shuffles) */
+		for (uint32_t h = 0; h < used; ++h) {
+			const int from = (int)(h * pp + pix);
+			float t[24];
+#pragma unroll
+			for (int i = 0; i < 24; ++i) t[i] = __shfl(s[i], from);          /* all 24 exchanges in flight before the first fold waits for one (the first version waited per pass: profiles/r03zb_probe_coop_fold.log) */
+			if (folder) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int k = base + (int)h * 8 + j;
+					if (k < J.passCount) foldSample(r, g, b, t[3 * j], t[3 * j + 1], t[3 * j + 2], J.passBegin + k + 1);
+				}
+			}
+		}
+	}
+	if (folder) { out[0] = r; out[1] = g; out[2] = b; }
+}
+#endif
+
 template <int LEVEL, int WPS, bool PROG, int SAMP>
 __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 																 unsigned long long *counters,
@@ -508,6 +549,10 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
 				const float *slab = myStage + (size_t)o * slabFloats;
 				if (!jobDeferred(o)) {          /* (a pass segment's samples are folded behind the kernel) */
+#ifdef CRH_EXP_COOP_FOLD
+					if (J.bw * J.bh <= 32 && J.passCount >= 16) foldBlockCoop(P, J, slab, fb, lane);
+					else
+#endif
 					for (uint32_t pix = lane; pix < (uint32_t)(J.bw * J.bh); pix += 64u) foldBlockPixel(P, J, pix, slab, fb);
 				}
 				__threadfence_block();                 /* ... and read before a later job overwrites them */

@@ -10,20 +10,26 @@ ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
 if os.environ.get("PROBE_KERNEL"):          # 0: the one-unit-at-a-time form, 2: the rolling-units form (the default)
     ctx.set_option(abi.OPT_KERNEL, int(os.environ["PROBE_KERNEL"]))
 only = sys.argv[1:]          # optional scene names
+# PROBE_SPP=256 PROBE_UNIT_ITEMS=2048,512: the passes per pixel and the work-unit sizes (one run each) instead of the defaults
+units = [int(v) for v in os.environ["PROBE_UNIT_ITEMS"].split(",")] if os.environ.get("PROBE_UNIT_ITEMS") else [None]
 for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("cfg3_venus", 1920, 1080, 16, 32), ("soup_1m", 2560, 1440, 16, 8)):
-    if only and name not in only:
-        continue
-    scene = api.Scene(os.path.join(BUILT, name + ".blob"))
-    ctx.upload(scene)
-    fb = ctx.framebuffer(w, h)
-    ctx.clear(fb, w, h); ctx.reset_counters()
-    ctx.render_region(fb, w, h, spp, b); ctx.synchronize()
+  if only and name not in only:
+      continue
+  if os.environ.get("PROBE_SPP"): spp = int(os.environ["PROBE_SPP"])
+  scene = api.Scene(os.path.join(BUILT, name + ".blob"))
+  ctx.upload(scene)
+  fb = ctx.framebuffer(w, h)
+  for items in units:
+    if items: ctx.set_option(abi.OPT_UNIT_ITEMS, items)
+    for rep in range(2):
+        ctx.clear(fb, w, h); ctx.reset_counters()
+        ctx.render_region(fb, w, h, spp, b); ctx.synchronize()
     ms = ctx.kernel_time_ms()[0]; c = ctx.counters(); t = ctx.phase_ticks()
     rays = c["rays"]
-    print(f"{name}: {ms:.1f} ms {rays/ms/1e3:.0f} Mray/s  rays {rays} node_tests/ray {c['node_tests']/rays:.1f} tri/ray {c['tri_tests']/rays:.2f}")
+    print(f"{name}{' unit %d' % items if items else ''}: {ms:.1f} ms {rays/ms/1e3:.0f} Mray/s  rays {rays} node_tests/ray {c['node_tests']/rays:.1f} tri/ray {c['tri_tests']/rays:.2f}")
     tot = t["traverse"] + t["setup"] + t["w_setup"] + t["shade"] + t["t_swap"] + t["t_gen"]
     def line(k, ticks, n, lanes=None):
-        s = f"  {k:6s} {100.0*ticks/max(tot,1):5.1f}% of step time, {n} steps, {ticks*10.0/max(n,1):8.1f} ns/step"
+        s = f"  {k:6s} {100.0*ticks/max(tot,1):5.1f}% of step time = {ticks / 1e5 / 4096:6.2f} ms per wave (4096 waves), {n} steps, {ticks*10.0/max(n,1):8.1f} ns/step"
         if lanes is not None: s += f", {lanes/max(n,1):5.1f} lanes/step"
         print(s)
     line("node", t["traverse"], t["w_node"], t["u_node"])

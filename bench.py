@@ -83,12 +83,51 @@ def algorithmic_bytes(cnt, path_state=True):
     return b
 
 
+def _elf64_sections(data):
+    """{name: (type, addr, offset, size, link, entsize)} of a little-endian ELF64 image."""
+    import struct
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    raw = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    stroff = raw[shstrndx][4]
+    out = {}
+    for name, typ, _flags, addr, off, size, link, _info, _align, entsize in raw:
+        end = data.index(b"\0", stroff + name)
+        out[data[stroff + name:end].decode(errors="replace")] = (typ, addr, off, size, link, entsize)
+    return out, raw
+
+
+def _pathtrace_code_bytes(obj):
+    """The machine code and the kernel descriptors of every k_pathtrace* kernel of one gfx950 code object (an ELF64): (symbol name, bytes) pairs, sorted.
+    Nothing else of the object enters the fingerprint — notes, build ids, string tables, symbol order and the other kernels' code differ between two builds
+    of the same source (a clean rebuild changed 359 bytes outside .text and with them the whole-object md5) or with edits elsewhere."""
+    import struct
+    secs, raw = _elf64_sections(obj)
+    symtab = secs.get(".symtab")
+    if not symtab:
+        return None
+    _typ, _addr, off, size, link, entsize = symtab
+    stroff = raw[link][4]
+    out = []
+    for i in range(size // (entsize or 24)):
+        name, _info, _other, shndx, value, ssize = struct.unpack_from("<IBBHQQ", obj, off + i * (entsize or 24))
+        end = obj.index(b"\0", stroff + name)
+        sym = obj[stroff + name:end]
+        if b"k_pathtrace" not in sym or not ssize or shndx == 0 or shndx >= len(raw):
+            continue
+        _n, styp, _f, saddr, soff, ssz = raw[shndx][:6]
+        if styp == 8:          # SHT_NOBITS
+            continue
+        start = soff + (value - saddr)
+        out.append((sym, obj[start:start + ssize]))
+    return sorted(out)
+
+
 def kernel_source_md5():
-    """Fingerprint of the DEVICE code of the path-tracing kernels in the built library: the gfx950 code object of csrc/cray_hip.hip inside
-    the .hip_fatbin section of libcray_hip.so (the section bundles one code object per translation unit; the GPU BVH builder's is the other
-    one). PMC figures in profiles/ are quoted only while they describe the kernels that are running — host-side edits and edits to the BVH
-    builder do not invalidate them, any edit that changes the path-tracing code object does. (Until r02e the whole section was hashed:
-    e0fb1a6f... is the same device code as d699817a... under this definition.)"""
+    """Fingerprint of the DEVICE code of the path-tracing kernels in the built library: the .text bytes and the kernel descriptors of the k_pathtrace* symbols of
+    the gfx950 code object of csrc/cray_hip.hip inside the .hip_fatbin section of libcray_hip.so. PMC figures in profiles/ are quoted only while they describe the
+    kernels that are running: host-side edits, edits to the other kernels and a REBUILD of the same source do not change the fingerprint (round 3 hashed the whole
+    code object, which a rebuild changed with identical machine code); any edit that changes the path-tracing kernels' instructions does."""
     import hashlib
     import struct
     path = os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so")
@@ -96,21 +135,11 @@ def kernel_source_md5():
         data = f.read()
     if data[:4] != b"\x7fELF" or data[4] != 2:
         return hashlib.md5(data).hexdigest()
-    shoff, = struct.unpack_from("<Q", data, 0x28)
-    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
-    def sec(i):
-        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
-        return name, off, size
-    _, stroff, strsize = sec(shstrndx)
-    fat = None
-    for i in range(shnum):
-        name, off, size = sec(i)
-        end = data.index(b"\0", stroff + name)
-        if data[stroff + name:end] == b".hip_fatbin":
-            fat = data[off:off + size]
-            break
-    if fat is None:
+    secs, _ = _elf64_sections(data)
+    if ".hip_fatbin" not in secs:
         return hashlib.md5(data).hexdigest()
+    _t, _a, off, size = secs[".hip_fatbin"][:4]
+    fat = data[off:off + size]
     magic, objects, pos = b"__CLANG_OFFLOAD_BUNDLE__", [], 0
     while True:                                    # one offload bundle per translation unit: {magic, n, n x (offset, size, triple)}
         p = fat.find(magic, pos)
@@ -130,7 +159,12 @@ def kernel_source_md5():
         return hashlib.md5(fat).hexdigest()
     h = hashlib.md5()
     for obj in objects:
-        h.update(obj)
+        code = _pathtrace_code_bytes(obj) if obj[:4] == b"\x7fELF" else None
+        if not code:
+            h.update(obj)
+            continue
+        for sym, blob in code:
+            h.update(sym); h.update(blob)
     return h.hexdigest()
 
 
@@ -145,6 +179,18 @@ def measured_profile(workload_key):
     if t.get("source_md5") != kernel_source_md5() or t.get("workload", "cfg2") != workload_key:
         return None, None
     return t.get("hbm_bytes_per_launch"), t.get("valu")
+
+
+def fractions(alg_bytes, traffic_bytes, ms):
+    """The two roofline fractions of one launch, by name, so that neither is mistaken for the other: frac_algorithmic = the bytes a cache-less machine
+    would move (scene records touched) / time / HBM peak — it EXCEEDS 1 wherever L2 and the 256 MB Infinity Cache serve most records, and says so;
+    frac_measured_traffic = the measured L2<->fabric volume (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, MALL hits included) / time / HBM peak, null when
+    profiles/ holds no PMC measurement of this device code and workload."""
+    fa = alg_bytes / ms / 1e6 / HBM_PEAK_GBS
+    out = {"frac_algorithmic": round(fa, 4), "frac_measured_traffic": round(traffic_bytes / ms / 1e6 / HBM_PEAK_GBS, 4) if traffic_bytes else None}
+    if fa > 1.0:
+        out["frac_note"] = "algorithmic fraction above 1: the records were served by L2 / Infinity Cache, not by HBM (see frac_measured_traffic)"
+    return out
 
 
 def measure_other_workloads(api, abi, built_dir):
@@ -190,13 +236,75 @@ def measure_other_workloads(api, abi, built_dir):
             out[key] = {"workload": wl["what"].format(W=w, H=h, SPP=f"{spp} of {wl['samples']}", B=b), "mrays": round(full["rays"] / ms / 1e3, 1), "kernel_ms": round(ms, 2),
                         "rays": full["rays"], "rays_per_path": round(full["rays"] / max(full["paths"], 1), 2),
                         "node_tests_per_ray": round(full["node_tests"] / max(full["rays"], 1), 1), "tri_tests_per_ray": round(full["tri_tests"] / max(full["rays"], 1), 1),
-                        "bytes_per_ray": round(alg / max(full["rays"], 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "bytes_per_ray": round(alg / max(full["rays"], 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1),
+                        **fractions(alg, traffic, ms),
                         "traffic": traffic, "setup_s": round(time.perf_counter() - t0 - 4 * ms / 1e3, 2)}
             ctx.close()
             scene.close()
         except Exception as e:      # a missing blob / failed build must not take the headline line with it
             out[key] = {"failed": f"{type(e).__name__}: {e}"[:300]}
     return out
+
+
+SCALING_CFG4_SPP = 16
+
+
+def scaling_cfg4(api, render, torch, dist, built_dir, local_rank, rank, world, reps=3):
+    """BASELINE.json configs[3] — input/statues.json 3840x2160, the scene the 1/2/4/8-GPU curve is quoted on — at a stated reduced sample count, with the
+    SAME share + gather path as the headline (4-row strips per rank, the owned strips gathered on rank 0), emitted at every N (N = 1 included) so that
+    the points of the driver's scaling run divide. Outside the timed region. Returns {mrays, ms, gather_ms, rays, spp} on rank 0 (ms = max over ranks)."""
+    wl = WORKLOADS["cfg4"]
+    blob = os.path.join(built_dir, wl["blob"] + ".blob")
+    have = torch.tensor([1.0 if os.path.exists(blob) else 0.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    if world > 1:
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+    if not float(have[0]):
+        return {"skipped": f"{blob} not built"}
+    W, H, B, spp = wl["width"], wl["height"], wl["bounces"], SCALING_CFG4_SPP
+    scene = api.Scene(blob)
+    fr = render.FrameRenderer(api, scene, W, H, device=local_rank, rank=rank, world=world, tile=wl["tile"], order=wl["tile_order"])
+    fr.ctx.set_option(api.abi.OPT_COUNTER_LEVEL, 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fr.render(spp, B); fr.reduce(dist); barrier()          # warm-up (code object, buffers, the collective's first use)
+    fr.ctx.reset_counters()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    best = None
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(fr.stream):
+            e0.record(fr.stream)
+        fr.render(spp, B)
+        with torch.cuda.stream(fr.stream):
+            e1.record(fr.stream)
+        fr.reduce(dist)
+        with torch.cuda.stream(fr.stream):
+            e2.record(fr.stream)
+        barrier()
+        wall = (time.perf_counter() - t0) * 1e3
+        rec = (wall, e0.elapsed_time(e1), e1.elapsed_time(e2))
+        best = rec if best is None or rec[0] < best[0] else best
+    rays = fr.ctx.counters()["rays"] / reps
+    tt = torch.tensor([best[0], best[1], best[2], rays], dtype=torch.float64, device=fr.device)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        wall_ms, render_ms, gather_ms, total_rays = float(tmax[0]), float(tmax[1]), float(tmax[2]), float(tt[3])
+    else:
+        wall_ms, render_ms, gather_ms, total_rays = (float(v) for v in tt)
+    fr.close()
+    scene.close()
+    return {"workload": wl["what"].format(W=W, H=H, SPP=f"{spp} of {wl['samples']}", B=B), "spp": spp, "n_gpus": world,
+            "mrays": round(total_rays / wall_ms / 1e3, 1), "ms": round(wall_ms, 3), "render_ms": round(render_ms, 3), "gather_ms": round(gather_ms, 3),
+            "rays": int(total_rays), "scaling": "strong (the frame is a fixed job)",
+            "note": "best of %d frames, wall clock between barriers, max over ranks; render_ms / gather_ms = stream events around this rank's dispatch / the strip gather "
+                    "(at N > 1 a rank's gather_ms includes waiting for the slowest peer)" % reps}
 
 
 def parity_columns(img, ref):
@@ -240,6 +348,7 @@ def dropin_timing(workload):
     phase = st.get("render_phase_ms", st["render_ms"])
     return {"program": "c-ray_amd/_lib/c-ray-hip < hdr.json (1 GPU)",
             "render_phase_ms": phase, "mrays": round(st["rays"] / phase / 1e3, 1),
+            "mrays_over_frame_ms": round(st["rays"] / st["frame_ms"] / 1e3, 1) if st.get("frame_ms") else None,
             "render_ms": st["render_ms"], "kernel_ms": st.get("kernel_ms"), "dispatches": st.get("dispatches"), "launch_host_ms": st.get("launch_host_ms"),
             "resolve_srgb_ms": st["resolve_srgb_ms"], "download_ms": st.get("download_ms"), "gather_ms": st.get("gather_ms"),
             "frame_ms": st.get("frame_ms"), "setup_ms": st.get("setup_ms"), "flatten_ms": st["flatten_ms"], "context_ms": st.get("context_ms"),
@@ -248,7 +357,9 @@ def dropin_timing(workload):
             "note": "render_phase_ms = SURVEY 8(d)'s phase: the timer of src/c-ray.c:279-281 around renderFrame() (frame_ms) minus the set-up (setup_ms: everything "
                     "before the GPU was ready to dispatch — context + code objects + per-wave buffers, which run beside the flattener, then the scene upload); it holds "
                     "the dispatch (render_ms; kernel_ms = its GPU time), the 8-bit conversion on the device + its download (resolve_srgb_ms), the float "
-                    "buffer's download and the host in between; mrays = rays / render_phase_ms. process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
+                    "buffer's download and the host in between; mrays = rays / render_phase_ms. mrays_over_frame_ms = rays / frame_ms: the rate over what the REFERENCE's own "
+                    "timer (c-ray.c:279-281) would show a user of the drop-in — set-up included — and the figure to hold against the reference's CPU rate, whose timer "
+                    "includes its (BVH-free, cheap) set-up too. process_wall_s also holds JSON / OBJ parsing and the GPU BVH build"}
 
 
 def dropin_iterative(workload, samples=129):
@@ -367,9 +478,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gather_events = []
+
     def step():
         fr.render(SPP, B)
-        fr.reduce(dist)
+        if world > 1:              # the gather's own stream time, reported beside the frame (it is inside the timed region either way)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(fr.stream)
+            fr.reduce(dist)
+            ev[1].record(fr.stream)
+            gather_events.append(ev)
+        else:
+            fr.reduce(dist)
 
     # counting pass (outside the timed region): every crh_counters field for the roofline's algorithmic bytes
     ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
@@ -390,15 +510,26 @@ def main():
     elapsed = time.perf_counter() - t0
     cnt = ctx.counters()
     _, kernel_total_ms, launches = ctx.kernel_time_ms()
+    kernel_name = ctx.last_kernel_name()
+    gather_ms = sum(a_.elapsed_time(b_) for a_, b_ in gather_events[-a.steps:]) / max(a.steps, 1) if gather_events else 0.0
 
-    tt = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["paths"])], dtype=torch.float64, device=fr.device)
+    tt = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["paths"]), gather_ms, kernel_total_ms / max(launches, 1)], dtype=torch.float64, device=fr.device)
+    kernel_ms_max = float(tt[4])
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
+        elapsed, gather_ms, kernel_ms_max = float(tmax[0]), float(tmax[3]), float(tmax[4])
     total_rays, total_paths = float(tt[1]), float(tt[2])
 
+    cfg4_scaling = None
+    if a.workload == "cfg2" and SPP == WORKLOAD["samples"] and not a.no_others:
+        try:
+            cfg4_scaling = scaling_cfg4(api, render, torch, dist, BUILT, local_rank, rank, world)
+        except Exception as e:          # must not take the headline line with it
+            cfg4_scaling = {"failed": f"{type(e).__name__}: {e}"[:300]}
+            if world > 1:
+                raise
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = total_rays / elapsed / 1e6
@@ -423,18 +554,29 @@ def main():
                        "baseline_config": {"cfg2": "configs[1] (the 1-GPU headline; at N > 1 a STRONG-scaling run of the same 88 ms frame)", "cfg3": "configs[2]",
                                            "cfg4": "configs[3] (the scene BASELINE.json quotes the 1/2/4/8-GPU curve on: --workload cfg4)",
                                            "soup": "configs[4] at 1 M triangles", "soup10m": "configs[4]"}.get(a.workload)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "gather_ms": round(gather_ms, 3) if world > 1 else None, "kernel_ms_max_over_ranks": round(kernel_ms_max, 3),
+            # `bound` is set from the evidence: the PMC run of THIS device code (profiles/, fingerprint-gated) shows the vector ALU issuing most of the time
+            # -> "valu-issue"; without such a run the label is the metric's nominal one, "hbm", and the note says that nothing measured backs it
+            "roofline": {"bound": "valu-issue" if (valu or {}).get("pipe_busy", 0) >= 0.7 else "hbm",
+                         "bound_evidence": ("profiles/hbm_traffic.json `valu` (rocprofv3 PMC of this device code): VALU pipe busy %.0f %%, lane utilisation %.0f %%"
+                                            % (100 * valu["pipe_busy"], 100 * valu.get("lane_utilisation", 0))) if valu and valu.get("pipe_busy") else
+                                           "no PMC run of this device code in profiles/ (fingerprint mismatch): nominal label",
+                         "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_scene / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_pathtrace_roll", "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
+                         **fractions(alg_no_state, traffic if world == 1 else None, avg_kernel_ms),
+                         "kernel": kernel_name, "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
                          "bytes_per_ray": round(alg_no_state / max(full["rays"], 1), 1),
                          "frac_with_path_state": round(frac_state, 5),
-                         "what_it_is": "ALGORITHMIC rate, not an HBM measurement: scene records touched (node / triangle / instance / shading / texel), "
-                                       "B_state = 0 (SURVEY 8(d): persistent megakernel), divided by the launch time. Most of those bytes are served by L2 and the "
-                                       "256 MB Infinity Cache; `traffic` is the measured L2<->fabric volume (FETCH_SIZE x2 + WRITE_SIZE, MALL hits included) and is "
-                                       "null whenever profiles/hbm_traffic.json was not measured on these kernel sources / this workload. frac_with_path_state adds "
-                                       "152 B/ray for the per-wave path table",
+                         "what_it_is": "`achieved` / `frac` (= frac_algorithmic) are the ALGORITHMIC rate, not an HBM measurement: scene records touched (node / triangle / "
+                                       "instance / shading / texel), B_state = 0 (SURVEY 8(d): persistent megakernel), divided by the launch time. Most of those bytes are "
+                                       "served by L2 and the 256 MB Infinity Cache; `traffic` is the measured L2<->fabric volume per launch (FETCH_SIZE x2 + WRITE_SIZE, MALL "
+                                       "hits included), frac_measured_traffic the same over time and HBM peak; both are null whenever profiles/hbm_traffic.json was not "
+                                       "measured on this device code (fingerprint of the k_pathtrace* machine code) / this workload. frac_with_path_state adds 152 B/ray for "
+                                       "the per-wave path table. The kernel is bound by vector-instruction issue (`valu`), not by HBM",
                          "valu": valu},
         }
+        if cfg4_scaling is not None:
+            out["scaling_cfg4"] = cfg4_scaling
         if world == 1 and not a.no_cpu:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import oracle_py

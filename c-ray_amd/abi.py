@@ -5,11 +5,11 @@ Field order and sizes must match the header exactly (tests/test_abi.py checks th
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 NODE_NONE = 0xFFFFFFFF
-OPT_COUNTER_LEVEL, OPT_BLOCKS_PER_CU, OPT_PASS_CHUNK, OPT_WAVES_PER_SIMD, OPT_WAVE_STATS, OPT_UNIT_ITEMS, OPT_SCHED_WEIGHTS, OPT_UNITS_PER_WAVE, OPT_SAMPLER, OPT_TAIL_PERCENT, OPT_SCHED_RUNS, OPT_KERNEL, OPT_SCHED_WG, OPT_TRACE_SLABS, OPT_SHADE_SORT, OPT_TAIL_SPLIT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
+OPT_COUNTER_LEVEL, OPT_BLOCKS_PER_CU, OPT_PASS_CHUNK, OPT_WAVES_PER_SIMD, OPT_WAVE_STATS, OPT_UNIT_ITEMS, OPT_SCHED_WEIGHTS, OPT_UNITS_PER_WAVE, OPT_SAMPLER, OPT_TAIL_PERCENT, OPT_SCHED_RUNS, OPT_KERNEL, OPT_SCHED_WG, OPT_TRACE_SLABS, OPT_SHADE_SORT, OPT_TAIL_SPLIT, OPT_ROUND_LIMIT, OPT_RENDER_SLABS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18
 TAIL_SPLIT_DEFAULT = 0        # CRH_TAIL_SPLIT_DEFAULT
 TRACE_SLABS_LITERAL, TRACE_SLABS_EXACT = 0, 1
 KERNEL_WAVE, KERNEL_WG, KERNEL_ROLL = 0, 1, 2
@@ -125,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "crh_scene_upload", "crh_framebuffer_alloc", "crh_framebuffer_free", "crh_framebuffer_clear",
     "crh_framebuffer_download", "crh_framebuffer_to_srgb8", "crh_render_region", "crh_render_tiles",
     "crh_synchronize", "crh_frames_reduce", "crh_frames_gather", "crh_frames_prepare", "crh_context_prepare", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
-    "crh_blob_save", "crh_blob_load", "crh_blob_free", "crh_bvh_build_triangles", "crh_debug_eval_math", "crh_debug_plan_units",
+    "crh_blob_save", "crh_blob_load", "crh_blob_free", "crh_bvh_build_triangles", "crh_debug_eval_math", "crh_debug_plan_units", "crh_last_kernel_name",
 ]
 MATH_FUNCTIONS = ("sinf", "cosf", "sincosf_sin", "sincosf_cos", "logf", "log10f", "atanf", "acosf", "asinf", "tanf", "powf", "atan2f")   # enum crh_math_function
 

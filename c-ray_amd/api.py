@@ -71,6 +71,7 @@ def library():
         "crh_counters_get": (C.c_int, [ctx, C.POINTER(abi.Counters)]),
         "crh_counters_reset": (C.c_int, [ctx]),
         "crh_kernel_time_ms": (C.c_int, [ctx, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "crh_last_kernel_name": (C.c_char_p, [ctx]),
         "crh_trace_rays": (C.c_int, [ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
         "crh_debug_eval_math": (C.c_int, [ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
         "crh_bvh_build_triangles": (C.c_int, [ctx, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -241,6 +242,10 @@ class Context:
         last, total, n = C.c_float(), C.c_double(), C.c_uint64()
         _check(self.L.crh_kernel_time_ms(self.h, C.byref(last), C.byref(total), C.byref(n)), "crh_kernel_time_ms")
         return last.value, total.value, n.value
+
+    def last_kernel_name(self):
+        """The instantiation of the path-tracing kernel launched last, as a profiler names it ("" before the first dispatch)."""
+        return (self.L.crh_last_kernel_name(self.h) or b"").decode()
 
     def bvh_build_triangles(self, polys_ptr, poly_count, vertices_ptr, vertex_count):
         """buildBottomLevelBvh on the GPU: (nodes uint32[n, 8] = crh_bvh_node records, prim order int32[count], stats dict)."""

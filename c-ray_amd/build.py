@@ -28,8 +28,15 @@ LIB = os.path.join(OUT_DIR, "libcray_hip.so")
 SOURCES = [os.path.join(CSRC, "cray_hip.hip"), os.path.join(CSRC, "bvh_build.hip")]
 CXX_SOURCES = [os.path.join(CSRC, "scene_compile.cpp")]      # host-only C++ (g++, -ffp-contract=off: prepared triangles)
 C_SOURCES = [os.path.join(HERE, "host", "scene_blob.c")]
-DEPS = SOURCES + CXX_SOURCES + C_SOURCES + [os.path.join(CSRC, "pt_device.h"), os.path.join(CSRC, "exact_math.h"), os.path.join(CSRC, "scene_compile.h"), os.path.join(CSRC, "ctx_access.h"),
-                              os.path.join(REPO, "include", "cray_hip.h"), os.path.abspath(__file__)]
+def deps():
+    """Everything the library is built from: every file of csrc/ (the kernels are header-heavy: pathtrace_roll.h holds the hot kernel) and of include/,
+    the C sources, and this script. tests/test_abi.py checks that each file cray_hip.hip / bvh_build.hip #include is in here."""
+    out = list(C_SOURCES) + [os.path.abspath(__file__)]
+    for d in (CSRC, os.path.join(REPO, "include")):
+        out += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hip", ".cpp", ".c")))
+    return out
+
+
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize",
          "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
@@ -39,7 +46,7 @@ def up_to_date():
     if not os.path.exists(LIB):
         return False
     t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(d) <= t for d in DEPS)
+    return all(os.path.getmtime(d) <= t for d in deps())
 
 
 def build(force=False, verbose=True, extra=()):

@@ -35,51 +35,11 @@
 #define CRH_ROLL_SLOT_SHIFT 30u                /* item word of a path record: slot of its job << 30 | item index inside the job */
 #define CRH_ROLL_ITEM_MASK 0x3FFFFFFFu
 
-#ifdef CRH_EXP_COOP_FOLD
-/* dev experiment (a variant library; DESIGN.md 7: a work unit costs its wave ~25 us in OPEN + FOLD, profiles/r03zb_probe_step_clocks_units.log). foldBlockPixel gives every pixel of the block to
- * one lane, which fetches eight passes per round trip: a 2-pixel block of 256 passes keeps two lanes busy for 32 dependent round trips while 62 wait. Here the WHOLE wave fetches: with P pixels
- * (rounded up to a power of two, at most 32) lane l serves pixel l % P as helper l / P, every helper loads eight passes of its pixel per round, and the pixel's fold lane (helper 0) pulls them
- * out of the helpers' registers in pass order (ds_bpermute): the same running mean over the same values in the same order, in 64 / P times fewer round trips. All 64 lanes call this together. */
-__device__ __forceinline__ void foldBlockCoop(const crh_render_params &P, const BlockJob &J, const float *stage, float *fb, uint32_t lane) {
-	uint32_t pp = 1;
-	while (pp < (uint32_t)(J.bw * J.bh)) pp <<= 1;
-	const uint32_t helpers = 64u / pp, pix = lane & (pp - 1u), me = lane / pp;
-	const int px = (int)(pix % (uint32_t)J.bw), py = (int)(pix / (uint32_t)J.bw);
-	const bool valid = pix < (uint32_t)(J.bw * J.bh) && px < J.w && py < J.h;
-	const int x = J.x0 + px, y = J.y0 + py;
-	float *out = fb + ((size_t)(valid ? x : 0) + (size_t)(P.image_height - ((valid ? y : 0) + 1)) * (size_t)P.image_width) * 3;
-	float r = 0.0f, g = 0.0f, b = 0.0f;
-	const bool folder = valid && me == 0u;
-	if (folder) { r = out[0]; g = out[1]; b = out[2]; }
-	const float *sp = stage + (size_t)pix * (size_t)J.passCount * 3;
-	for (int base = 0; base < J.passCount; base += (int)helpers * 8) {
-		float s[24];
-		const int mine = base + (int)me * 8;
-#pragma unroll
-		for (int i = 0; i < 24; ++i) s[i] = (valid && mine + i / 3 < J.passCount) ? sp[3 * mine + i] : 0.0f;
-		const uint32_t used = min(helpers, (uint32_t)((J.passCount - base + 7) / 8));          /* helpers that hold passes of this round (wave-uniform: every lane shuffles) */
-		for (uint32_t h = 0; h < used; ++h) {
-			const int from = (int)(h * pp + pix);
-			float t[24];
-#pragma unroll
-			for (int i = 0; i < 24; ++i) t[i] = __shfl(s[i], from);          /* all 24 exchanges in flight before the first fold waits for one (the first version waited per pass: profiles/r03zb_probe_coop_fold.log) */
-			if (folder) {
-#pragma unroll
-				for (int j = 0; j < 8; ++j) {
-					const int k = base + (int)h * 8 + j;
-					if (k < J.passCount) foldSample(r, g, b, t[3 * j], t[3 * j + 1], t[3 * j + 2], J.passBegin + k + 1);
-				}
-			}
-		}
-	}
-	if (folder) { out[0] = r; out[1] = g; out[2] = b; }
-}
-#endif
 
 template <int LEVEL, int WPS, bool PROG, int SAMP>
 __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 																 unsigned long long *counters,
-																 float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll) {
+																 float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll, unsigned int *errFlag) {
 	__shared__ uint32_t s_stack[CRH_STACK_LDS * CRH_BLOCK];
 	__shared__ uint32_t s_park[CRH_PARK_SLOTS * CRH_BLOCK];
 	/* wave-uniform words: stack fill levels, shade-class counts, the ring of job slots */
@@ -99,20 +59,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	                                  * segment of a split pixel (BlockQueue: firstMicro, segs > 1; SJ_WH bit 30), the segment's place in Q.defer: k_fold_deferred folds those */
 	       SJ_WORDS };
 	enum { SJ_WH_DEFER = 1 << 30 };
-#ifndef CRH_EXP_FOLD_ANY
 	enum { SJ_WH_H_MASK = 0x3FFF };
-#else
-	/* dev experiment (a variant library; DESIGN.md 6 / 7: measured, no gain): the job slots are a SET instead of a ring — RQ_HEAD holds the mask of open slots, a job is folded as
-	 * soon as it is complete, whatever its slot (RQ_FLAGS bits 8..9: which), so that one long-running job does not keep the wave from cycling its other slots. Only the chunks of
-	 * one unit must fold in pass order: a job that continues a unit carries its predecessor's slot + 1 in SJ_WH bits 26..28 until that one is folded */
-	enum { SJ_WH_H_MASK = 0x3FF };
-	enum { SJ_WH_PRED_SHIFT = 26, SJ_WH_PRED_MASK = 7 << 26 };
-#endif
-#ifdef CRH_EXP_ENDGAME
-#define CRH_RQ_IS_DRY(v) (((v) & 1) != 0)
-#else
 #define CRH_RQ_IS_DRY(v) ((v) != 0)
-#endif
 	enum { NS = (int)CRH_ROLL_SLOTS, RQ_WORDS = RQ_SLOT0 + NS * SJ_WORDS };
 	static_assert(NS >= 2 && NS <= 4, "2..4 job slots (two bits of the item word)");
 	static_assert((CRH_STACK_LDS + CRH_PARK_SLOTS) * CRH_BLOCK * 4 + (CRH_BLOCK / 64) * (CRH_ROLL_IDS_BYTES + RQ_WORDS * 4) + 512 + 256 + CRH_INST_LDS_BYTES + CRH_SHADE_LDS_BYTES <= 40960, "4 blocks per CU share 160 KB of LDS (incl. powf's tables)");
@@ -127,9 +75,6 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	LdsStack stk;
 	stk.lds = (lds_u32 *)&s_stack[threadIdx.x];
 	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
-#if CRH_TLAS_LDS
-	stk.tlas = nullptr;
-#endif
 	CRH_STAGE_SHADE_TABLES();
 	CRH_STAGE_INSTANCE_TABLES();
 	CountersT<LEVEL, PROG> cnt;
@@ -170,28 +115,6 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	auto jobDeferred = [&](int slot) { return (wq[RQ_SLOT0 + slot * SJ_WORDS + SJ_WH] & SJ_WH_DEFER) != 0; };
 	/* lane 0, after it changed a job's words: the two words the scheduler reads every round */
 	auto refreshJobWords = [&]() {
-#ifdef CRH_EXP_FOLD_ANY
-		const int mask = wq[RQ_HEAD], gen = wq[RQ_GEN];
-		int left = 0, flags = 0, nOpen = 0;
-		bool moreChunks = false;
-		if ((mask >> gen) & 1) {
-			lds_int *gj = wq + RQ_SLOT0 + gen * SJ_WORDS;
-			const int gb = gj[SJ_BWBH];
-			left = (gb & 0xFFFF) * (gb >> 16) * gj[SJ_PASSN] - gj[SJ_NEXT];
-			if (left < 0) left = 0;
-			moreChunks = !(gj[SJ_WH] & SJ_WH_DEFER) && gj[SJ_PASS0] + gj[SJ_PASSN] < passEnd;
-		}
-		for (int t = NS - 1; t >= 0; --t) {
-			if (!((mask >> t) & 1)) continue;
-			++nOpen;
-			lds_int *oj = wq + RQ_SLOT0 + t * SJ_WORDS;
-			const int ob = oj[SJ_BWBH];
-			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0 && !(oj[SJ_WH] & SJ_WH_PRED_MASK) && !(t == gen && moreChunks)) flags = 1 | (t << 8);
-		}
-		if (nOpen < NS && (!CRH_RQ_IS_DRY(wq[RQ_DRY]) || moreChunks)) flags |= 2;
-		wq[RQ_OPEN] = nOpen;
-		wq[RQ_GENLEFT] = left; wq[RQ_FLAGS] = flags;
-#else
 		const int head = wq[RQ_HEAD], open = wq[RQ_OPEN];
 		int left = 0, flags = 0;
 		bool moreChunks = false;             /* the youngest job's unit has passes left: the next job is its following chunk, whatever the queue holds */
@@ -205,17 +128,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 			 * (ST_OPEN reads the unit from the youngest job): folded earlier, the unit's remaining passes would never be generated */
 			if (oj[SJ_NEXT] >= (ob & 0xFFFF) * (ob >> 16) * oj[SJ_PASSN] && oj[SJ_OUT] == 0 && (open > 1 || !moreChunks)) flags |= 1;
 		}
-#if defined(CRH_EXP_ENDGAME) && defined(CRH_EXP_ENDGAME_OPEN)       /* ... and holds at most CRH_EXP_ENDGAME_OPEN jobs open: what a wave has committed itself to when the queue runs dry is what it finishes late with */
-		if (open < NS && (moreChunks || (!CRH_RQ_IS_DRY(wq[RQ_DRY]) && open < ((wq[RQ_DRY] & 2) ? (int)(CRH_EXP_ENDGAME_OPEN) : NS)))) flags |= 2;       /* (the cap is on NEW units: a unit's next chunk is always opened) */
-#else
 		if (open < NS && (!CRH_RQ_IS_DRY(wq[RQ_DRY]) || moreChunks)) flags |= 2;
-#endif
-#ifdef CRH_EXP_ENDGAME         /* dev experiment (a variant library): once the work queue holds fewer than CRH_EXP_ENDGAME units per wave, a wave keeps at most CRH_EXP_ENDGAME_FILL paths
-                                * in flight (RQ_DRY bit 1 -> RQ_FLAGS bit 2): a path's bounce takes one turn of the table, so a smaller table finishes the last long paths sooner */
-		if (wq[RQ_DRY] & 2) flags |= 4;
-#endif
 		wq[RQ_GENLEFT] = left; wq[RQ_FLAGS] = flags;
-#endif
 	};
 
 	if (lane == 0) {
@@ -230,9 +144,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	memset(&w, 0, sizeof(w));
 	w.phase = PH_IDLE;
 	uint32_t myPath = 0;
-	uint32_t guard = 0;                 /* experimental kernel: a wave that spins without finishing gives up (incomplete frame, never a hung GPU) */
+	/* a wave that has run K.roundLimit scheduling rounds without finishing gives up — never a hung GPU — and says so: the dispatch's error word (host-visible) makes
+	 * crh_synchronize / crh_framebuffer_download return CRH_ERR_HIP "incomplete frame" (the default limit is hours of one wave's work; CRH_OPT_ROUND_LIMIT) */
+	uint32_t guard = (uint32_t)K.roundLimit;
 	for (;;) {
-		if (++guard > 60000000u) break;
+		if (--guard == 0u) { if (lane == 0) atomicOr(errFlag, CRH_ERRFLAG_ROUND_LIMIT); break; }
 #ifdef CRH_EXP_ABS_TIMES
 		if (waveStats && !snapDone && (guard & 15u) == 0u) {
 			uint32_t handedOut = 0;
@@ -268,13 +184,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		const bool canGen = genLeft && freeQ >= 64;
 		/* the next job can be opened when the job being generated has no items left and a slot is free */
 		const bool canOpen = !genLeft && (jobFlags & 2);
-		const bool foldReady = (jobFlags & 1) != 0;          /* (CRH_EXP_FOLD_ANY: bits 8..9 say which slot) */
-#ifdef CRH_EXP_ENDGAME
-		const int fillTo = (jobFlags & 4) ? min(K.fillTo, (int)(CRH_EXP_ENDGAME_FILL)) : K.fillTo;
-		const bool wantGen = raysQ < 64 && (((int)CRH_PATHS - freeQ) < fillTo || (nE + nF > 0 && raysQ < nE + nF));
-#else
+		const bool foldReady = (jobFlags & 1) != 0;
 		const bool wantGen = raysQ < 64 && (((int)CRH_PATHS - freeQ) < K.fillTo || (nE + nF > 0 && raysQ < nE + nF));
-#endif
 		const int walkers = nN + nT + nC;
 		enum { ST_NODE, ST_TRI, ST_CTRL, ST_SWAP, ST_GEN, ST_SHADE, ST_MISS, ST_OPEN, ST_FOLD, ST_END };
 		int pick;
@@ -380,44 +291,29 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 #endif
 					const f4 *q = ptab + myPath * CRH_PATH_F4;
 					const f4 q0 = q[0], q1 = q[1];
-					{ TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port2); }
+					{ TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port2, (uint32_t)K.rayFlags); }
 				}
 				if (lane == 0) { wq[RQ_HITS] = hitsQ + (int)__popcll(hm); wq[RQ_MISSES] = missQn + (int)__popcll(mm); wq[RQ_RAYS] = raysQ - take; }
 				__threadfence_block();
 				break;
 			}
 			case ST_OPEN: {          /* the next job: the following chunk of the youngest job's unit, or a new unit from the queue */
-#ifdef CRH_EXP_FOLD_ANY
-				const int o = wq[RQ_HEAD];                                       /* the mask of open slots */
-				const int s = (int)__builtin_ctz(~(uint32_t)o), open = ((o >> wq[RQ_GEN]) & 1) ? 1 : 0;       /* the lowest free slot (the scheduler opens only when one is free); open: the youngest job is still open */
-				int pred = 0;
-#else
 				const int o = wq[RQ_HEAD], open = wq[RQ_OPEN];
 				const int s = (o + open) % NS;
-#endif
 				BlockJob J;
 				bool have = false;
 				const float *base = myStage + (size_t)s * slabFloats;
 				int defer = 0;
-#ifdef CRH_EXP_ENDGAME
-				bool endgame = false;
-#endif
 				if (open > 0 && !jobDeferred(wq[RQ_GEN])) {
 					J = loadJob(wq[RQ_GEN]);
 					if (J.passBegin + J.passCount < passEnd) {
 						J.passBegin += J.passCount; J.passCount = min(chunk, passEnd - J.passBegin); have = true;
-#ifdef CRH_EXP_FOLD_ANY
-						pred = (wq[RQ_GEN] + 1) << SJ_WH_PRED_SHIFT;         /* this chunk folds after the one it continues */
-#endif
 					}
 				}
 				if (!have) {
 					uint32_t unit = 0;
 					if (lane == 0) unit = atomicAdd((uint32_t *)(__attribute__((address_space(1))) uint32_t *)Q.counter, 1u);
 					unit = __builtin_amdgcn_readfirstlane(unit);
-#ifdef CRH_EXP_ENDGAME
-					endgame = unit + (uint32_t)(CRH_EXP_ENDGAME) * gridDim.x * (CRH_BLOCK / 64u) >= Q.total;
-#endif
 					if (unit < Q.total) {
 						++unitsDone;
 						uint32_t lo = 0, hi = Q.ntiles;
@@ -450,27 +346,13 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					if (have) {
 						lds_int *j = wq + RQ_SLOT0 + s * SJ_WORDS;
 						j[SJ_X0] = J.x0; j[SJ_Y0] = J.y0; j[SJ_WH] = J.w | (J.h << 16) | defer
-#ifdef CRH_EXP_FOLD_ANY
-						          | pred
-#endif
 						          ; j[SJ_BWBH] = J.bw | (J.bh << 16); j[SJ_PASS0] = J.passBegin; j[SJ_PASSN] = J.passCount;
 						j[SJ_NEXT] = 0; j[SJ_OUT] = 0;
 						j[SJ_BASE_LO] = (int)(uint32_t)(uintptr_t)base; j[SJ_BASE_HI] = (int)(uint32_t)((uintptr_t)base >> 32);
-#ifdef CRH_EXP_FOLD_ANY
-						wq[RQ_HEAD] = o | (1 << s); wq[RQ_GEN] = s;
-#else
 						wq[RQ_OPEN] = open + 1; wq[RQ_GEN] = s;
-#endif
 					} else {
-#ifdef CRH_EXP_ENDGAME
-						wq[RQ_DRY] = wq[RQ_DRY] | 1;
-#else
 						wq[RQ_DRY] = 1;
-#endif
 					}
-#ifdef CRH_EXP_ENDGAME
-					if (endgame) wq[RQ_DRY] = wq[RQ_DRY] | 2;
-#endif
 #ifdef CRH_EXP_ABS_TIMES
 					if (!have && !tDry) tDry = wall_clock64();
 #endif
@@ -539,36 +421,16 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				break;
 			}
 			case ST_FOLD: {          /* the older job is complete: its samples go into the frame in pass order; its slot is free again */
-#ifdef CRH_EXP_FOLD_ANY
-				const int o = (jobFlags >> 8) & 3, open = 0;
-				(void)open;
-#else
 				const int o = wq[RQ_HEAD], open = wq[RQ_OPEN];
-#endif
 				const BlockJob J = loadJob(o);
 				__threadfence_block();                 /* the staged samples of all lanes are visible to the folding lanes */
 				const float *slab = myStage + (size_t)o * slabFloats;
 				if (!jobDeferred(o)) {          /* (a pass segment's samples are folded behind the kernel) */
-#ifdef CRH_EXP_COOP_FOLD
-					if (J.bw * J.bh <= 32 && J.passCount >= 16) foldBlockCoop(P, J, slab, fb, lane);
-					else
-#endif
 					for (uint32_t pix = lane; pix < (uint32_t)(J.bw * J.bh); pix += 64u) foldBlockPixel(P, J, pix, slab, fb);
 				}
 				__threadfence_block();                 /* ... and read before a later job overwrites them */
 				CRH_LOCKSTEP();          /* every lane has read the ring's words */
-#ifdef CRH_EXP_FOLD_ANY
-				if (lane == 0) {
-					wq[RQ_HEAD] = wq[RQ_HEAD] & ~(1 << o);
-					for (int t = 0; t < NS; ++t) {          /* the chunk that continues this job's unit may fold now */
-						lds_int *tj = wq + RQ_SLOT0 + t * SJ_WORDS;
-						if (((tj[SJ_WH] & SJ_WH_PRED_MASK) >> SJ_WH_PRED_SHIFT) == o + 1) tj[SJ_WH] = tj[SJ_WH] & ~SJ_WH_PRED_MASK;
-					}
-					refreshJobWords();
-				}
-#else
 				if (lane == 0) { wq[RQ_HEAD] = (o + 1) % NS; wq[RQ_OPEN] = open - 1; refreshJobWords(); }
-#endif
 				__threadfence_block();
 				break;
 			}

@@ -913,19 +913,10 @@ struct TravHit {
  */
 #define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
 /* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside a BLAS */
-/* (-DCRH_EXP_PARK_RAY_ONLY, round 3 experiment: park the ray only — origin and direction — and recompute the slab constants and the octant when the lane
- * leaves the BLAS (makeRayK is a pure function: the same bits); frees seven LDS words per lane, which the quad-cooperative fetch of cray_hip.hip needs,
- * and costs three correctly rounded divisions per instance visit: -2.4 % on hdr.json, -6 % on statues.json) */
-#if !defined(CRH_EXP_COOP_FETCH) && !defined(CRH_EXP_PARK_RAY_ONLY)
-#define CRH_PARK_FULL 1        /* (measured: the recomputation costs 2-6 %, profiles/r03c_ab_coop_fetch.log) */
-#endif
-#ifdef CRH_PARK_FULL
+/* (parking the ray only and recomputing the slab constants on the way out was measured: -2.4 % on hdr.json, -6 % on statues.json; profiles/r03_exp_variants.patch) */
 /* (the slab offsets ss = -(o * inv) are not parked: three multiplications and three negations of parked values give the same bits back, and the
  * three LDS words per lane they occupied until round 3 — 3 KB per workgroup — now hold the instance records, cray_hip.hip: CRH_INST_LDS0_MAX) */
 enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_OCT, CRH_PARK_SLOTS };
-#else
-enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, CRH_PARK_SLOTS };
-#endif
 
 enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6, PH_NODE_SLOW = 7 };   /* PH_NODE_SLOW: a node step for a degenerate ray (rare; served with the control steps) */   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
@@ -1027,20 +1018,11 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	 * reads, far cheaper than a scheduling round at the occupancy such a step would get. */
 	if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
 	w.inBlas = 0; w.instFound = 0;
-#ifdef CRH_PARK_FULL
 	w.k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
 	w.k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
 	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
 	w.k.ss = vscale(vmul(w.k.o, w.k.inv), -1.0f);                    /* makeRayK's own expression on the same values */
 	w.k.oct = stk.unpark(PK_OCT);
-#else
-	{
-		const uint32_t lit = w.k.oct & CRH_RAY_LITERAL;
-		w.k = makeRayK(v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))},
-					   v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))});         /* the same function of the same ray: the same bits as at walkBegin */
-		w.k.oct |= lit;
-	}
-#endif
 	w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
 	w.spBase = 0;
 	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
@@ -1093,28 +1075,13 @@ CRH_DEV void stepNodeLoaded(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port
 	w.node = (inL && inR) ? (swap ? fr : fl) : (inL ? fl : (inR ? fr : CRH_NONE));
 	walkAdvance(S, w, stk, cnt, port);
 }
-/* Where a node step reads its child pair: global memory — or, for a stack type that stages the top-level BVH in LDS (cray_hip.hip: LdsStack::nodePair,
- * -DCRH_TLAS_LDS), that copy while the walk is at the top level. */
-template <class T, class = void> struct has_node_pair : std::false_type {};
-template <class T> struct has_node_pair<T, std::void_t<decltype(std::declval<const T &>().tlasInLds())>> : std::true_type {};
 template <bool FAST = true, class Stack, class Cnt, class Port>
 CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
-	const uint32_t node = w.node;
-	f4 l0, l1, r0, r1;
-	bool staged = false;
-	if constexpr (has_node_pair<Stack>::value) {
-		if (stk.tlasInLds() && !w.inBlas) { stk.nodePair(S, node, l0, l1, r0, r1); staged = true; }
-	}
-	if (!staged) {
-#ifndef CRH_EXP_NO_OFFSET32      /* the pair's byte offset as ONE 32-bit value added to the (wave-uniform) array base: global_load with a scalar base, a 32-bit vector offset and
-                              * immediate offsets for the four quarters instead of two 64-bit address computations per node step (round 3: +1 % on hdr.json / venus, profiles/r03q_ab_offset32.log).
-                              * The scene compiler refuses node / triangle / shading-record / texel arrays of 4 GB and more (134 M nodes, 89 M triangles per scene) */
-		const char *pair = (const char *)S.nodes + (uint32_t)(node << 5);
-		l0 = *(const f4 *)pair; l1 = *(const f4 *)(pair + 16); r0 = *(const f4 *)(pair + 32); r1 = *(const f4 *)(pair + 48);
-#else
-		l0 = S.nodes[2u * node]; l1 = S.nodes[2u * node + 1u]; r0 = S.nodes[2u * node + 2u]; r1 = S.nodes[2u * node + 3u];
-#endif
-	}
+	/* the pair's byte offset as ONE 32-bit value added to the (wave-uniform) array base: global_load with a scalar base, a 32-bit vector offset and immediate
+	 * offsets for the four quarters instead of two 64-bit address computations per node step (round 3: profiles/r03q_ab_offset32.log). The scene compiler
+	 * refuses node / triangle / shading-record / texel arrays of 4 GB and more (134 M nodes, 89 M triangles per scene) */
+	const char *pair = (const char *)S.nodes + (uint32_t)(w.node << 5);
+	const f4 l0 = *(const f4 *)pair, l1 = *(const f4 *)(pair + 16), r0 = *(const f4 *)(pair + 32), r1 = *(const f4 *)(pair + 48);
 	stepNodeLoaded<FAST>(S, w, stk, cnt, port, l0, l1, r0, r1);
 }
 
@@ -1140,14 +1107,9 @@ CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port)
 	const uint32_t slot = w.pA;
 	const bool two = slot + 1u < w.pAe;
 	const uint32_t slot2 = two ? slot + 1u : slot;
-#ifndef CRH_EXP_NO_OFFSET32
 	const char *ta = (const char *)S.tris + (uint32_t)(slot * 48u), *tb = (const char *)S.tris + (uint32_t)(slot2 * 48u);
 	const f4 a0 = *(const f4 *)ta, a1 = *(const f4 *)(ta + 16), a2 = *(const f4 *)(ta + 32);
 	const f4 b0 = *(const f4 *)tb, b1 = *(const f4 *)(tb + 16), b2 = *(const f4 *)(tb + 32);
-#else
-	const f4 a0 = S.tris[3u * slot], a1 = S.tris[3u * slot + 1u], a2 = S.tris[3u * slot + 2u];
-	const f4 b0 = S.tris[3u * slot2], b1 = S.tris[3u * slot2 + 1u], b2 = S.tris[3u * slot2 + 2u];
-#endif
 	w.pA = slot2 + 1u;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
 	testTriangle(a0, a1, a2, slot, w, cnt);
@@ -1209,10 +1171,8 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			stk.push(w.sp++, w.node); stk.push(w.sp++, w.pA); stk.push(w.sp++, w.pAe); stk.push(w.sp++, w.pB); stk.push(w.sp++, w.pBe);
 			stk.park(PK_OX, asU32(w.k.o.x)); stk.park(PK_OY, asU32(w.k.o.y)); stk.park(PK_OZ, asU32(w.k.o.z));
 			stk.park(PK_DX, asU32(w.k.d.x)); stk.park(PK_DY, asU32(w.k.d.y)); stk.park(PK_DZ, asU32(w.k.d.z));
-#ifdef CRH_PARK_FULL
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
 			stk.park(PK_OCT, w.k.oct);
-#endif
 			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
 			else { w.node = instRoot(inst); w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;

@@ -269,7 +269,7 @@ struct Compiler {
 
 	void run() {
 		CHECK(s->struct_size == sizeof(crh_scene_desc), CRH_ERR_INVALID, "crh_scene_desc.struct_size %u != %zu", s->struct_size, sizeof(crh_scene_desc));
-		CHECK(s->abi_version == CRH_ABI_VERSION, CRH_ERR_INVALID, "ABI version %u != %d", s->abi_version, CRH_ABI_VERSION);
+		CHECK(s->abi_version == CRH_SCENE_VERSION, CRH_ERR_INVALID, "scene description version %u != %d", s->abi_version, CRH_SCENE_VERSION);
 		CHECK(s->node_count < 0x3FFFFFFFull && s->prim_index_count < 0x3FFFFFFFull && s->poly_count < 0x7FFFFFFFull, CRH_ERR_UNSUPPORTED, "scene too large for 32-bit device indices");
 		CHECK(s->camera.width > 0 && s->camera.height > 0, CRH_ERR_INVALID, "camera has no image size");
 		out.camera = s->camera;

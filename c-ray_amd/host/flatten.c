@@ -168,7 +168,7 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 	memset(&f, 0, sizeof(f));
 	memset(out, 0, sizeof(*out));
 	out->struct_size = sizeof(*out);
-	out->abi_version = CRH_ABI_VERSION;
+	out->abi_version = CRH_SCENE_VERSION;
 
 	/* --- BVHs: every BLAS, then the TLAS, concatenated --- */
 	size_t totalNodes = crh_access_bvh_node_count(w->topLevel), totalPrims = (size_t)w->instanceCount, totalPolys = 0, totalMats = (size_t)w->sphereCount;

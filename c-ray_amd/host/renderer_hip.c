@@ -26,7 +26,12 @@
  * and redraws; the float buffer is gathered once, at the end. The result is the reference's single-thread result: with several threads the
  * reference itself races on state.finishedPasses and is not reproducible.
  *
- * Environment: CRAY_HIP_DEVICES=<n> caps the number of GPUs used; CRH_DUMP_F32=<path> dumps the float buffer; CRH_DUMP_STATS=<path>
+ * A GPU that fails — at set-up or in the middle of the frame — does not end the program: its strips (a pure function of (g, G): share.h) are dealt to the
+ * GPUs that finished and rendered there from pass 0, the way the reference's cluster master re-issues the tiles of a worker it lost (src/datatypes/tile.c:31-42);
+ * that frame is assembled on the host (the survivors' buffers merged: a pixel has one owner, everybody else holds 0.0f there). Only when NO GPU is left
+ * does renderFrame() end with logr(error, ...).
+ *
+ * Environment: CRAY_HIP_DEVICES=<n> caps the number of GPUs used; CRH_DROPIN_PASSES=<n> (dev / tests) fixes the passes per dispatch; CRH_DUMP_F32=<path> dumps the float buffer; CRH_DUMP_STATS=<path>
  * writes where the frame's time went; CRH_FRAMES=reduce: see above.
  * No GPU => logr(error, ...) (which exits, src/utils/logging.c:69-73): there is no CPU fallback in this file.
  */
@@ -116,6 +121,7 @@ static uint32_t gpuShare(const struct renderer *r, int g, int G, crh_tile **out)
  * layout, the float buffer's). scratch (G > 1): a frame-sized byte buffer of this thread. */
 static int refreshOutput(crh_ctx *ctx, const float *fb, int W, int H, struct texture *output, const crh_tile *share, uint32_t n, int G, unsigned char *scratch) {
 	if (G == 1) return crh_framebuffer_to_srgb8(ctx, fb, W, H, output->data.byte_p);
+	if (!scratch) return CRH_OK;          /* no memory for this thread's preview copy: the preview of its strips is skipped, the frame is not affected */
 	const int rc = crh_framebuffer_to_srgb8(ctx, fb, W, H, scratch);
 	if (rc != CRH_OK) return rc;
 	for (uint32_t t = 0; t < n; ++t)
@@ -195,6 +201,8 @@ static void *gpuThread(void *arg) {
 	startTimer(&phase);
 	int passes = r->prefs.sampleCount;
 	if (pixels && (uint64_t)passes * pixels > FIRST_DISPATCH_PATHS) passes = (int)(FIRST_DISPATCH_PATHS / pixels);
+	const int fixedPasses = getenv("CRH_DROPIN_PASSES") ? atoi(getenv("CRH_DROPIN_PASSES")) : 0;          /* dev / tests: that many passes per dispatch */
+	if (fixedPasses > 0) passes = fixedPasses;
 	if (passes < 1) passes = 1;
 	for (int done = 0; done < r->prefs.sampleCount && r->state.isRendering && !r->state.renderAborted; ) {
 		p.first_pass = done;
@@ -219,6 +227,7 @@ static void *gpuThread(void *arg) {
 			if (n && refreshOutput(w->ctx, w->fb, W, H, w->output, share, n, G, scratch) != CRH_OK) logr(warning, "GPU %d: preview: %s\n", w->device, crh_last_error());
 			const double msPerPass = (double)us / 1e3 / (double)p.pass_count;
 			passes = msPerPass > 0.0 ? (int)(DISPATCH_TARGET_MS / msPerPass) : passes;
+			if (fixedPasses > 0) passes = fixedPasses;
 			if (passes < 1) passes = 1;
 		}
 		while (w->state->paused && !r->state.renderAborted) sleepMSec(100);
@@ -335,6 +344,78 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	return rays;
 }
 
+/* The strips of the GPUs that failed, rendered by the ones that did not (tile.c:31-42 is the reference's version of this: a lost worker's tiles are handed out
+ * again). Strip i of the frame belongs to GPU i mod G (share.h); the strips of a failed GPU are dealt round-robin to the survivors, which render them for ALL
+ * passes into their own (there still zero) framebuffers, whatever the failed GPU had got done. Returns 0, or -1 with the survivor's message logged. */
+static int redealFailedShares(struct renderer *r, struct gpuWorker *workers, int gpus) {
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	int survivors[MAX_GPUS], ns = 0;
+	for (int g = 0; g < gpus; ++g) if (!workers[g].failed) survivors[ns++] = g;
+	if (!ns) return -1;
+	crh_tile *extra[MAX_GPUS];
+	uint32_t nExtra[MAX_GPUS];
+	const size_t cap = (size_t)crh_strip_share_max(H, gpus) * (size_t)gpus;
+	for (int s = 0; s < ns; ++s) { extra[s] = calloc(cap ? cap : 1, sizeof(crh_tile)); nExtra[s] = 0; }
+	int next = 0, strips = 0;
+	for (int g = 0; g < gpus; ++g) {
+		if (!workers[g].failed) continue;
+		crh_tile *t = NULL;
+		const uint32_t n = gpuShare(r, g, gpus, &t);
+		for (uint32_t i = 0; i < n; ++i, ++strips) { extra[next][nExtra[next]++] = t[i]; next = (next + 1) % ns; }
+		free(t);
+	}
+	logr(warning, "c-ray-hip: re-dealing the %i strips of the failed GPUs to the %i remaining GPU%s\n", strips, ns, PLURAL(ns));
+	crh_render_params p;
+	memset(&p, 0, sizeof(p));
+	p.image_width = W; p.image_height = H; p.max_passes = r->prefs.sampleCount; p.bounces = r->prefs.bounces;
+	uint64_t most = 1;
+	for (int s = 0; s < ns; ++s) {
+		uint64_t px = 0;
+		for (uint32_t i = 0; i < nExtra[s]; ++i) px += (uint64_t)(extra[s][i].x1 - extra[s][i].x0) * (uint64_t)(extra[s][i].y1 - extra[s][i].y0);
+		if (px > most) most = px;
+	}
+	int passes = r->prefs.sampleCount;
+	if ((uint64_t)passes * most > FIRST_DISPATCH_PATHS) passes = (int)(FIRST_DISPATCH_PATHS / most);
+	if (passes < 1) passes = 1;
+	int rc = 0;
+	for (int done = 0; done < r->prefs.sampleCount && !rc && !r->state.renderAborted; done += p.pass_count) {
+		p.first_pass = done;
+		p.pass_count = r->prefs.sampleCount - done < passes ? r->prefs.sampleCount - done : passes;
+		for (int s = 0; s < ns && !rc; ++s)          /* every survivor's dispatch is in flight before the first one is waited for */
+			if (nExtra[s] && crh_render_tiles(workers[survivors[s]].ctx, &p, extra[s], nExtra[s], workers[survivors[s]].fb) != CRH_OK) rc = -1;
+		for (int s = 0; s < ns && !rc; ++s)
+			if (nExtra[s] && crh_synchronize(workers[survivors[s]].ctx) != CRH_OK) rc = -1;
+		if (rc) logr(warning, "c-ray-hip: re-dealt strips: %s\n", crh_last_error());
+		getKeyboardInput(r);
+	}
+	for (int s = 0; s < ns; ++s) {
+		crh_counters c;
+		if (!rc && crh_counters_get(workers[survivors[s]].ctx, &c) == CRH_OK) workers[survivors[s]].rays = c.rays;
+		free(extra[s]);
+	}
+	return rc;
+}
+
+/* The frame of a run that lost a GPU: the survivors' float buffers merged on the host (one owner per pixel, 0.0f everywhere else), and the 8-bit output the way
+ * renderer.c:296-300 makes it, pixel by pixel, with the reference's own colorToSRGB / setPixel. */
+static int assembleOnHost(struct renderer *r, struct gpuWorker *workers, int gpus, struct texture *output) {
+	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
+	float *dst = r->state.renderBuffer->data.float_p;
+	float *tmp = malloc((size_t)W * H * 3 * sizeof(float));
+	if (!tmp) return -1;
+	memset(dst, 0, (size_t)W * H * 3 * sizeof(float));
+	for (int g = 0; g < gpus; ++g) {
+		if (workers[g].failed) continue;
+		if (crh_framebuffer_download(workers[g].ctx, workers[g].fb, W, H, tmp) != CRH_OK) { free(tmp); return -1; }
+		for (size_t i = 0; i < (size_t)W * H * 3; ++i) if (tmp[i] != 0.0f) dst[i] = tmp[i];
+	}
+	free(tmp);
+	for (int y = 0; y < H; ++y)
+		for (int x = 0; x < W; ++x)
+			setPixel(output, colorToSRGB(textureGetPixel(r->state.renderBuffer, x, y, false)), x, y);
+	return 0;
+}
+
 struct texture *renderFrame(struct renderer *r) {
 	const int W = (int)r->prefs.imageWidth, H = (int)r->prefs.imageHeight;
 	struct timeval frame;
@@ -435,28 +516,41 @@ struct texture *renderFrame(struct renderer *r) {
 	uint64_t rays = 0;
 	const char *firstError = "";
 	for (int g = gpus - 1; g >= 0; --g) { failed += workers[g].failed; rays += workers[g].rays; if (workers[g].failed) firstError = workers[g].error; }
-	if (failed) logr(error, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), firstError);
+	if (failed) {
+		logr(warning, "c-ray-hip: %i GPU dispatch thread%s failed: %s\n", failed, PLURAL(failed), firstError);
+		if (failed == gpus) logr(error, "c-ray-hip: no GPU is left to render the frame: %s\n", firstError);
+		if (!r->state.renderAborted && redealFailedShares(r, workers, gpus) != 0) logr(error, "c-ray-hip: the strips of the failed GPU%s could not be rendered elsewhere\n", PLURAL(failed));
+		rays = 0;
+		for (int g = 0; g < gpus; ++g) if (!workers[g].failed) rays += workers[g].rays;
+	}
 	if (warming && warm.rc != CRH_OK) logr(warning, "c-ray-hip: RCCL set-up beside the frame failed; the gather will retry\n");
 	if (!r->state.renderAborted)
 		for (int i = 0; i < r->state.tileCount; ++i) { r->state.renderTiles[i].isRendering = false; r->state.renderTiles[i].renderComplete = true; }
 
 	startTimer(&phase);
-	/* assemble the frame on GPU 0 (RCCL over xGMI; the shares are disjoint) */
-	crh_ctx *ctxs[MAX_GPUS];
-	float *fbs[MAX_GPUS];
-	for (int g = 0; g < gpus; ++g) { ctxs[g] = workers[g].ctx; fbs[g] = workers[g].fb; }
-	assembleFrame(ctxs, fbs, gpus, W, H);
-	const long gatherUs = getUs(phase);
-	startTimer(&phase);
-	/* 8-bit output exactly like renderer.c:294-300 — on the device — and the float buffer: one download each */
 	struct texture *buf = r->state.renderBuffer;
-	if (crh_framebuffer_to_srgb8(workers[0].ctx, workers[0].fb, W, H, output->data.byte_p) != CRH_OK)
-		logr(error, "c-ray-hip: sRGB conversion failed: %s\n", crh_last_error());
-	const long resolveUs = getUs(phase);
-	startTimer(&phase);
-	if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
-		logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
-	const long downloadUs = getUs(phase);
+	long gatherUs = 0, resolveUs = 0, downloadUs = 0;
+	if (failed) {
+		/* a GPU was lost: the survivors hold the whole frame between them, but not in the strip pattern the gather moves */
+		if (assembleOnHost(r, workers, gpus, output) != 0) logr(error, "c-ray-hip: assembling the frame on the host failed: %s\n", crh_last_error());
+		gatherUs = getUs(phase);
+	} else {
+		/* assemble the frame on GPU 0 (RCCL over xGMI; the shares are disjoint) */
+		crh_ctx *ctxs[MAX_GPUS];
+		float *fbs[MAX_GPUS];
+		for (int g = 0; g < gpus; ++g) { ctxs[g] = workers[g].ctx; fbs[g] = workers[g].fb; }
+		assembleFrame(ctxs, fbs, gpus, W, H);
+		gatherUs = getUs(phase);
+		startTimer(&phase);
+		/* 8-bit output exactly like renderer.c:294-300 — on the device — and the float buffer: one download each */
+		if (crh_framebuffer_to_srgb8(workers[0].ctx, workers[0].fb, W, H, output->data.byte_p) != CRH_OK)
+			logr(error, "c-ray-hip: sRGB conversion failed: %s\n", crh_last_error());
+		resolveUs = getUs(phase);
+		startTimer(&phase);
+		if (crh_framebuffer_download(workers[0].ctx, workers[0].fb, W, H, buf->data.float_p) != CRH_OK)
+			logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
+		downloadUs = getUs(phase);
+	}
 	const long frameUs = getUs(frame);
 	/* CRH_DUMP_STATS=<path>: where the frame went, for bench.py's `dropin` object. render_phase_ms is SURVEY.md 8(d)'s phase — the timer
 	 * of src/c-ray.c:279-281 around renderFrame() minus the set-up (flatten / context / upload: everything before the slowest GPU was ready
@@ -496,8 +590,8 @@ struct texture *renderFrame(struct renderer *r) {
 	logr(info, "%llu rays traced on %i GPU%s.\n", (unsigned long long)rays, gpus, PLURAL(gpus));
 
 	for (int g = 0; g < gpus; ++g) {
-		crh_framebuffer_free(workers[g].ctx, workers[g].fb);
-		crh_context_destroy(workers[g].ctx);
+		if (workers[g].ctx && workers[g].fb) crh_framebuffer_free(workers[g].ctx, workers[g].fb);
+		if (workers[g].ctx) crh_context_destroy(workers[g].ctx);
 	}
 	pthread_mutex_destroy(&sync.mu);
 	pthread_cond_destroy(&sync.cv);

@@ -70,7 +70,7 @@ int crh_blob_save(const char *path, const crh_scene_desc *scene, const crh_blob_
 	struct blob_header h;
 	memset(&h, 0, sizeof(h));
 	memcpy(h.magic, BLOB_MAGIC, 8);
-	h.abi_version = CRH_ABI_VERSION;
+	h.abi_version = CRH_SCENE_VERSION;
 	h.section_count = SEC_COUNT;
 	h.tlas_node_base = scene->tlas_node_base;  h.tlas_node_count = scene->tlas_node_count;
 	h.tlas_prim_base = scene->tlas_prim_base;  h.tlas_prim_count = scene->tlas_prim_count;
@@ -118,7 +118,7 @@ int crh_blob_load(const char *path, crh_scene_desc **scene_out, crh_blob_prefs *
 	fclose(f);
 
 	const struct blob_header *h = (const struct blob_header *)buf;
-	if (memcmp(h->magic, BLOB_MAGIC, 8) != 0 || h->abi_version != CRH_ABI_VERSION || h->section_count != SEC_COUNT) {
+	if (memcmp(h->magic, BLOB_MAGIC, 8) != 0 || h->abi_version != CRH_SCENE_VERSION || h->section_count != SEC_COUNT) {
 		free(buf);
 		return CRH_ERR_INVALID;
 	}
@@ -141,7 +141,7 @@ int crh_blob_load(const char *path, crh_scene_desc **scene_out, crh_blob_prefs *
 	o->buffer = buf;
 	crh_scene_desc *s = &o->desc;
 	s->struct_size = sizeof(*s);
-	s->abi_version = CRH_ABI_VERSION;
+	s->abi_version = CRH_SCENE_VERSION;
 #define GET(ID, FIELD, TYPE, COUNT) do { s->FIELD = (const TYPE *)(buf + sec[ID].offset); s->COUNT = sec[ID].count; } while (0)
 	GET(SEC_NODES,     nodes,        crh_bvh_node, node_count);
 	GET(SEC_PRIMS,     prim_indices, int32_t,      prim_index_count);

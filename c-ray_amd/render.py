@@ -90,8 +90,10 @@ class FrameRenderer:
         self.ctx.upload(scene)
         with torch.cuda.stream(self.stream):
             self.fb = torch.zeros((self.height, self.width, 3), dtype=torch.float32, device=self.device)
+            # (the gather's index / pack tensors too: they are filled on the stream they are used on — ADVICE r03: built on the default stream,
+            # their zero-fill could race with the first index_select on this one)
+            self.gather = StripGather(torch, self.width, self.height, rank, world, self.device) if world > 1 else None
         self.tiles = owned_tiles(self.width, self.height, tile[0], tile[1], order, rank, world)
-        self.gather = StripGather(torch, self.width, self.height, rank, world, self.device) if world > 1 else None
 
     def render(self, samples, bounces, clear=True):
         """Enqueue this rank's tiles (asynchronous on the stream)."""

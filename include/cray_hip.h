@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define CRH_ABI_VERSION 1
+/* 2 (round 4): crh_debug_plan_units writes EIGHT ints per unit (six in version 1), crh_frames_gather / crh_frames_prepare / crh_context_prepare exist,
+ * CRH_OPT_ROUND_LIMIT / CRH_OPT_RENDER_SLABS exist, CRH_KERNEL_WAVE / CRH_KERNEL_WG are refused by the product build. A host checks crh_abi_version() == CRH_ABI_VERSION. */
+#define CRH_ABI_VERSION 2
+/* layout version of crh_scene_desc and of the scene blobs (crh_blob_save / crh_blob_load): the records have not changed since round 1 */
+#define CRH_SCENE_VERSION 1
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define CRH_OK                0
@@ -178,7 +182,7 @@ typedef struct crh_camera {
 /* Everything renderFrame() can see in struct world + the global vertex buffers, as POD. */
 typedef struct crh_scene_desc {
 	uint32_t struct_size;     /* sizeof(crh_scene_desc), checked by crh_scene_upload */
-	uint32_t abi_version;     /* CRH_ABI_VERSION */
+	uint32_t abi_version;     /* CRH_SCENE_VERSION: the layout of this description's records (the entry points' version is crh_abi_version()) */
 
 	const crh_bvh_node *nodes;        uint64_t node_count;        /* all BLAS then the TLAS */
 	const int32_t      *prim_indices; uint64_t prim_index_count;
@@ -279,10 +283,11 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */
 #define CRH_OPT_TAIL_PERCENT 10   /* share (0..50, default 16) of a dispatch's pixels that ends the work queue as quarter-size blocks, so the waves finish close together;
                                    * | (p2 + 1) << 8 also sets the share (default 4) at the very end that is cut into sixteenth-size blocks */
-#define CRH_OPT_KERNEL       12   /* which form of the path-tracing kernel: CRH_KERNEL_ROLL (default since round 3) = every wave a self-contained machine that keeps up to four
-                                   * work units open, so that its path table stays full across unit boundaries; CRH_KERNEL_WAVE = the same machine, one unit at a time (the
-                                   * default until round 3); CRH_KERNEL_WG = the four waves of a workgroup share one path table and take walker / shader roles.
-                                   * All three compute the same frame bit for bit */
+#define CRH_OPT_KERNEL       12   /* which form of the path-tracing kernel: CRH_KERNEL_ROLL (default, and since round 4 the only form in the product library) = every wave a
+                                   * self-contained machine that keeps up to four work units open, so that its path table stays full across unit boundaries. Builds with
+                                   * -DCRH_WITH_ALT_KERNELS (the kernel emulation of tests/emu, A/B variant libraries) also hold CRH_KERNEL_WAVE = the same machine, one unit
+                                   * at a time (the default until round 3) and CRH_KERNEL_WG = the four waves of a workgroup share one path table and take walker / shader
+                                   * roles; all three compute the same frame bit for bit. The product build answers CRH_ERR_UNSUPPORTED for the other two */
 #define CRH_OPT_SCHED_WG     13   /* workgroup kernel scheduler: linger | drainAt<<8 | maxDrainers<<20 | partialMin<<24 | walkMin<<32 | fillTo<<40 */
 #define CRH_OPT_TRACE_SLABS  14   /* crh_trace_rays and rays with a zero / denormal direction component (a slab the reference's arithmetic turns into NaN, bvh.c:326-352):
                                    * CRH_TRACE_SLABS_LITERAL (default) = the reference's select chain followed literally: its record and its node / triangle test counts,
@@ -306,6 +311,12 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * the last waves are those whose path table is full when the queue runs dry: draining it takes ~1.4 ms (DESIGN.md §6, r03zb_probe_finish*).
                                    * The environment variable CRH_TAIL_SPLIT sets a process's default (A/B runs of unmodified hosts) */
 #define CRH_TAIL_SPLIT_DEFAULT 0
+#define CRH_OPT_ROUND_LIMIT  17   /* scheduling rounds (2..2e9, default 2e9: hours of one wave's work) after which a wave of the path-tracing kernel gives up instead of spinning
+                                   * on: the dispatch is flagged, and crh_synchronize / crh_framebuffer_download / crh_framebuffer_to_srgb8 return CRH_ERR_HIP "incomplete frame"
+                                   * (the reference's convention: an error code and a message, src/datatypes/scene.c:122-134). A tiny value is the test hook for that path */
+#define CRH_OPT_RENDER_SLABS 18   /* the render kernels and rays with a zero / denormal direction component: CRH_TRACE_SLABS_EXACT (default: see CRH_OPT_TRACE_SLABS) or
+                                   * CRH_TRACE_SLABS_LITERAL = the reference's NaN arithmetic followed literally (bvh.c:326-352) — the same node visits as the reference for
+                                   * every ray of the frame, at the reference's price for such a ray: a walk of most of the scene with the rest of its wave waiting */
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);
@@ -371,6 +382,9 @@ int crh_counters_reset(crh_ctx *ctx);
 /* Duration in milliseconds of the most recent crh_render_region's path-tracing kernel, measured
  * with HIP events on the context's stream; also the launch count and total since the last reset. */
 int crh_kernel_time_ms(crh_ctx *ctx, float *last_ms, double *total_ms, uint64_t *launches);
+/* The instantiation of the path-tracing kernel the context launched last, as rocprofv3 names it (e.g. "k_pathtrace_roll<1,4,false,0>":
+ * counter level, waves per SIMD, rare features, sampler); "" before the first dispatch. bench.py quotes it in `roofline.kernel`. */
+const char *crh_last_kernel_name(crh_ctx *ctx);
 
 /* Debug / parity: evaluate one function of the device math library (c-ray_amd/csrc/exact_math.h: the libm functions of the hot path
  * restated with the bits of the reference's host libm) on n caller values; y_host is the second argument of powf(x, y) /

@@ -129,3 +129,19 @@ def resize_camera(scene, width, height):
     assert cam.width * height == cam.height * width, "resize_camera keeps the aspect ratio"
     cam.width, cam.height = width, height
     return scene
+
+
+def kernel_forms(pkg, ctx):
+    """The forms of the path-tracing kernel the loaded library holds (CRH_OPT_KERNEL). The product library holds k_pathtrace_roll alone (round 4); the kernel
+    emulation of tests/emu (and A/B variant libraries built with -DCRH_WITH_ALT_KERNELS) also hold the one-unit-at-a-time and the workgroup-cooperative forms,
+    so the tests that compare the forms with each other run in full in the emulation tier and compare the rolling kernel with itself / the fixtures on the GPU."""
+    abi = pkg.abi
+    forms = [abi.KERNEL_ROLL]
+    for k in (abi.KERNEL_WAVE, abi.KERNEL_WG):
+        try:
+            ctx.set_option(abi.OPT_KERNEL, k)
+            forms.append(k)
+        except pkg.api.CrhError as e:
+            assert e.code == abi.ERR_UNSUPPORTED, e
+    ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+    return forms

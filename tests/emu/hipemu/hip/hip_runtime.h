@@ -216,7 +216,7 @@ static __forceinline__ int atomicExch(volatile int *p, int v) { return atomicExc
 static __forceinline__ unsigned atomicOr(volatile unsigned *p, unsigned v) { return atomicOr((unsigned *)p, v); }
 
 /* ---- runtime API (the subset cray_hip.hip uses) ------------------------------------------------------------------------------------------ */
-typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidDevice = 101 } hipError_t;
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidDevice = 101, hipErrorInvalidDeviceFunction = 98, hipErrorLaunchFailure = 719 } hipError_t;
 typedef struct hipemu_stream *hipStream_t;
 typedef struct hipemu_event *hipEvent_t;
 typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;

@@ -264,12 +264,13 @@ const char *hipGetErrorString(hipError_t e) {
 		case hipSuccess: return "no error";
 		case hipErrorInvalidValue: return "invalid argument";
 		case hipErrorOutOfMemory: return "out of memory";
+		case hipErrorLaunchFailure: return "unspecified launch failure";
+		case hipErrorInvalidDeviceFunction: return "invalid device function";
 		case hipErrorNotReady: return "not ready";
 		case hipErrorInvalidDevice: return "invalid device ordinal";
 	}
 	return "unknown error";
 }
-hipError_t hipGetLastError(void) { return hipSuccess; }
 /* HIPEMU_DEVICES=<n>: that many identical "devices" (all of them this CPU and this heap): lets a host that drives several GPUs from several
  * threads — renderer_hip.c — run its partition and gather logic */
 static int deviceCount() { const char *e = getenv("HIPEMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : (n > 16 ? 16 : n); }
@@ -277,6 +278,16 @@ hipError_t hipGetDeviceCount(int *n) { if (!n) return hipErrorInvalidValue; *n =
 /* HIPEMU_FAIL_DEVICE=<d>: every hipMalloc of a thread whose current device is d fails (a GPU that cannot be set up: renderer_hip.c's failed-worker path) */
 static thread_local int t_device = 0;
 static int failDevice() { const char *e = getenv("HIPEMU_FAIL_DEVICE"); return e ? atoi(e) : -1; }
+/* HIPEMU_FAIL_LAUNCH=<d>:<n>: the n-th hipGetLastError() (n >= 1: the n-th kernel launch a host checks) of a thread whose current device is d reports a launch
+ * failure, and so does every later one — a GPU that dies in the middle of a frame (renderer_hip.c re-deals its strips to the GPUs that are left) */
+static thread_local int t_launchChecks = 0;
+hipError_t hipGetLastError(void) {
+	static const char *e = getenv("HIPEMU_FAIL_LAUNCH");
+	if (!e) return hipSuccess;
+	int d = -1, n = 0;
+	if (sscanf(e, "%d:%d", &d, &n) != 2 || t_device != d) return hipSuccess;
+	return ++t_launchChecks >= n ? hipErrorLaunchFailure : hipSuccess;
+}
 hipError_t hipSetDevice(int device) { if (device < 0 || device >= deviceCount()) return hipErrorInvalidDevice; t_device = device; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device) {
 	if (!prop || device < 0 || device >= deviceCount()) return hipErrorInvalidValue;

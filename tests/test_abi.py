@@ -56,16 +56,55 @@ def test_product_does_not_reference_the_oracle():
 
 
 def test_default_library_holds_no_experimental_kernel_and_no_emulation(pkg):
-    """The library the product loads is the measured one: it holds the three kernel forms of CRH_OPT_KERNEL (k_pathtrace_roll, the default since round 3,
-    k_pathtrace, k_pathtrace_wg) and none of the -DCRH_EXP_* experiments (the quad-cooperative fetch's LDS slabs would show in the kernels' LDS size), it is
-    not the CPU emulation, and the product sources never name the emulation library."""
+    """The library the product loads is the measured one: it holds ONE form of the path-tracing kernel, k_pathtrace_roll (round 4: the other two forms of
+    CRH_OPT_KERNEL, k_pathtrace and k_pathtrace_wg, live in csrc/pathtrace_alt.h and are compiled only with -DCRH_WITH_ALT_KERNELS: the emulation tier and A/B
+    variant libraries), the product sources carry at most the one dev probe macro (CRH_EXP_ABS_TIMES) — the measured-negative experiments are patches under
+    profiles/ —, it is not the CPU emulation, and the product sources never name the emulation library."""
     lib = os.path.join(REPO, "c-ray_amd", "_lib", "libcray_hip.so")
     blob = open(lib, "rb").read()
-    assert b"k_pathtrace_roll" in blob and b"k_pathtrace_wg" in blob and b"crh_emu_stats" not in blob and b"hipemu" not in blob
+    assert b"k_pathtrace_roll" in blob and b"k_pathtrace_wgIL" not in blob and b"11k_pathtraceIL" not in blob and b"crh_emu_stats" not in blob and b"hipemu" not in blob
+    assert os.path.getsize(lib) < 3 << 20
+    exp = 0
     for root, _, files in os.walk(os.path.join(REPO, "c-ray_amd")):
         for f in files:
             if f.endswith((".py", ".c", ".h", ".cpp", ".hip")):
-                assert "libcray_hip_emu" not in open(os.path.join(root, f), errors="replace").read(), os.path.join(root, f)
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "libcray_hip_emu" not in text, os.path.join(root, f)
+                exp += len(re.findall(r"CRH_EXP_", text))
+    assert exp <= 8, exp
+
+
+def test_build_script_knows_every_source_of_the_library(pkg):
+    """c-ray_amd/build.py rebuilds when a source is newer than the library: every file the two .hip sources #include (transitively, from csrc/ and include/)
+    must be in its dependency list — round 3's list missed csrc/pathtrace_roll.h, the file that holds the hot kernel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("crh_build", os.path.join(REPO, "c-ray_amd", "build.py"))
+    build = importlib.util.module_from_spec(spec); spec.loader.exec_module(build)
+    deps = {os.path.realpath(d) for d in build.deps()}
+    dirs = [os.path.join(REPO, "c-ray_amd", "csrc"), os.path.join(REPO, "include")]
+    seen, todo = set(), [os.path.join(dirs[0], "cray_hip.hip"), os.path.join(dirs[0], "bvh_build.hip"), os.path.join(dirs[0], "scene_compile.cpp")]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'#\s*include\s+"([^"]+)"', open(f).read()):
+            for d in dirs:
+                if os.path.exists(os.path.join(d, inc)):
+                    todo.append(os.path.join(d, inc))
+    assert len(seen) >= 8 and any(f.endswith("pathtrace_roll.h") for f in seen)
+    for f in seen:
+        assert os.path.realpath(f) in deps, f
+    # ... and an edit to the hot kernel's file makes the library stale
+    roll = os.path.join(dirs[0], "pathtrace_roll.h")
+    lib = build.LIB
+    if os.path.exists(lib):
+        st = os.stat(roll)
+        try:
+            os.utime(roll, (st.st_atime, os.path.getmtime(lib) + 10))
+            assert not build.up_to_date()
+        finally:
+            os.utime(roll, (st.st_atime, st.st_mtime))
 
 
 def test_blob_roundtrip(pkg, golden_blob, tmp_path):

@@ -80,6 +80,39 @@ def test_strip_gather_reproduces_the_frame(world, manifest, golden_blob, golden_
     assert np.array_equal(np.load(out), golden_ref("fence")), f"{world}-rank gathered frame differs from the reference's single-process frame"
 
 
+def _cfg4_worker(rank, world, port, w, h, out_path):
+    """bench.py: scaling_cfg4's host path at BASELINE configs[3]'s frame size — this rank's strips (owned_tiles), a per-pixel pattern standing in for the
+    dispatch (every owned pixel a value only its coordinates determine, every other pixel 0), the strip gather onto rank 0."""
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fb = np.zeros((h, w, 3), np.float32)
+    ys, xs = np.mgrid[0:h, 0:w]
+    full = np.stack([xs * 0.25 + ys + 1.0, ys * 0.5 + xs + 2.0, (xs ^ ys) + 3.0], axis=2).astype(np.float32)          # (never 0: an unowned pixel would show)
+    for x0, y0, x1, y1 in pkg.render.owned_tiles(w, h, 64, 64, 1, rank, world):
+        fb[h - y1:h - y0, x0:x1] = full[h - y1:h - y0, x0:x1]          # framebuffer rows are stored top-down (texture.c:24-28)
+    tfb = pkg.render.StripGather(torch, w, h, rank, world, torch.device("cpu"))(torch.from_numpy(fb), dist)
+    if rank == 0:
+        np.save(out_path, np.array([np.array_equal(tfb.numpy(), full), float((tfb.numpy() != 0).all())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scaling_cfg4_share_and_gather_at_full_frame_size(tmp_path):
+    """bench.py emits `scaling_cfg4` (statues.json 3840x2160, the scene BASELINE.json quotes the 1/2/4/8-GPU curve on) through the same strips + gather as the
+    headline: two gloo ranks assemble that frame size exactly — every pixel from exactly one owner."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_cfg4_worker, args=(2, _free_port(), 3840, 2160, out), nprocs=2, join=True)
+    ok = np.load(out)
+    assert ok[0] == 1.0 and ok[1] == 1.0
+
+
 def test_strip_rows_match_the_c_hosts_pack_order(pkg):
     """render.py: strip_rows lists, per rank, the framebuffer rows k_strip_rows (cray_hip.hip: crh_frames_gather) packs: strip by strip, bottom row of a strip first."""
     for h, world in ((100, 8), (720, 8), (7, 3), (3, 2), (9, 16)):

@@ -13,7 +13,7 @@ The bar (stated once, used everywhere below): BIT-EXACT.
 import numpy as np
 import pytest
 
-from conftest import BIG_CASES, built_blob, camera_rays, image_stats, resize_camera
+from conftest import BIG_CASES, built_blob, camera_rays, image_stats, kernel_forms, resize_camera
 
 pytestmark = pytest.mark.gpu
 CASES = ["cfg1_scene", "alphanode", "fence", "glowmetal", "refraction", "uvsphere"]
@@ -214,11 +214,12 @@ def test_rolling_and_one_unit_at_a_time_kernels_are_bit_identical(pkg, ctx, mani
     until round 3). Same per-path operations, so: the same frame and the same counters — for default and tiny units, one-pass chunks, ragged tiles split
     over two dispatches, both counter levels."""
     abi = pkg.abi
+    ref_kernel = abi.KERNEL_WAVE if abi.KERNEL_WAVE in kernel_forms(pkg, ctx) else abi.KERNEL_ROLL      # (product library: the rolling kernel at its default settings; the forms meet in the emulation tier)
     try:
         for name in ("refraction", "glowmetal", "cfg1_scene", "fence"):
             m = manifest[name]
             w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
-            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+            ctx.set_option(abi.OPT_KERNEL, ref_kernel)
             full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob(name), w, h, s, b)
             ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
             for items, chunk in ((2048, 64), (64, 1), (256, 2)):
@@ -252,10 +253,12 @@ def test_split_pixels_fold_in_pass_order(pkg, ctx, manifest, golden_blob):
     bit for bit: a ragged last segment (160 = 64 + 64 + 32), pass ranges (the second dispatch continues the running mean of the first; 30 passes are not split),
     tile lists with ragged edges, every number of split units per wave, both counter levels; with fewer passes the last units are small blocks (no pixel split)."""
     abi = pkg.abi
+    ref_kernel = abi.KERNEL_WAVE if abi.KERNEL_WAVE in kernel_forms(pkg, ctx) else abi.KERNEL_ROLL      # (product library: the rolling kernel without split units)
     try:
         for name, w, h, s in (("refraction", 48, 30, 160), ("glowmetal", 37, 19, 257), ("cfg1_scene", 64, 40, 24)):
             b = manifest[name]["bounces"]
-            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WAVE)
+            ctx.set_option(abi.OPT_KERNEL, ref_kernel)
+            ctx.set_option(abi.OPT_TAIL_SPLIT, 0)
             full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob(name), w, h, s, b)
             ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
             for split in (4, 0, 1, 64):
@@ -292,6 +295,11 @@ def test_workgroup_kernel_is_bit_identical_to_the_wave_kernel(pkg, ctx, manifest
     linger / always linger, drain at once / never, no drainers, partial batches of 1, tables of 64 paths), both samplers, a scene with
     node programs, multi-chunk passes and ragged tiles."""
     abi = pkg.abi
+    if abi.KERNEL_WG not in kernel_forms(pkg, ctx):
+        with pytest.raises(pkg.api.CrhError) as e:          # the product library says so instead of launching something else
+            ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_WG)
+        assert e.value.code == abi.ERR_UNSUPPORTED and "CRH_WITH_ALT_KERNELS" in str(e.value)
+        pytest.skip("the product library holds k_pathtrace_roll only (round 4); this comparison runs in the emulation tier (tests/test_kernel_emu.py)")
     scheds = [(8, 192, 1, 16, 32, 768), (0, 1, 4, 1, 1, 64), (255, 4095, 0, 64, 64, 960), (3, 64, 2, 8, 16, 256)]
     try:
         for name in ("refraction", "glowmetal", "cfg1_scene"):
@@ -367,6 +375,80 @@ def test_zero_component_rays(pkg, ctx, oracle, golden_blob):
     for f in ("inst", "poly", "distance", "point", "normal", "material"):
         assert np.array_equal(hx[f], ho[f]), f
     assert (hx["node_tests"] <= ho["node_tests"]).all() and hx["node_tests"].sum() < 0.25 * ho["node_tests"].sum()
+
+
+def test_rendered_frame_of_zero_component_rays_literal_slabs(pkg, ctx, oracle, golden_blob):
+    """CRH_OPT_RENDER_SLABS = LITERAL puts degenerate rays through a RENDERED frame: with a zero-size sensor and an axis-aligned
+    camera every camera ray of the frame is the same ray with two exactly-zero direction components (camera.c:66-75: pixX = pixY = 0, direction = forward),
+    the case the reference's NaN slab arithmetic turns into a walk of most of the scene (bvh.c:326-352). With LITERAL the frame AND the node / triangle
+    test counts equal the oracle's (which restates that arithmetic literally); the default (EXACT slabs) gives the same frame on this scene with
+    far fewer node visits — the documented difference is in the visits, DESIGN.md section 5."""
+    api, abi = pkg.api, pkg.abi
+    blob = golden_blob("cfg1_scene")
+    scene, oscene = api.Scene(blob), oracle.OracleScene(blob)
+    w, h, s, b = 12, 8, 3, 4
+    for d in (scene.desc, oscene.desc):
+        cam = d.camera
+        cam.width, cam.height = w, h
+        cam.sensor[0] = cam.sensor[1] = 0.0
+        cam.aperture = 0.0
+        for i, v in enumerate((1.0, 0.0, 0.0)): cam.right[i] = v
+        for i, v in enumerate((0.0, 1.0, 0.0)): cam.up[i] = v
+        for i, v in enumerate((0.0, 0.0, 1.0)): cam.forward[i] = v
+        pos = (cam.A[3], cam.A[7], cam.A[11])
+        for i, v in enumerate((1.0, 0.0, 0.0, pos[0], 0.0, 1.0, 0.0, pos[1], 0.0, 0.0, 1.0, pos[2])): cam.A[i] = v       # keep the position, drop the rotation
+    ray = oracle.camera_ray(oscene, 3, 4, 0, s)
+    assert (np.asarray(ray[3:6]) == 0.0).sum() == 2, ray               # the oracle's camera ray IS degenerate
+    ref, ocnt = oracle.render(oscene, w, h, s, b)
+    ctx.upload(scene)
+    fb = ctx.framebuffer(w, h)
+    try:
+        ctx.set_option(abi.OPT_RENDER_SLABS, abi.TRACE_SLABS_LITERAL)
+        ctx.reset_counters()
+        ctx.render_region(fb, w, h, s, b)
+        img, cnt = ctx.download(fb, w, h), ctx.counters()
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), image_stats(img, ref)
+        for k in ("rays", "paths", "node_tests", "tri_tests"):
+            assert cnt[k] == ocnt[k], (k, cnt[k], ocnt[k])
+        ctx.set_option(abi.OPT_RENDER_SLABS, abi.TRACE_SLABS_EXACT)
+        ctx.clear(fb, w, h)
+        ctx.reset_counters()
+        ctx.render_region(fb, w, h, s, b)
+        img2, cnt2 = ctx.download(fb, w, h), ctx.counters()
+        assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32)), image_stats(img2, ref)
+        assert cnt2["rays"] == ocnt["rays"] and cnt2["node_tests"] < cnt["node_tests"]
+    finally:
+        ctx.set_option(abi.OPT_RENDER_SLABS, abi.TRACE_SLABS_EXACT)
+
+
+def test_round_limit_flags_an_incomplete_frame(pkg, ctx, manifest, golden_blob):
+    """A wave of the path-tracing kernel that runs out of scheduling rounds (CRH_OPT_ROUND_LIMIT; the default is hours of work) gives up instead of
+    spinning on — and the dispatch SAYS so: synchronize / download return CRH_ERR_HIP "incomplete frame" (round 3's kernel left silently with CRH_OK).
+    The flag is cleared by the report: the next dispatch, with the limit back at its default, renders the reference frame."""
+    api, abi = pkg.api, pkg.abi
+    m = manifest["glowmetal"]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    full, cnt_full, fb = gpu_render(pkg, ctx, golden_blob("glowmetal"), w, h, s, b)
+    try:
+        ctx.set_option(abi.OPT_ROUND_LIMIT, 40)
+        ctx.clear(fb, w, h)
+        ctx.render_region(fb, w, h, s, b)
+        with pytest.raises(api.CrhError) as e:
+            ctx.synchronize()
+        assert e.value.code == abi.ERR_HIP and "incomplete frame" in str(e.value)
+        ctx.render_region(fb, w, h, s, b)
+        with pytest.raises(api.CrhError) as e:
+            ctx.download(fb, w, h)
+        assert e.value.code == abi.ERR_HIP and "incomplete frame" in str(e.value)
+    finally:
+        ctx.set_option(abi.OPT_ROUND_LIMIT, 2000000000)
+    ctx.synchronize()                                   # reported once: clean again
+    ctx.clear(fb, w, h)
+    ctx.reset_counters()
+    ctx.render_region(fb, w, h, s, b)
+    assert np.array_equal(ctx.download(fb, w, h), full) and ctx.counters() == cnt_full
+    with pytest.raises(api.CrhError):
+        ctx.set_option(abi.OPT_ROUND_LIMIT, 1)
 
 
 def test_srgb8_matches_oracle(pkg, ctx, oracle, manifest, golden_blob):

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import camera_rays, image_stats
+from conftest import camera_rays, image_stats, kernel_forms
 
 
 def test_oracle_bit_exact_on_volumes(oracle, manifest, golden_blob, golden_ref):
@@ -58,7 +58,8 @@ def test_gpu_volumes_vs_reference(pkg, manifest, golden_blob, golden_ref):
         ctx.upload(pkg.api.Scene(golden_blob("volumes")))
         fb = ctx.framebuffer(w, h)
         frames = []
-        for kern in (pkg.abi.KERNEL_WAVE, pkg.abi.KERNEL_WG, pkg.abi.KERNEL_ROLL):
+        forms = kernel_forms(pkg, ctx)          # the product library: the rolling kernel; the emulation tier: all three forms
+        for kern in forms:
             ctx.set_option(pkg.abi.OPT_KERNEL, kern)
             ctx.clear(fb, w, h)
             ctx.reset_counters()
@@ -70,7 +71,8 @@ def test_gpu_volumes_vs_reference(pkg, manifest, golden_blob, golden_ref):
     finally:
         ctx.close()
     img, cnt = frames[0]
-    assert np.array_equal(img, frames[1][0]) and cnt == frames[1][1] and np.array_equal(img, frames[2][0]) and cnt == frames[2][1]        # all three kernel forms: same frame
+    for other, other_cnt in frames[1:]:        # every kernel form the library holds: the same frame
+        assert np.array_equal(img, other) and cnt == other_cnt
     ref = golden_ref("volumes")
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), image_stats(img, ref)        # logf of the free-flight draw included
     assert cnt["rays"] == m["rays"], (cnt["rays"], m["rays"])

@@ -176,7 +176,7 @@ class Context:
         buf = np.zeros(24, dtype=np.uint64)
         _check(self.L.crh_debug_phase_ticks(self.h, buf.ctypes.data), "crh_debug_phase_ticks")
         keys = ("setup", "traverse", "shade", "w_node", "w_tri", "w_ctrl", "w_round", "w_shade", "w_setup", "u_node", "u_shade",
-                "t_swap", "t_gen", "n_swap", "n_gen", "u_swap", "u_tri", "u_ctrl")
+                "t_swap", "t_gen", "n_swap", "n_gen", "u_swap", "u_tri", "u_ctrl", "w_tri_in", "u_tri_in", "w_ctrl_in", "u_ctrl_in", "u_wait_tri", "u_wait_fin")
         return {k: int(v) for k, v in zip(keys, buf)}
 
     def prepare(self):

@@ -68,7 +68,8 @@ using namespace crh;
 #define CRH_SHADE_LDS_IMAGES 8u           /* image descriptors (8 B) and texture descriptors (32 B) */
 #define CRH_SHADE_LDS_BYTES (CRH_SHADE_LDS * (CRH_SHADE_LDS_MATERIALS * 32u + CRH_SHADE_LDS_BSDFS * 16u + CRH_SHADE_LDS_CONSTS * 16u + CRH_SHADE_LDS_IMAGES * 40u))
 #ifndef CRH_STACK_LDS
-#define CRH_STACK_LDS ((40960 - 3968 - (int)CRH_INST_LDS_BYTES - (int)CRH_SHADE_LDS_BYTES) / 1024 - 10)     /* what the LDS holds after the id stacks, tables and park slots (18 with the default instance tables) */
+#define CRH_STACK_LDS ((40960 - 3968 - (int)CRH_INST_LDS_BYTES - (int)CRH_SHADE_LDS_BYTES) / 1024 - 15)     /* what the LDS holds after the id stacks, tables and the 15 park slots: 12 entries with the default tables —
+                                                                                                                 * as many NODE entries as before round 4, when five of 17 held the parked top-level walk of a lane inside a BLAS */
 #endif
 /* CRH_LOCKSTEP(): marks a place where the lanes of a wave hand data to each other through LDS with no wave collective in between,
  * relying on what the hardware guarantees anyway — a wave executes in lockstep and its LDS operations in program order. It expands to
@@ -870,8 +871,20 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	DScene d;
 	memset(&d, 0, sizeof(d));
 #define UP(field, ptr, count) do { rc = upload(c, ptr, count, &d.field); if (rc) { freeScene(c); return rc; } } while (0)
-	UP(nodes, cs.nodes.data(), cs.nodes.size());
-	UP(tris, cs.tris.data(), cs.tris.size());
+	{	/* BVH nodes and prepared triangles share ONE allocation — nodes, then (256-byte aligned) triangles, then one record of padding: a fused walk step
+		 * (pathtrace_roll.h) addresses a lane's child pair OR its next two triangles as (S.nodes, a kernel argument in SGPRs) + one 32-bit byte offset, and reads
+		 * the two triangles as six consecutive quarters (the second one unused when the leaf range holds one: at the array's end that is the padding) */
+		const size_t nodeBytes = (cs.nodes.size() * sizeof(f4) + 255u) & ~(size_t)255u, triBytes = cs.tris.size() * sizeof(f4);
+		if (nodeBytes + triBytes + 96u >= (1ull << 32)) { freeScene(c); return fail(CRH_ERR_UNSUPPORTED, "crh_scene_upload: BVH nodes + prepared triangles of 4 GB and more"); }
+		void *p = nullptr;
+		HIP_TRY(hipMalloc(&p, nodeBytes + triBytes + 96u));
+		c->sceneAllocs.push_back(p);
+		HIP_TRY(hipMemset((char *)p + nodeBytes + triBytes, 0, 96u));
+		if (cs.nodes.size()) HIP_TRY(hipMemcpy(p, cs.nodes.data(), cs.nodes.size() * sizeof(f4), hipMemcpyHostToDevice));
+		if (triBytes) HIP_TRY(hipMemcpy((char *)p + nodeBytes, cs.tris.data(), triBytes, hipMemcpyHostToDevice));
+		d.nodes = (const f4 *)p;
+		d.tris = (const f4 *)((const char *)p + nodeBytes);
+	}
 	UP(shade, cs.shade.data(), cs.shade.size());
 	UP(prims, scene->prim_indices, (size_t)scene->prim_index_count);
 	UP(instances, cs.instances.data(), cs.instances.size());

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace(const
  * written before the lock is taken and published by the release fence). Every path's own sequence of operations is the same
  * as in k_pathtrace, hence the same frame bit for bit. A watchdog (wall clock) aborts the dispatch instead of hanging.
  * ================================================================================================================================ */
-#define CRH_WG_STACK_LDS 22          /* (22 + 13 park) x 1 KB + 2 x 2 KB id arrays + control words <= 40 KB: 4 workgroups per CU */
+#define CRH_WG_STACK_LDS 17          /* (17 + 15 park) x 1 KB + 2 x 2 KB id arrays + control words <= 40 KB: 4 workgroups per CU */
 
 /* traversal stack of the workgroup kernel: LDS first, deeper entries in a per-lane column of a global array (never scratch) */
 struct WgStack {

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	const size_t slabFloats = (size_t)Q.bw * Q.bh * chunk * 3;           /* one job's samples; a wave owns one slab per slot */
 	float *const myStage = stage + (size_t)__builtin_amdgcn_readfirstlane(wave) * (size_t)NS * slabFloats;
 	const int passEnd = P.first_pass + P.pass_count;
+	const uint32_t trisOff = (uint32_t)((const char *)S.tris - (const char *)S.nodes);          /* (one allocation: crh_scene_upload) */
 	f4 *const ptab = (f4 *)(queues + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_WAVE_QUEUE_FLOATS);
 	__shared__ int s_rq[(CRH_BLOCK / 64) * RQ_WORDS];
 	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_ROLL_IDS_BYTES];
@@ -213,17 +214,39 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		switch (pick) {
 			case ST_NODE: {
 				int now = nN;
+				/* Fused walk steps (round 4): a lane that descends needs a child pair, a lane at a leaf its next two triangles — both kinds of record are requested at the
+				 * top of an iteration and waited for ONCE, then the node lanes step, then (when enough of them wait: K.triInRun) the triangle lanes. The steps, their order per
+				 * path and their thresholds are the unfused loop's (round 3; git history); what changes is that a triangle step's memory round trip overlaps the node step's instead of
+				 * following it — and that a lane does ONE step per iteration: 5-10 % more iterations, each with one round trip instead of up to two. Measured (profiles/r04b_ab_*.log,
+				 * r04c_ab_kept.log): hdr.json +1.4...2.6 %, statues +0.2...0.9 %, 1 M soup +1.0 %, venus -0.9...-1.3 %; the share of a frame's last 2 ms does not move (r04d_probe_share8.log). */
+				f4 q0 = f4{0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;          /* (defined once per run: a lane reads only what it loaded in the same iteration, but an
+				                                                                                            * undefined value that meets a loaded one at every join costs the register allocator 70 spills) */
 				do {
-					if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
-					if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_node += 1; cnt.u_node += (uint32_t)now; } }
-					if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) {
-						if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
+					const bool isN = w.phase == PH_NODE;
+					const int nTw = (int)__popcll(__ballot(w.phase == PH_TRI));
+					const bool isT = nTw >= K.triInRun && w.phase == PH_TRI;
+					if constexpr (LEVEL >= 2) {
+						const uint32_t wf = (uint32_t)__popcll(__ballot(w.phase == PH_SHADE || w.phase == PH_IDLE));
+						if (lane == 0) { cnt.u_wait_tri += nTw >= K.triInRun ? 0u : (uint32_t)nTw; cnt.u_wait_fin += wf; cnt.w_node += 1; cnt.u_node += (uint32_t)now; if (nTw >= K.triInRun) { cnt.w_tri_in += 1; cnt.u_tri_in += (uint32_t)nTw; } }
 					}
+					/* one 32-bit byte offset from S.nodes for either kind of record (crh_scene_upload puts the triangles behind the nodes in the same allocation), six
+					 * quarters in the same registers: a child pair is the first four, two triangles (48 bytes each, consecutive) all six */
+					if (isN || isT) {
+						const uint32_t off = isN ? (uint32_t)(w.node << 5) : trisOff + w.pA * 48u;
+						const char *rec = (const char *)S.nodes + off;
+						q0 = *(const f4 *)rec; q1 = *(const f4 *)(rec + 16); q2 = *(const f4 *)(rec + 32); q3 = *(const f4 *)(rec + 48);
+						if (isT) { q4 = *(const f4 *)(rec + 64); q5 = *(const f4 *)(rec + 80); }
+					}
+					if (isN) stepNodeLoaded<true>(S, w, stk, cnt, port, q0, q1, q2, q3);
+					if (isT) stepTriLoaded(S, w, stk, cnt, port, q0, q1, q2, q3, q4, q5);
 					if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
+						if constexpr (LEVEL >= 2) { const uint32_t n2 = (uint32_t)__popcll(__ballot(w.phase == PH_CTRL)); if (lane == 0) { cnt.w_ctrl_in += 1; cnt.u_ctrl_in += n2; } }
 						if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
 					}
 					now = __popcll(__ballot(w.phase == PH_NODE));
-				} while (now * 8 >= nN * K.runNum);
+					/* (the lanes this iteration's node step sent to a leaf are served at the top of the next one: enough of them keep the run going, as their in-place
+					 * triangle step — after which they counted as node lanes again — did before the steps were fused) */
+				} while (now * 8 >= nN * K.runNum || (int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun);
 				break;
 			}
 			case ST_TRI: {
@@ -590,5 +613,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		v = waveSum(cnt.u_swap); if (lead && v) atomicAdd(&counters[23], (unsigned long long)v);
 		v = waveSum(cnt.u_tri); if (lead && v) atomicAdd(&counters[24], (unsigned long long)v);
 		v = waveSum(cnt.u_ctrl); if (lead && v) atomicAdd(&counters[25], (unsigned long long)v);
+		v = waveSum(cnt.w_tri_in); if (lead && v) atomicAdd(&counters[26], (unsigned long long)v);
+		v = waveSum(cnt.u_tri_in); if (lead && v) atomicAdd(&counters[27], (unsigned long long)v);
+		v = waveSum(cnt.w_ctrl_in); if (lead && v) atomicAdd(&counters[28], (unsigned long long)v);
+		v = waveSum(cnt.u_ctrl_in); if (lead && v) atomicAdd(&counters[29], (unsigned long long)v);
+		v = waveSum(cnt.u_wait_tri); if (lead && v) atomicAdd(&counters[30], (unsigned long long)v);
+		v = waveSum(cnt.u_wait_fin); if (lead && v) atomicAdd(&counters[31], (unsigned long long)v);
 	}
 }

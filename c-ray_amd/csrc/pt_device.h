@@ -156,6 +156,8 @@ template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	uint32_t w_node, w_tri, w_ctrl, w_round, w_shade, w_setup;   /* debug: WAVE-level step counts by kind (lane 0 counts) */
 	uint32_t u_node, u_shade;                                     /* debug: lanes served by the node / shade steps */
 	uint32_t t_swap, t_gen, n_swap, n_gen, u_swap, u_tri, u_ctrl;                /* debug: swap / gen step clocks, counts, lanes moved by swaps */
+	uint32_t w_tri_in, u_tri_in, w_ctrl_in, u_ctrl_in;                           /* debug (rolling kernel): triangle / control steps served INSIDE node runs, and their lanes */
+	uint32_t u_wait_tri, u_wait_fin;                                              /* debug (rolling kernel): summed over node steps, the lanes that sat the step out waiting for a triangle step / for a retire + refill */
 };
 template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
 	static constexpr int level = 1;
@@ -907,16 +909,18 @@ struct TravHit {
  * kind of step that most lanes are waiting for — lanes never sit out a whole divergent loop of their neighbours.
  * Hit attributes are derived after the walk (finishHit).
  *
- * Stack: LDS-resident (device) / local array (host emulation); entries are device node indices, plus the saved
- * TLAS state (resume pair, pending instance ranges) while a lane is inside a BLAS; the world-space slab constants
- * are parked in fixed LDS slots meanwhile.
+ * Stack: LDS-resident (device) / local array (host emulation); entries are device node indices. While a lane is inside
+ * a BLAS the interrupted top-level walk (resume pair, pending instance ranges) and the world-space ray with its slab
+ * constants are parked in fixed LDS slots (PK_*).
  */
-#define CRH_TLAS_SAVE 5    /* stack entries a BLAS visit adds on top of the node entries */
+#define CRH_TLAS_SAVE 0    /* stack entries a BLAS visit adds on top of the node entries: none since round 4 (the interrupted top-level walk — resume pair and pending
+                            * instance ranges — is parked in fixed slots, PK_NODE ... PK_PBE, beside the world ray; until then it went through five stack pushes and pops, each
+                            * with its own LDS-or-overflow branch: ~15 vector and ~50 scalar instructions per BLAS visit in the node step that leaves and in the control step that enters) */
 /* fixed per-lane park slots (LDS on the device): the world-space ray and its slab constants while a lane is inside a BLAS */
 /* (parking the ray only and recomputing the slab constants on the way out was measured: -2.4 % on hdr.json, -6 % on statues.json; profiles/r03_exp_variants.patch) */
 /* (the slab offsets ss = -(o * inv) are not parked: three multiplications and three negations of parked values give the same bits back, and the
  * three LDS words per lane they occupied until round 3 — 3 KB per workgroup — now hold the instance records, cray_hip.hip: CRH_INST_LDS0_MAX) */
-enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_OCT, CRH_PARK_SLOTS };
+enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_OCT, PK_NODE, PK_PA, PK_PAE, PK_PB, PK_PBE, CRH_PARK_SLOTS };
 
 enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6, PH_NODE_SLOW = 7 };   /* PH_NODE_SLOW: a node step for a degenerate ray (rare; served with the control steps) */   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
@@ -1023,7 +1027,7 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
 	w.k.ss = vscale(vmul(w.k.o, w.k.inv), -1.0f);                    /* makeRayK's own expression on the same values */
 	w.k.oct = stk.unpark(PK_OCT);
-	w.pBe = stk.pop(--w.sp); w.pB = stk.pop(--w.sp); w.pAe = stk.pop(--w.sp); w.pA = stk.pop(--w.sp); w.node = stk.pop(--w.sp);
+	w.node = stk.unpark(PK_NODE); w.pA = stk.unpark(PK_PA); w.pAe = stk.unpark(PK_PAE); w.pB = stk.unpark(PK_PB); w.pBe = stk.unpark(PK_PBE);
 	w.spBase = 0;
 	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > 0u) w.node = stk.pop(--w.sp);
@@ -1102,19 +1106,27 @@ CRH_DEV void testTriangle(const f4 q0, const f4 q1, const f4 q2, uint32_t slot, 
 }
 /* One triangle step = the next TWO triangles of the pending leaf range when it holds two (in order, the second sees the
  * first's hit distance: poly.c:17-36 via bvh.c:449-458); both records are requested before either is used. */
+/* (the records arrive loaded: stepTri fetches them itself; the rolling kernel's node run requests them together with the node pairs of the lanes that keep descending
+ * and calls this — fused walk steps, pathtrace_roll.h) */
 template <class Stack, class Cnt, class Port>
-CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
+CRH_DEV void stepTriLoaded(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port, const f4 a0, const f4 a1, const f4 a2, const f4 b0, const f4 b1, const f4 b2) {
 	const uint32_t slot = w.pA;
 	const bool two = slot + 1u < w.pAe;
 	const uint32_t slot2 = two ? slot + 1u : slot;
-	const char *ta = (const char *)S.tris + (uint32_t)(slot * 48u), *tb = (const char *)S.tris + (uint32_t)(slot2 * 48u);
-	const f4 a0 = *(const f4 *)ta, a1 = *(const f4 *)(ta + 16), a2 = *(const f4 *)(ta + 32);
-	const f4 b0 = *(const f4 *)tb, b1 = *(const f4 *)(tb + 16), b2 = *(const f4 *)(tb + 32);
 	w.pA = slot2 + 1u;
 	if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
 	testTriangle(a0, a1, a2, slot, w, cnt);
 	if (two) testTriangle(b0, b1, b2, slot2, w, cnt);
 	walkAdvance(S, w, stk, cnt, port);
+}
+template <class Stack, class Cnt, class Port>
+CRH_DEV void stepTri(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
+	const uint32_t slot = w.pA;
+	const uint32_t slot2 = slot + 1u < w.pAe ? slot + 1u : slot;
+	const char *ta = (const char *)S.tris + (uint32_t)(slot * 48u), *tb = (const char *)S.tris + (uint32_t)(slot2 * 48u);
+	const f4 a0 = *(const f4 *)ta, a1 = *(const f4 *)(ta + 16), a2 = *(const f4 *)(ta + 32);
+	const f4 b0 = *(const f4 *)tb, b1 = *(const f4 *)(tb + 16), b2 = *(const f4 *)(tb + 32);
+	stepTriLoaded(S, w, stk, cnt, port, a0, a1, a2, b0, b1, b2);
 }
 
 /* CTRL: leave a finished BLAS (bvh.c:468-486 loop body tail) and / or visit the next instance of a TLAS leaf (bvh.c:472-484) */
@@ -1168,7 +1180,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			rootA = CRH_DNODE_FIRST(n1); rootAe = rootA + CRH_DNODE_COUNT(n1);
 		}
 		if (enter) {
-			stk.push(w.sp++, w.node); stk.push(w.sp++, w.pA); stk.push(w.sp++, w.pAe); stk.push(w.sp++, w.pB); stk.push(w.sp++, w.pBe);
+			stk.park(PK_NODE, w.node); stk.park(PK_PA, w.pA); stk.park(PK_PAE, w.pAe); stk.park(PK_PB, w.pB); stk.park(PK_PBE, w.pBe);
 			stk.park(PK_OX, asU32(w.k.o.x)); stk.park(PK_OY, asU32(w.k.o.y)); stk.park(PK_OZ, asU32(w.k.o.z));
 			stk.park(PK_DX, asU32(w.k.d.x)); stk.park(PK_DY, asU32(w.k.d.y)); stk.park(PK_DZ, asU32(w.k.d.z));
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));

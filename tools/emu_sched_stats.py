@@ -63,6 +63,9 @@ for k, n, lanes in rows:
         s += f", {n * ns[k] / 1e6:10.1f} wave-ms per step"
     print(s)
 print(f"  rounds {t['w_round']}")
+if t.get("w_tri_in") is not None and t["w_node"]:
+    print(f"  inside node runs: {t['w_tri_in']} triangle steps at {t['u_tri_in'] / max(t['w_tri_in'], 1):.1f} lanes, {t['w_ctrl_in']} control steps at {t['u_ctrl_in'] / max(t['w_ctrl_in'], 1):.1f} lanes; "
+          f"per node step {t['u_wait_tri'] / t['w_node']:.1f} lanes waited for a triangle step, {t['u_wait_fin'] / t['w_node']:.1f} for a retire / refill")
 if ns:
     print(f"  model A (a step costs what the GPU measured per STEP):      {per_step / 1e6:9.1f} wave-ms = {per_step / 1e6 / 4096:.2f} ms on 4096 waves, {per_step / max(rays, 1):.1f} wave-ns per ray")
     print(f"  model B (a step costs what the GPU measured per LANE-step): {per_lane / 1e6:9.1f} wave-ms = {per_lane / 1e6 / 4096:.2f} ms on 4096 waves, {per_lane / max(rays, 1):.1f} wave-ns per ray")

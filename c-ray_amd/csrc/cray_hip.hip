@@ -864,8 +864,11 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	if (rc) return rc;
 	CompiledScene cs;
 	std::string err;
+	const auto tUp0 = std::chrono::steady_clock::now();
+	auto upMs = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tUp0).count(); };
 	rc = compile_scene(scene, cs, err);
 	if (rc != CRH_OK) return fail(rc, "crh_scene_upload: " + err);
+	const double tCompile = upMs();
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	freeScene(c);
 	DScene d;
@@ -909,10 +912,14 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	 * set-up. Measured in round 3 (CRH_TRACE_SYNC): without it the first dispatch's kernel starts 7-25 ms after its launch — behind work the runtime
 	 * still owes the pageable host-to-device copies above, which neither hipStreamSynchronize on the context's (non-blocking) stream nor
 	 * hipDeviceSynchronize waits for; with it, 1-5 us. (Until round 3 the watchdog flag's copy in crh_synchronize was this barrier by accident.) */
+	const double tCopies = upMs();
 	rc = preloadKernel(c, true);         /* ... and an (empty) launch of the kernel on the context's stream is waited for: see below */
 	if (rc != CRH_OK) return rc;
 	unsigned int flag = 0;
 	HIP_TRY(hipMemcpy(&flag, c->dWork + (CRH_WORK_SLOTS - 1), sizeof(flag), hipMemcpyDeviceToHost));
+	if (getenv("CRH_TRACE_UPLOAD"))         /* dev: where crh_scene_upload's time goes */
+		fprintf(stderr, "crh_scene_upload trace: layout compile %.1f ms, allocations + copies %.1f ms (%.1f MB), code object + barrier %.1f ms\n", tCompile, tCopies - tCompile,
+				(double)(cs.nodes.size() * 16 + cs.tris.size() * 16 + cs.shade.size() * sizeof(DShadeTri) + cs.texels.size() * 16) / 1e6, upMs() - tCopies);
 	return CRH_OK;
 }
 

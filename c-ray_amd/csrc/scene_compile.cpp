@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
+#include <mutex>
+#include <thread>
 
 namespace crh {
 
@@ -27,6 +30,27 @@ struct Fail {
 			throw Fail{code, buf_};                            \
 		}                                                      \
 	} while (0)
+
+/* fn(begin, end) over [0, n) on up to sixteen threads (chunks of at least `grain`); a Fail thrown by any chunk is rethrown here (the first one in index order
+ * would need a sort: any one of them is a correct diagnosis). CRH_COMPILE_THREADS=1 keeps everything on the calling thread. */
+template <class F> void parallelFor(size_t n, size_t grain, F fn) {
+	static const unsigned want = [] { const char *e = getenv("CRH_COMPILE_THREADS"); const unsigned h = std::thread::hardware_concurrency(); return e && atoi(e) > 0 ? (unsigned)atoi(e) : (h > 16u ? 16u : (h ? h : 1u)); }();
+	const size_t chunks = std::min<size_t>(want, std::max<size_t>(n / std::max<size_t>(grain, 1), 1));
+	if (chunks <= 1) { fn((size_t)0, n); return; }
+	std::mutex mu;
+	bool failed = false;
+	Fail first{0, ""};
+	std::vector<std::thread> pool;
+	auto run = [&](size_t c) {
+		const size_t b = n * c / chunks, e = n * (c + 1) / chunks;
+		try { fn(b, e); }
+		catch (const Fail &f) { std::lock_guard<std::mutex> g(mu); if (!failed) { failed = true; first = f; } }
+	};
+	for (size_t c = 1; c < chunks; ++c) pool.emplace_back(run, c);
+	run(0);
+	for (auto &t : pool) t.join();
+	if (failed) throw first;
+}
 
 inline bool isBsdfKind(uint32_t k) { return k >= CRH_BSDF_DIFFUSE && k <= CRH_BSDF_BACKGROUND; }
 inline bool isColorKind(uint32_t k) { return k >= CRH_COLOR_CONSTANT && k <= CRH_COLOR_VECTOCOLOR; }
@@ -48,38 +72,47 @@ struct Compiler {
 
 	BvhInfo relayoutBvh(uint32_t node_base, uint32_t node_count, uint32_t prim_base, uint32_t prim_count, const char *what) {
 		BvhInfo info{0, 0, 0};
-		if (out.nodes.size() % 4) out.nodes.resize(out.nodes.size() + 2);   /* even device node index */
+		if (out.nodes.size() % 4) out.nodes.resize(out.nodes.size() + 2, f4{0, 0, 0, 0});   /* even device node index */
 		const uint32_t dev_base = (uint32_t)(out.nodes.size() / 2);
 		info.dev_base = dev_base;
 		info.root = dev_base + 1;
 		if (node_count == 0) return info;
 		CHECK((uint64_t)node_base + node_count <= s->node_count, CRH_ERR_INVALID, "%s: node range out of bounds", what);
 		CHECK((uint64_t)prim_base + prim_count <= s->prim_index_count, CRH_ERR_INVALID, "%s: prim range out of bounds", what);
-		out.nodes.resize((size_t)(dev_base + 1 + node_count) * 2, f4{0, 0, 0, 0});
-		std::vector<uint32_t> depth(node_count, 0);
+		out.nodes.resize((size_t)(dev_base + 1 + node_count) * 2);
+		out.nodes[(size_t)dev_base * 2] = f4{0, 0, 0, 0}; out.nodes[(size_t)dev_base * 2 + 1] = f4{0, 0, 0, 0};          /* the unused slot in front of the root */
+		/* validation + records: every node on its own (threads) ... */
+		parallelFor(node_count, 1u << 16, [&](size_t b0, size_t e0) {
+			for (uint32_t i = (uint32_t)b0; i < (uint32_t)e0; ++i) {
+				const crh_bvh_node &n = s->nodes[node_base + i];
+				const uint32_t count = CRH_NODE_PRIMCOUNT(n);
+				const bool leaf = CRH_NODE_ISLEAF(n);
+				uint32_t first;
+				if (leaf) {
+					CHECK((uint64_t)n.first + count <= prim_count, CRH_ERR_INVALID, "%s: leaf %u prim range out of bounds", what, i);
+					first = prim_base + n.first;
+				} else {
+					/* children are allocated after their parent, as an (odd, even) pair: bvh.c:221-223 */
+					CHECK(n.first > i && (uint64_t)n.first + 1 < node_count && (n.first & 1u), CRH_ERR_INVALID,
+						  "%s: inner node %u has child index %u (count %u)", what, i, n.first, node_count);
+					first = dev_base + 1 + n.first;
+				}
+				f4 a{n.bounds[0], n.bounds[1], n.bounds[2], n.bounds[3]};
+				f4 b{n.bounds[4], n.bounds[5], asF32(first), asF32((count & 0x3FFFFFFFu) | (leaf ? 0x40000000u : 0u))};
+				out.nodes[(size_t)(dev_base + 1 + i) * 2] = a;
+				out.nodes[(size_t)(dev_base + 1 + i) * 2 + 1] = b;
+			}
+		});
+		/* ... the depth in index order (children come after their parent) */
+		std::vector<uint8_t> depth(node_count, 0);
 		for (uint32_t i = 0; i < node_count; ++i) {
 			const crh_bvh_node &n = s->nodes[node_base + i];
-			const uint32_t count = CRH_NODE_PRIMCOUNT(n);
-			const bool leaf = CRH_NODE_ISLEAF(n);
-			uint32_t first;
-			if (leaf) {
-				CHECK((uint64_t)n.first + count <= prim_count, CRH_ERR_INVALID, "%s: leaf %u prim range out of bounds", what, i);
-				first = prim_base + n.first;
-			} else {
-				/* children are allocated after their parent, as an (odd, even) pair: bvh.c:221-223 */
-				CHECK(n.first > i && (uint64_t)n.first + 1 < node_count && (n.first & 1u), CRH_ERR_INVALID,
-					  "%s: inner node %u has child index %u (count %u)", what, i, n.first, node_count);
-				first = dev_base + 1 + n.first;
-				const uint32_t d = depth[i] + 1;
-				depth[n.first] = std::max(depth[n.first], d);
-				depth[n.first + 1] = std::max(depth[n.first + 1], d);
-				info.depth = std::max(info.depth, d);
-				CHECK(d <= 64, CRH_ERR_UNSUPPORTED, "%s deeper than MAX_BVH_DEPTH 64 (bvh.c:32)", what);
-			}
-			f4 a{n.bounds[0], n.bounds[1], n.bounds[2], n.bounds[3]};
-			f4 b{n.bounds[4], n.bounds[5], asF32(first), asF32((count & 0x3FFFFFFFu) | (leaf ? 0x40000000u : 0u))};
-			out.nodes[(size_t)(dev_base + 1 + i) * 2] = a;
-			out.nodes[(size_t)(dev_base + 1 + i) * 2 + 1] = b;
+			if (CRH_NODE_ISLEAF(n)) continue;
+			const uint32_t d = (uint32_t)depth[i] + 1;
+			CHECK(d <= 64, CRH_ERR_UNSUPPORTED, "%s deeper than MAX_BVH_DEPTH 64 (bvh.c:32)", what);
+			depth[n.first] = (uint8_t)std::max<uint32_t>(depth[n.first], d);
+			depth[n.first + 1] = (uint8_t)std::max<uint32_t>(depth[n.first + 1], d);
+			info.depth = std::max(info.depth, d);
 		}
 		if (node_count > 1) {
 			CHECK(!CRH_NODE_ISLEAF(s->nodes[node_base]), CRH_ERR_INVALID, "%s: multi-node BVH with a leaf root", what);
@@ -268,6 +301,8 @@ struct Compiler {
 	}
 
 	void run() {
+		auto t0 = std::chrono::steady_clock::now();
+		auto lap = [&]() { const auto t1 = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; return ms; };
 		CHECK(s->struct_size == sizeof(crh_scene_desc), CRH_ERR_INVALID, "crh_scene_desc.struct_size %u != %zu", s->struct_size, sizeof(crh_scene_desc));
 		CHECK(s->abi_version == CRH_SCENE_VERSION, CRH_ERR_INVALID, "scene description version %u != %d", s->abi_version, CRH_SCENE_VERSION);
 		CHECK(s->node_count < 0x3FFFFFFFull && s->prim_index_count < 0x3FFFFFFFull && s->poly_count < 0x7FFFFFFFull, CRH_ERR_UNSUPPORTED, "scene too large for 32-bit device indices");
@@ -294,7 +329,8 @@ struct Compiler {
 			const size_t W = tx.width, H = tx.height, Cn = tx.channels;
 			out.texels.resize(out.texels.size() + W * H);
 			f4 *dst = out.texels.data() + d.first;
-			for (size_t y = 0; y < H; ++y)
+			parallelFor(H, 64, [&](size_t y0, size_t y1) {
+			for (size_t y = y0; y < y1; ++y)
 				for (size_t x = 0; x < W; ++x) {
 					const size_t base = (x + ((H - 1) - y) * W) * Cn;
 					f4 o;
@@ -310,11 +346,14 @@ struct Compiler {
 					}
 					dst[x + y * W] = o;
 				}
+			});
 		}
 		if (out.textures.empty()) { DTexture d; memset(&d, 0, sizeof(d)); d.width = d.height = 1; out.textures.push_back(d); }
 		if (out.texels.empty()) out.texels.push_back(f4{0, 0, 0, 0});
 
+		const double tTex = lap();
 		compileGraph();
+		const double tGraph = lap();
 		CHECK(s->background < s->gnode_count && s->gnodes[s->background].kind == CRH_BSDF_BACKGROUND, CRH_ERR_INVALID, "scene.background is not a background node");
 		out.background = s->background;
 		out.materials.assign(s->materials, s->materials + s->material_count);
@@ -326,8 +365,16 @@ struct Compiler {
 		}
 
 		/* BLAS per mesh, prepared triangles */
-		out.tris.assign((size_t)std::max<uint64_t>(s->prim_index_count, 1) * 3, f4{0, 0, 0, 0});
-		{ DShadeTri z; memset(&z, 0, sizeof(z)); out.shade.assign((size_t)std::max<uint64_t>(s->prim_index_count, 1), z); }
+		/* (every prim slot of a mesh with a BVH is written below; slots no mesh owns — none in scenes the flattener makes — are zeroed first) */
+		out.tris.resize((size_t)std::max<uint64_t>(s->prim_index_count, 1) * 3);
+		out.shade.resize((size_t)std::max<uint64_t>(s->prim_index_count, 1));
+		{
+			bool all = s->prim_index_count > 0;
+			uint64_t covered = 0;
+			for (uint64_t m = 0; m < s->mesh_count; ++m) if (s->meshes[m].node_count) covered += s->meshes[m].poly_count;
+			if (covered != s->prim_index_count) all = false;
+			if (!all) { memset((void *)out.tris.data(), 0, out.tris.size() * sizeof(f4)); memset((void *)out.shade.data(), 0, out.shade.size() * sizeof(DShadeTri)); }
+		}
 		std::vector<BvhInfo> meshBvh(s->mesh_count);
 		uint32_t maxBlasDepth = 0;
 		for (uint64_t m = 0; m < s->mesh_count; ++m) {
@@ -337,7 +384,8 @@ struct Compiler {
 			meshBvh[m] = relayoutBvh(mesh.node_base, mesh.node_count, mesh.prim_base, mesh.node_count ? mesh.poly_count : 0, "BLAS");
 			maxBlasDepth = std::max(maxBlasDepth, meshBvh[m].depth);
 			if (!mesh.node_count) continue;
-			for (uint32_t k = 0; k < mesh.poly_count; ++k) {
+			parallelFor(mesh.poly_count, 1u << 14, [&](size_t k0, size_t k1) {
+			for (uint32_t k = (uint32_t)k0; k < (uint32_t)k1; ++k) {
 				const int32_t pi = s->prim_indices[mesh.prim_base + k];
 				CHECK(pi >= 0 && (uint32_t)pi < mesh.poly_count, CRH_ERR_INVALID, "mesh %llu: prim index %d out of range", (unsigned long long)m, pi);
 				const crh_poly &p = s->polys[mesh.poly_base + pi];
@@ -359,6 +407,7 @@ struct Compiler {
 				q[1] = f4{e1.y, e1.z, e2.x, e2.y};
 				q[2] = f4{e2.z, n.x, n.y, n.z};
 				DShadeTri &st = out.shade[(size_t)mesh.prim_base + k];
+				memset((void *)&st, 0, sizeof(st));
 				st.flags = CRH_POLY_MATERIAL(p);
 				if (CRH_POLY_HASNORMALS(p)) {
 					st.flags |= CRH_SHADE_HASNORMALS;
@@ -373,8 +422,11 @@ struct Compiler {
 					for (int c = 0; c < 2; ++c) { st.t0[c] = T[2 * (size_t)p.t[0] + c]; st.t1[c] = T[2 * (size_t)p.t[1] + c]; st.t2[c] = T[2 * (size_t)p.t[2] + c]; }
 				}
 			}
+			});
 		}
 
+		const double tBlas = lap();
+		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: textures %.1f ms, node graph %.1f ms, BLAS + prepared triangles %.1f ms\n", tTex, tGraph, tBlas);
 		/* TLAS */
 		CHECK(s->tlas_prim_count == (s->tlas_node_count ? s->instance_count : 0), CRH_ERR_INVALID, "TLAS prim count does not match the instance count");
 		const BvhInfo tlas = relayoutBvh(s->tlas_node_base, s->tlas_node_count, s->tlas_prim_base, s->tlas_prim_count, "TLAS");
@@ -430,6 +482,7 @@ struct Compiler {
 			out.instances[k] = d;
 		}
 		assignShadeClasses();
+		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: TLAS + instances + classes %.1f ms\n", lap());
 		for (uint64_t i = 0; i < s->instance_count; ++i) {           /* instances outside the TLAS (none with the reference's builder) are still validated */
 			const crh_instance &in = s->instances[i];
 			CHECK(in.kind <= CRH_INSTANCE_MESH_VOLUME, CRH_ERR_UNSUPPORTED, "unknown instance kind %u", in.kind);
@@ -446,8 +499,11 @@ struct Compiler {
 	 * Purely a scheduling hint: every path's own sequence of operations, hence every result, is independent of it. */
 	void assignShadeClasses() {
 		std::vector<uint32_t> sigOfMesh(s->mesh_count, 0xFFFFFFFFu);
+		std::vector<uint32_t> sigMemo((size_t)s->material_count * 2u, 0xFFFFFFFFu);          /* a mesh asks once per POLYGON: the walk of a material's graph is done once */
 		auto sigOfMaterial = [&](uint32_t m, bool sphere) -> uint32_t {
 			if (m >= s->material_count) return 0xFFFFFFu;
+			uint32_t &memo = sigMemo[(size_t)m * 2u + (sphere ? 1u : 0u)];
+			if (memo != 0xFFFFFFFFu) return memo;
 			const crh_material &mt = s->materials[m];
 			/* the bsdf kinds in the material's graph (the loader wraps every JSON material in mix(transparent, X, alpha): the root says nothing) */
 			uint32_t kinds = 0;
@@ -459,7 +515,8 @@ struct Compiler {
 				todo.push_back(s->gnodes[g].a); todo.push_back(s->gnodes[g].b); todo.push_back(s->gnodes[g].c);
 			}
 			const bool emits = mt.emission[0] > 0.0f || mt.emission[1] > 0.0f || mt.emission[2] > 0.0f;
-			return kinds | (out.materials[m].pad[0] ? 1u << 16 : 0u) | (emits ? 1u << 17 : 0u) | (sphere ? 1u << 18 : 0u);
+			memo = kinds | (out.materials[m].pad[0] ? 1u << 16 : 0u) | (emits ? 1u << 17 : 0u) | (sphere ? 1u << 18 : 0u);
+			return memo;
 		};
 		std::vector<uint32_t> sig(out.instances.size(), 0xFFFFFFu);
 		for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {

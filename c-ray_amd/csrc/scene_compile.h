@@ -21,16 +21,48 @@
  *           compiled to constants, image fetches or short postfix programs (pure functions of the hit).
  */
 #pragma once
+#include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 #include "pt_device.h"
 
 namespace crh {
 
+/* The four big arrays of a compiled scene (nodes, prepared triangles, shading records, texels: 150 MB for BASELINE configs[1]) live in plain heap blocks that grow
+ * WITHOUT value-initialising what the compiler is about to overwrite anyway (std::vector::resize zero-fills: 190 MB of memset for the texels alone), and are
+ * filled by several threads (scene_compile.cpp: parallelFor). Plain-old-data only. */
+template <class T> struct PodBuf {
+	T *p = nullptr;
+	size_t n = 0, cap = 0;
+	PodBuf() = default;
+	PodBuf(const PodBuf &) = delete;
+	PodBuf &operator=(const PodBuf &) = delete;
+	~PodBuf() { free(p); }
+	T *data() { return p; }
+	const T *data() const { return p; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	T &operator[](size_t i) { return p[i]; }
+	const T &operator[](size_t i) const { return p[i]; }
+	void reserve(size_t c) {
+		if (c <= cap) return;
+		size_t nc = cap ? cap : 16;
+		while (nc < c) nc *= 2;
+		T *q = (T *)realloc((void *)p, nc * sizeof(T));
+		if (!q) throw std::bad_alloc();
+		p = q; cap = nc;
+	}
+	void resize(size_t c) { reserve(c); n = c; }                                  /* new elements are NOT initialised */
+	void resize(size_t c, const T &v) { const size_t o = n; resize(c); for (size_t i = o; i < c; ++i) p[i] = v; }
+	void assign(size_t c, const T &v) { n = 0; resize(c, v); }
+	void push_back(const T &v) { reserve(n + 1); p[n++] = v; }
+};
+
 struct CompiledScene {
-	std::vector<f4> nodes;
-	std::vector<f4> tris;
-	std::vector<DShadeTri> shade;
+	PodBuf<f4> nodes;
+	PodBuf<f4> tris;
+	PodBuf<DShadeTri> shade;
 	std::vector<DInstance> instances;
 	std::vector<DBsdf> bsdfs;
 	std::vector<crh_material> materials;   /* scene materials + pad[0] = 1 when the material's bsdf graph reads the hit's uv */
@@ -38,7 +70,7 @@ struct CompiledScene {
 	std::vector<DImage> images;
 	std::vector<DOp> prog;
 	std::vector<DTexture> textures;
-	std::vector<f4> texels;
+	PodBuf<f4> texels;
 	uint32_t tlas_root = 0, tlas_node_count = 0, tlas_prim_base = 0, background = 0, shade_classes = 0;
 	uint32_t tlas_first = 0;    /* device index of TLAS node 1 (the TLAS nodes are contiguous: node i at tlas_first - 1 + i) */
 	uint32_t max_stack = 0;     /* worst-case traversal stack entries (TLAS depth + saved TLAS state + deepest BLAS) */

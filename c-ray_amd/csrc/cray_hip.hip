@@ -230,6 +230,7 @@ __device__ __forceinline__ DScene globalize(const DScene &S) {
 	G.instances = asGlobal(S.instances); G.materials = asGlobal(S.materials);
 	G.bsdfs = asGlobal(S.bsdfs); G.consts = asGlobal(S.consts); G.images = asGlobal(S.images); G.prog = asGlobal(S.prog);
 	G.textures = asGlobal(S.textures); G.texels = asGlobal(S.texels);
+	G.camera = (const crh_camera *)(const __attribute__((address_space(4))) crh_camera *)S.camera;          /* constant address space: uniform scalar loads */
 	return G;
 }
 
@@ -903,7 +904,8 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	d.material_count = (uint32_t)cs.materials.size(); d.bsdf_count = (uint32_t)cs.bsdfs.size(); d.const_count = (uint32_t)cs.consts.size();
 	d.image_count = (uint32_t)cs.images.size(); d.texture_count = (uint32_t)cs.textures.size();
 	d.tlas_root = cs.tlas_root; d.tlas_node_count = cs.tlas_node_count; d.tlas_prim_base = cs.tlas_prim_base; d.shade_classes = cs.shade_classes; d.instance_count = (uint32_t)cs.instances.size();
-	d.background = cs.background; d.camera = cs.camera;
+	d.background = cs.background;
+	{ const crh_camera *cam = nullptr; rc = upload(c, &cs.camera, 1, &cam); if (rc) { freeScene(c); return rc; } d.camera = cam; }
 	c->d = d;
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
 	c->hasVolumes = cs.has_volumes;

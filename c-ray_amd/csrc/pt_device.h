@@ -139,7 +139,8 @@ struct DScene {
 	uint32_t image_count, texture_count;
 	uint32_t material_count, bsdf_count, const_count;       /* records in materials[] / bsdfs[] / consts[] (small tables may be staged in LDS: loadMaterial / loadBsdf / loadConst) */
 	uint32_t tlas_first;        /* device index of the first TLAS node after the root (the TLAS nodes tlas_first .. tlas_first + tlas_node_count - 2 are contiguous) */
-	crh_camera camera;
+	const crh_camera *camera;   /* (a record in memory rather than 26 words of kernel argument: only path generation reads it — scalar loads when a GEN step runs instead of scalar
+	                             * registers that live, and spill, across the whole machine) */
 };
 
 /* Counter levels: 0 none, 1 rays + paths only (timed runs), 2 everything (parity / roofline runs).
@@ -1327,7 +1328,7 @@ CRH_DEV void beginPath(const DScene &S, const crh_render_params &P, int x, int y
 	CRH_COUNT1(cnt, paths, 1);
 	const uint32_t pixIdx = (uint32_t)(y * P.image_width + x);          /* renderer.c:280 */
 	initSampler(r.rng, pass, P.max_passes, pixIdx);                       /* :281 */
-	getCameraRay(S.camera, r.rng, x, y, ro, rd);                          /* :284 */
+	getCameraRay(*S.camera, r.rng, x, y, ro, rd);                          /* :284 */
 	r.wr = r.wg = r.wb = 1.0f; r.fr = r.fg = r.fb = 0.0f; r.depth = 0;
 }
 

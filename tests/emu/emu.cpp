@@ -38,7 +38,7 @@ DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
 	d.textures = c.textures.data(); d.texels = c.texels.data();
 	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base; d.tlas_first = c.tlas_first;
 	d.material_count = (uint32_t)c.materials.size(); d.bsdf_count = (uint32_t)c.bsdfs.size(); d.const_count = (uint32_t)c.consts.size(); d.image_count = (uint32_t)c.images.size(); d.texture_count = (uint32_t)c.textures.size();
-	d.background = c.background; d.camera = c.camera;
+	d.background = c.background; d.camera = &c.camera;
 	return d;
 }
 std::string g_err;

@@ -240,6 +240,10 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 }
 
 #define CRH_NCOUNTERS 32
+/* the counter block of a context: CRH_NCOUNTERS global 64-bit counters, then CRH_NCOUNTERS 32-bit words per wave (the rolling kernel's wave-level numbers of the counting
+ * instantiation: pathtrace_roll.h, CRH_WCTR) for the largest grid a context launches (8 workgroups per CU) */
+#define CRH_COUNTER_WAVES_MAX(cus) ((size_t)(cus) * 8u * 4u)
+#define CRH_COUNTER_BYTES(cus) (CRH_NCOUNTERS * sizeof(unsigned long long) + CRH_COUNTER_WAVES_MAX(cus) * CRH_NCOUNTERS * sizeof(uint32_t))
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
 struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, shadeMin;
@@ -715,8 +719,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 		if (stream) c->stream = (hipStream_t)stream;
 		else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->ownStream = (e == hipSuccess); }
 	}
-	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, CRH_NCOUNTERS * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, CRH_NCOUNTERS * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->dCounters, CRH_COUNTER_BYTES(c->cuCount));
+	if (e == hipSuccess) e = hipMemset(c->dCounters, 0, CRH_COUNTER_BYTES(c->cuCount));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->dWork, CRH_WORK_SLOTS * sizeof(uint32_t));
 	if (e == hipSuccess) e = hipMemset(c->dWork, 0, CRH_WORK_SLOTS * sizeof(uint32_t));      /* a work counter is zero whenever a dispatch takes it: crh_render_tiles resets it BEHIND the kernel */
 	if (e == hipSuccess) e = hipHostMalloc((void **)&c->hErr, sizeof(unsigned int), hipHostMallocDefault);
@@ -1503,7 +1507,7 @@ int crh_counters_reset(crh_ctx *c) {
 	if (!c) return fail(CRH_ERR_INVALID, "crh_counters_reset: ctx is NULL");
 	int rc = crh_synchronize(c);
 	if (rc) return rc;
-	HIP_TRY(hipMemset(c->dCounters, 0, CRH_NCOUNTERS * sizeof(unsigned long long)));
+	HIP_TRY(hipMemset(c->dCounters, 0, CRH_COUNTER_BYTES(c->cuCount)));
 	c->lastMs = 0.0f; c->totalMs = 0.0; c->launches = 0;
 	return CRH_OK;
 }
@@ -1530,6 +1534,12 @@ int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* CRH_NCOUNTERS - 8 = 24 v
 	unsigned long long h[CRH_NCOUNTERS - 8];
 	HIP_TRY(hipMemcpy(h, c->dCounters + 8, sizeof(h), hipMemcpyDeviceToHost));
 	for (int i = 0; i < CRH_NCOUNTERS - 8; ++i) out3[i] = h[i];
+	/* ... plus the per-wave words of the rolling kernel (the other kernel forms add to the global counters) */
+	const size_t waves = CRH_COUNTER_WAVES_MAX(c->cuCount);
+	std::vector<uint32_t> w(waves * CRH_NCOUNTERS);
+	HIP_TRY(hipMemcpy(w.data(), c->dCounters + CRH_NCOUNTERS, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	for (size_t v = 0; v < waves; ++v)
+		for (int i = 8; i < CRH_NCOUNTERS; ++i) out3[i - 8] += w[v * CRH_NCOUNTERS + i];
 	return CRH_OK;
 }
 

@@ -93,6 +93,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	const int passEnd = P.first_pass + P.pass_count;
 	const uint32_t trisOff = (uint32_t)((const char *)S.tris - (const char *)S.nodes);          /* (one allocation: crh_scene_upload) */
 	f4 *const ptab = (f4 *)(queues + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_WAVE_QUEUE_FLOATS);
+	/* the counting kernel's wave-level numbers (steps, lanes served, clocks per step kind: indices 8.. of the counter block) go straight to this wave's own words behind
+	 * the global counters — one fire-and-forget atomic by lane 0 per event, no contention — instead of through two dozen registers per lane that are summed at the end:
+	 * those registers were 70 spilled VGPRs, and the counting kernel's step clocks were not the timed kernel's */
+	uint32_t *const waveCtr = (uint32_t *)(counters + CRH_NCOUNTERS) + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_NCOUNTERS;
+#define CRH_WCTR(k, v) atomicAdd(&waveCtr[k], (uint32_t)(v))
 	__shared__ int s_rq[(CRH_BLOCK / 64) * RQ_WORDS];
 	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_ROLL_IDS_BYTES];
 	typedef volatile __attribute__((address_space(3))) int lds_int;
@@ -226,8 +231,12 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					const int nTw = (int)__popcll(__ballot(w.phase == PH_TRI));
 					const bool isT = nTw >= K.triInRun && w.phase == PH_TRI;
 					if constexpr (LEVEL >= 2) {
+						if (lane == 0) { CRH_WCTR(11, 1); CRH_WCTR(17, now); }
+#ifdef CRH_CENSUS          /* the node-run census (tools/emu_sched_stats.py: who sits a node step out, and why): six more per-lane counters, which the kernel emulation can afford and the
+                            * counting kernel on the GPU cannot — with them its spilled VGPRs went from 60 to 95-176 and its step clocks stopped resembling the timed kernel's */
 						const uint32_t wf = (uint32_t)__popcll(__ballot(w.phase == PH_SHADE || w.phase == PH_IDLE));
-						if (lane == 0) { cnt.u_wait_tri += nTw >= K.triInRun ? 0u : (uint32_t)nTw; cnt.u_wait_fin += wf; cnt.w_node += 1; cnt.u_node += (uint32_t)now; if (nTw >= K.triInRun) { cnt.w_tri_in += 1; cnt.u_tri_in += (uint32_t)nTw; } }
+						if (lane == 0) { CRH_WCTR(30, nTw >= K.triInRun ? 0u : (uint32_t)nTw); CRH_WCTR(31, wf); if (nTw >= K.triInRun) { CRH_WCTR(26, 1); CRH_WCTR(27, nTw); } }
+#endif
 					}
 					/* one 32-bit byte offset from S.nodes for either kind of record (crh_scene_upload puts the triangles behind the nodes in the same allocation), six
 					 * quarters in the same registers: a child pair is the first four, two triangles (48 bytes each, consecutive) all six */
@@ -240,7 +249,9 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					if (isN) stepNodeLoaded<true>(S, w, stk, cnt, port, q0, q1, q2, q3);
 					if (isT) stepTriLoaded(S, w, stk, cnt, port, q0, q1, q2, q3, q4, q5);
 					if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
-						if constexpr (LEVEL >= 2) { const uint32_t n2 = (uint32_t)__popcll(__ballot(w.phase == PH_CTRL)); if (lane == 0) { cnt.w_ctrl_in += 1; cnt.u_ctrl_in += n2; } }
+#ifdef CRH_CENSUS
+						if constexpr (LEVEL >= 2) { const uint32_t n2 = (uint32_t)__popcll(__ballot(w.phase == PH_CTRL)); if (lane == 0) { CRH_WCTR(28, 1); CRH_WCTR(29, n2); } }
+#endif
 						if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
 					}
 					now = __popcll(__ballot(w.phase == PH_NODE));
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				int now = nT;
 				do {
 					if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
-					if constexpr (LEVEL >= 2) { if (lane == 0) { cnt.w_tri += 1; cnt.u_tri += (uint32_t)now; } }
+					if constexpr (LEVEL >= 2) { if (lane == 0) { CRH_WCTR(12, 1); CRH_WCTR(24, now); } }
 					now = __popcll(__ballot(w.phase == PH_TRI));
 				} while (now * 8 >= nT * K.runNum);
 				break;
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					if (b < 4) clsLo -= gone << (8 * b); else clsHi -= gone << (8 * (b - 4));
 				}
 				}
-				if constexpr (LEVEL >= 2) { if (lane == 0) cnt.u_shade += (uint32_t)n; }
+				if constexpr (LEVEL >= 2) { if (lane == 0) CRH_WCTR(18, n); }
 				bool cont = false, done = false;
 				int mySlot = -1;
 				uint32_t id = 0;
@@ -561,13 +572,13 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		if constexpr (LEVEL >= 2) {
 			if (lane == 0) {
 				const uint32_t dt = CRH_TICK() - tk;
-				cnt.w_round += 1;
-				if (pick == ST_NODE) { cnt.t_trav += dt; }
-				else if (pick == ST_TRI) { cnt.t_setup += dt; }
-				else if (pick == ST_CTRL) { cnt.w_ctrl += 1; cnt.w_setup += dt; cnt.u_ctrl += (uint32_t)nC; }
-				else if (pick == ST_SWAP) { cnt.n_swap += 1; cnt.t_swap += dt; cnt.u_swap += (uint32_t)(nF + min(nE + nF, raysQ)); }
-				else if (pick == ST_GEN || pick == ST_MISS || pick == ST_OPEN || pick == ST_FOLD) { cnt.n_gen += 1; cnt.t_gen += dt; }
-				else { cnt.w_shade += 1; cnt.t_shade += dt; }
+				CRH_WCTR(14, 1);
+				if (pick == ST_NODE) { CRH_WCTR(9, dt); }
+				else if (pick == ST_TRI) { CRH_WCTR(8, dt); }
+				else if (pick == ST_CTRL) { CRH_WCTR(13, 1); CRH_WCTR(16, dt); CRH_WCTR(25, nC); }
+				else if (pick == ST_SWAP) { CRH_WCTR(21, 1); CRH_WCTR(19, dt); CRH_WCTR(23, nF + min(nE + nF, raysQ)); }
+				else if (pick == ST_GEN || pick == ST_MISS || pick == ST_OPEN || pick == ST_FOLD) { CRH_WCTR(22, 1); CRH_WCTR(20, dt); }
+				else { CRH_WCTR(15, 1); CRH_WCTR(10, dt); }
 			}
 		}
 	}
@@ -593,31 +604,6 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		v = waveSum(cnt.inst_hits); if (lead && v) atomicAdd(&counters[5], (unsigned long long)v);
 		v = waveSum(cnt.sphere_tests); if (lead && v) atomicAdd(&counters[6], (unsigned long long)v);
 		v = waveSum(cnt.tex_fetches); if (lead && v) atomicAdd(&counters[7], (unsigned long long)v);
-		if (lead) {
-			atomicAdd(&counters[8], (unsigned long long)cnt.t_setup);
-			atomicAdd(&counters[9], (unsigned long long)cnt.t_trav);
-			atomicAdd(&counters[10], (unsigned long long)cnt.t_shade);
-		}
-		v = waveSum(cnt.w_node); if (lead && v) atomicAdd(&counters[11], (unsigned long long)v);
-		v = waveSum(cnt.w_tri); if (lead && v) atomicAdd(&counters[12], (unsigned long long)v);
-		v = waveSum(cnt.w_ctrl); if (lead && v) atomicAdd(&counters[13], (unsigned long long)v);
-		v = waveSum(cnt.w_round); if (lead && v) atomicAdd(&counters[14], (unsigned long long)v);
-		v = waveSum(cnt.w_shade); if (lead && v) atomicAdd(&counters[15], (unsigned long long)v);
-		v = waveSum(cnt.w_setup); if (lead && v) atomicAdd(&counters[16], (unsigned long long)v);
-		v = waveSum(cnt.u_node); if (lead && v) atomicAdd(&counters[17], (unsigned long long)v);
-		v = waveSum(cnt.u_shade); if (lead && v) atomicAdd(&counters[18], (unsigned long long)v);
-		v = waveSum(cnt.t_swap); if (lead && v) atomicAdd(&counters[19], (unsigned long long)v);
-		v = waveSum(cnt.t_gen); if (lead && v) atomicAdd(&counters[20], (unsigned long long)v);
-		v = waveSum(cnt.n_swap); if (lead && v) atomicAdd(&counters[21], (unsigned long long)v);
-		v = waveSum(cnt.n_gen); if (lead && v) atomicAdd(&counters[22], (unsigned long long)v);
-		v = waveSum(cnt.u_swap); if (lead && v) atomicAdd(&counters[23], (unsigned long long)v);
-		v = waveSum(cnt.u_tri); if (lead && v) atomicAdd(&counters[24], (unsigned long long)v);
-		v = waveSum(cnt.u_ctrl); if (lead && v) atomicAdd(&counters[25], (unsigned long long)v);
-		v = waveSum(cnt.w_tri_in); if (lead && v) atomicAdd(&counters[26], (unsigned long long)v);
-		v = waveSum(cnt.u_tri_in); if (lead && v) atomicAdd(&counters[27], (unsigned long long)v);
-		v = waveSum(cnt.w_ctrl_in); if (lead && v) atomicAdd(&counters[28], (unsigned long long)v);
-		v = waveSum(cnt.u_ctrl_in); if (lead && v) atomicAdd(&counters[29], (unsigned long long)v);
-		v = waveSum(cnt.u_wait_tri); if (lead && v) atomicAdd(&counters[30], (unsigned long long)v);
-		v = waveSum(cnt.u_wait_fin); if (lead && v) atomicAdd(&counters[31], (unsigned long long)v);
 	}
 }
+#undef CRH_WCTR

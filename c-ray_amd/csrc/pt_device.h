@@ -157,8 +157,10 @@ template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	uint32_t w_node, w_tri, w_ctrl, w_round, w_shade, w_setup;   /* debug: WAVE-level step counts by kind (lane 0 counts) */
 	uint32_t u_node, u_shade;                                     /* debug: lanes served by the node / shade steps */
 	uint32_t t_swap, t_gen, n_swap, n_gen, u_swap, u_tri, u_ctrl;                /* debug: swap / gen step clocks, counts, lanes moved by swaps */
+#ifdef CRH_CENSUS
 	uint32_t w_tri_in, u_tri_in, w_ctrl_in, u_ctrl_in;                           /* debug (rolling kernel): triangle / control steps served INSIDE node runs, and their lanes */
 	uint32_t u_wait_tri, u_wait_fin;                                              /* debug (rolling kernel): summed over node steps, the lanes that sat the step out waiting for a triangle step / for a retire + refill */
+#endif
 };
 template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
 	static constexpr int level = 1;

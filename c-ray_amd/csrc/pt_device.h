@@ -810,6 +810,7 @@ CRH_DEV rgba sampleBackground(const DScene &S, ShadeRec &rec, Cnt &cnt, const Sr
  * bit 7: some component of the ray is not finite (reference NaN semantics are then followed literally). */
 struct RayK { v3 o, d, inv, ss; uint32_t oct; };
 #define CRH_RAY_SLOW 0xF0u
+#define CRH_RAY_PHASE_SHIFT 16
 #define CRH_RAY_LITERAL 0x100u   /* degenerate slabs follow the reference's NaN arithmetic literally instead of being tested exactly (set by the caller of walkBegin) */
 CRH_DEV bool finitef(float x) { return fabsf(x) <= FLT_MAX; }
 CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
@@ -821,6 +822,9 @@ CRH_DEV RayK makeRayK(v3 o, v3 d) {                     /* bvh.c:368-376 */
 	k.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u)
 		  | (fabsf(k.inv.x) > 1e30f ? 16u : 0u) | (fabsf(k.inv.y) > 1e30f ? 32u : 0u) | (fabsf(k.inv.z) > 1e30f ? 64u : 0u)
 		  | (fin ? 0u : 128u);
+	/* bits 16..18: the phase a lane with this ray is in when a child pair is next (PH_NODE, or PH_NODE_SLOW for a degenerate ray) — walkAdvance sets it with one
+	 * shift instead of mask + compare + select after every node and triangle step */
+	k.oct |= ((k.oct & CRH_RAY_SLOW) ? 7u /* PH_NODE_SLOW */ : 1u /* PH_NODE */) << CRH_RAY_PHASE_SHIFT;
 	return k;
 }
 /* bvh.c:326-352; n0 = {minx,maxx,miny,maxy}, n1 = {minz,maxz,first,countLeaf}.
@@ -890,8 +894,10 @@ CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDis
 	return tMin <= tMax;
 }
 #define CRH_DNODE_FIRST(n1) asU32((n1).z)
+/* (the leaf flag is the SIGN bit of the device record's last word — one signed compare in the node step instead of mask + compare; scene_compile.cpp: relayoutBvh) */
+#define CRH_DNODE_LEAF_BIT 0x80000000u
 #define CRH_DNODE_COUNT(n1) (asU32((n1).w) & 0x3FFFFFFFu)
-#define CRH_DNODE_ISLEAF(n1) ((asU32((n1).w) >> 30) & 1u)
+#define CRH_DNODE_ISLEAF(n1) ((int32_t)asU32((n1).w) < 0)
 
 struct TravHit {
 	float t;           /* isect->distance */
@@ -925,6 +931,7 @@ struct TravHit {
  * three LDS words per lane they occupied until round 3 — 3 KB per workgroup — now hold the instance records, cray_hip.hip: CRH_INST_LDS0_MAX) */
 enum { PK_OX, PK_OY, PK_OZ, PK_DX, PK_DY, PK_DZ, PK_IX, PK_IY, PK_IZ, PK_OCT, PK_NODE, PK_PA, PK_PAE, PK_PB, PK_PBE, CRH_PARK_SLOTS };
 
+static_assert(true, "");   /* (PH_NODE = 1 and PH_NODE_SLOW = 7 are what makeRayK stores in the ray flag word: CRH_RAY_PHASE_SHIFT) */
 enum { PH_SETUP = 0, PH_NODE = 1, PH_TRI = 2, PH_CTRL = 3, PH_SHADE = 4, PH_DONE = 5, PH_IDLE = 6, PH_NODE_SLOW = 7 };   /* PH_NODE_SLOW: a node step for a degenerate ray (rare; served with the control steps) */   /* PH_IDLE: a worker lane without a ray (queue driver) */
 
 struct Walk {
@@ -995,7 +1002,7 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 			w.node = instRoot(inst);
 		}
 		if (w.pA != w.pAe) { w.phase = PH_TRI; return true; }
-		if (w.node != CRH_NONE) { w.phase = (w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE; return true; }
+		if (w.node != CRH_NONE) { w.phase = w.k.oct >> CRH_RAY_PHASE_SHIFT; return true; }
 		return false;                                                            /* single-leaf BLAS missed by the exit ray */
 	}
 	if (w.inBlas == BLAS_VOL_EXIT && found) {
@@ -1015,7 +1022,7 @@ template <class Stack, class Cnt, class Port>
 CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	if (w.pA != w.pAe) { w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
-	if (w.node != CRH_NONE) { w.phase = (w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE; return; }
+	if (w.node != CRH_NONE) { w.phase = w.k.oct >> CRH_RAY_PHASE_SHIFT; return; }
 	if (!w.inBlas) { w.phase = PH_SHADE; return; }                /* TLAS exhausted -> the walk is over */
 	if constexpr (cnt_traits<Cnt>::programs) {       /* volumes exist only in the rare-features instantiations (see CountersT) */
 		if (__builtin_expect(w.inBlas >= BLAS_VOL_ENTRY, 0)) { if (volumeAdvance(S, w, stk, cnt, port)) return; }
@@ -1034,7 +1041,7 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	w.spBase = 0;
 	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
 	if (w.node == CRH_NONE && w.sp > 0u) w.node = stk.pop(--w.sp);
-	w.phase = (w.node != CRH_NONE) ? ((w.k.oct & CRH_RAY_SLOW) ? PH_NODE_SLOW : PH_NODE) : PH_SHADE;
+	w.phase = (w.node != CRH_NONE) ? (w.k.oct >> CRH_RAY_PHASE_SHIFT) : PH_SHADE;
 }
 
 template <class Stack, class Cnt, class Port>

@@ -98,7 +98,7 @@ struct Compiler {
 					first = dev_base + 1 + n.first;
 				}
 				f4 a{n.bounds[0], n.bounds[1], n.bounds[2], n.bounds[3]};
-				f4 b{n.bounds[4], n.bounds[5], asF32(first), asF32((count & 0x3FFFFFFFu) | (leaf ? 0x40000000u : 0u))};
+				f4 b{n.bounds[4], n.bounds[5], asF32(first), asF32((count & 0x3FFFFFFFu) | (leaf ? CRH_DNODE_LEAF_BIT : 0u))};
 				out.nodes[(size_t)(dev_base + 1 + i) * 2] = a;
 				out.nodes[(size_t)(dev_base + 1 + i) * 2 + 1] = b;
 			}

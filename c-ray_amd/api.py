@@ -61,6 +61,7 @@ def library():
         "crh_framebuffer_clear": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int]),
         "crh_framebuffer_download": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
         "crh_framebuffer_to_srgb8": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+        "crh_framebuffer_strips_to_srgb8": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
         "crh_render_region": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.c_void_p]),
         "crh_render_tiles": (C.c_int, [ctx, C.POINTER(abi.RenderParams), C.POINTER(abi.Tile), C.c_uint32, C.c_void_p]),
         "crh_synchronize": (C.c_int, [ctx]),
@@ -242,6 +243,11 @@ class Context:
         last, total, n = C.c_float(), C.c_double(), C.c_uint64()
         _check(self.L.crh_kernel_time_ms(self.h, C.byref(last), C.byref(total), C.byref(n)), "crh_kernel_time_ms")
         return last.value, total.value, n.value
+
+    def strips_to_srgb8(self, fb, width, height, strip_rows, g, n_gpus, out):
+        """crh_framebuffer_strips_to_srgb8: the rows of GPU g's strips of the 8-bit frame into `out` (uint8 [height, width, 3]); the other rows stay as they are."""
+        _check(self.L.crh_framebuffer_strips_to_srgb8(self.h, fb, width, height, strip_rows, g, n_gpus, out.ctypes.data), "crh_framebuffer_strips_to_srgb8")
+        return out
 
     def last_kernel_name(self):
         """The instantiation of the path-tracing kernel launched last, as a profiler names it ("" before the first dispatch)."""

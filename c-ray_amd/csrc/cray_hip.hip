@@ -987,6 +987,39 @@ int crh_framebuffer_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int hei
 	return CRH_OK;
 }
 
+/* The same conversion for a GPU that owns every n-th strip of the frame (host/share.h): the whole frame is converted on the device (a few microseconds), but only the
+ * rows of strips g, g + n, g + 2 n, ... travel — one strided copy straight into the caller's frame-sized buffer, whose other rows are left alone. (Until round 4 a
+ * multi-GPU host downloaded the whole 8-bit frame from every GPU after every dispatch to keep 1 / n of it.) */
+int crh_framebuffer_strips_to_srgb8(crh_ctx *c, const float *dev_fb, int width, int height, int strip_rows, int g, int n_gpus, uint8_t *host_rgb8) {
+	if (!c || !dev_fb || !host_rgb8 || width <= 0 || height <= 0 || strip_rows <= 0 || n_gpus <= 0 || g < 0 || g >= n_gpus) return fail(CRH_ERR_INVALID, "crh_framebuffer_strips_to_srgb8: bad argument");
+	if (n_gpus == 1) return crh_framebuffer_to_srgb8(c, dev_fb, width, height, host_rgb8);
+	int rc = setDevice(c);
+	if (rc) return rc;
+	const size_t n = (size_t)width * height * 3, rowBytes = (size_t)width * 3;
+	if (n > c->srgbBytes) {
+		if (c->dSrgb) HIP_TRY(hipFree(c->dSrgb));
+		c->dSrgb = nullptr; c->srgbBytes = 0;
+		HIP_TRY(hipMalloc((void **)&c->dSrgb, n));
+		c->srgbBytes = n;
+	}
+	const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+	hipLaunchKernelGGL(k_to_srgb8, dim3(grid), dim3(256), 0, c->stream, dev_fb, n, c->dSrgb);
+	hipError_t e = hipGetLastError();
+	/* strip k of this GPU covers image rows [(k n + g) R, ... + R) = framebuffer rows [H - y1, H - y0) (texture.c:24-28: row H - 1 - y): the full strips are
+	 * R-row blocks a constant n R rows apart — one 2-D copy, from the block nearest the top of the buffer (the last full strip) downwards */
+	const int R = strip_rows, period = n_gpus * R;
+	int fullStrips = 0, raggedY0 = -1;
+	for (int y0 = g * R; y0 < height; y0 += period) { if (y0 + R <= height) ++fullStrips; else raggedY0 = y0; }
+	if (e == hipSuccess && fullStrips > 0) {
+		const size_t base = (size_t)(height - (g * R + (fullStrips - 1) * period) - R) * rowBytes;
+		e = hipMemcpy2DAsync(host_rgb8 + base, (size_t)period * rowBytes, c->dSrgb + base, (size_t)period * rowBytes, (size_t)R * rowBytes, (size_t)fullStrips, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess && raggedY0 >= 0) e = hipMemcpyAsync(host_rgb8, c->dSrgb, (size_t)(height - raggedY0) * rowBytes, hipMemcpyDeviceToHost, c->stream);      /* the frame's last, shorter strip: the buffer's first rows */
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_framebuffer_strips_to_srgb8: ") + hipGetErrorString(e));
+	return CRH_OK;
+}
+
 /* ---- work plan of one dispatch (host only, no device needed: crh_debug_plan_units runs it for the CPU tests) ------------------------- */
 struct PlanKnobs { int unitItems, unitsPerWave, tailPercent, tail2Percent, passChunk, cuCount, blocksPerCU; bool wg; int tailSplit; /* 0 unless the rolling kernel runs the plan */ };
 struct WorkPlan {

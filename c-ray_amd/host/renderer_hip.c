@@ -117,19 +117,10 @@ static uint32_t gpuShare(const struct renderer *r, int g, int G, crh_tile **out)
 	return crh_strip_share(W, H, g, G, t);
 }
 
-/* renderer.c:294-300 for this GPU's share: colorToSRGB + setPixel's truncation on the device, then its rows into `output` (texture.c:18-22
- * layout, the float buffer's). scratch (G > 1): a frame-sized byte buffer of this thread. */
-static int refreshOutput(crh_ctx *ctx, const float *fb, int W, int H, struct texture *output, const crh_tile *share, uint32_t n, int G, unsigned char *scratch) {
-	if (G == 1) return crh_framebuffer_to_srgb8(ctx, fb, W, H, output->data.byte_p);
-	if (!scratch) return CRH_OK;          /* no memory for this thread's preview copy: the preview of its strips is skipped, the frame is not affected */
-	const int rc = crh_framebuffer_to_srgb8(ctx, fb, W, H, scratch);
-	if (rc != CRH_OK) return rc;
-	for (uint32_t t = 0; t < n; ++t)
-		for (int y = share[t].y0; y < share[t].y1; ++y) {
-			const size_t row = ((size_t)(H - (y + 1)) * W + (size_t)share[t].x0) * 3;
-			memcpy(output->data.byte_p + row, scratch + row, 3 * (size_t)(share[t].x1 - share[t].x0));
-		}
-	return CRH_OK;
+/* renderer.c:294-300 for this GPU's share: colorToSRGB + setPixel's truncation on the device, then the rows of ITS strips into `output` (texture.c:18-22
+ * layout, the float buffer's) — one strided copy of 1 / G of the 8-bit frame (crh_framebuffer_strips_to_srgb8). */
+static int refreshOutput(crh_ctx *ctx, const float *fb, int W, int H, struct texture *output, int g, int G) {
+	return crh_framebuffer_strips_to_srgb8(ctx, fb, W, H, CRH_STRIP_ROWS, g, G, output->data.byte_p);
 }
 
 /* A throw-away dispatch ends a GPU's set-up: a few pixels, one pass, into the (still empty) framebuffer, which is cleared again. Measured in round 3
@@ -194,7 +185,6 @@ static void *gpuThread(void *arg) {
 	const uint32_t n = gpuShare(r, w->device, G, &share);
 	uint64_t pixels = 0;
 	for (uint32_t i = 0; i < n; ++i) pixels += (uint64_t)(share[i].x1 - share[i].x0) * (uint64_t)(share[i].y1 - share[i].y0);
-	unsigned char *scratch = G > 1 ? malloc((size_t)W * H * 3) : NULL;
 	w->state->currentTileNum = 0;
 	w->uploadUs = getUs(phase);
 	w->readyUs = getUs(w->frameStart);
@@ -224,7 +214,7 @@ static void *gpuThread(void *arg) {
 		w->state->totalSamples = pixels * (uint64_t)done;
 		if (done < r->prefs.sampleCount) {
 			/* more to come: show what there is, and size the next dispatch by what this one cost */
-			if (n && refreshOutput(w->ctx, w->fb, W, H, w->output, share, n, G, scratch) != CRH_OK) logr(warning, "GPU %d: preview: %s\n", w->device, crh_last_error());
+			if (n && refreshOutput(w->ctx, w->fb, W, H, w->output, w->device, G) != CRH_OK) logr(warning, "GPU %d: preview: %s\n", w->device, crh_last_error());
 			const double msPerPass = (double)us / 1e3 / (double)p.pass_count;
 			passes = msPerPass > 0.0 ? (int)(DISPATCH_TARGET_MS / msPerPass) : passes;
 			if (fixedPasses > 0) passes = fixedPasses;
@@ -237,7 +227,6 @@ static void *gpuThread(void *arg) {
 	if (!w->failed && crh_counters_get(w->ctx, &c) == CRH_OK) w->rays = c.rays;
 	{ float last = 0.0f; uint64_t launches = 0; if (!w->failed) crh_kernel_time_ms(w->ctx, &last, &w->kernelMs, &launches); }
 	free(share);
-	free(scratch);
 	gpuThreadDone(w);
 	return NULL;
 }
@@ -268,7 +257,6 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	float *fb[MAX_GPUS];
 	crh_tile *tiles[MAX_GPUS];
 	uint32_t ntiles[MAX_GPUS];
-	unsigned char *scratch = gpus > 1 ? malloc((size_t)W * H * 3) : NULL;
 	for (int g = 0; g < gpus; ++g) {
 		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
 			crh_set_option(ctx[g], CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
@@ -295,7 +283,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 			if (ntiles[g] && crh_render_tiles(ctx[g], &p, tiles[g], ntiles[g], fb[g]) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
 		/* the 8-bit frame of this chunk, converted where the float buffer lives (stream order: after the chunk's kernel) */
 		for (int g = 0; g < gpus; ++g)
-			if (ntiles[g] && refreshOutput(ctx[g], fb[g], W, H, output, tiles[g], ntiles[g], gpus, scratch) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
+			if (ntiles[g] && refreshOutput(ctx[g], fb[g], W, H, output, g, gpus) != CRH_OK) logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
 		const double chunkMs = (double)getUs(tc) / 1e3;
 		done += chunk;
 		++dispatches;
@@ -340,7 +328,6 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 		free(tiles[g]);
 		r->state.threadStates[g].threadComplete = true;
 	}
-	free(scratch);
 	return rays;
 }
 

@@ -350,6 +350,9 @@ int crh_framebuffer_clear(crh_ctx *ctx, float *dev_fb, int width, int height);
 int crh_framebuffer_download(crh_ctx *ctx, const float *dev_fb, int width, int height, float *host_rgb);
 /* colorToSRGB + setPixel's 8-bit truncation (color.h:60-84, texture.c:18-22) of the float buffer. */
 int crh_framebuffer_to_srgb8(crh_ctx *ctx, const float *dev_fb, int width, int height, uint8_t *host_rgb8);
+/* ... for a GPU that owns strips g, g + n_gpus, ... of strip_rows image rows each (a multi-GPU host's share of the frame: host/share.h): only those rows of the 8-bit frame
+ * are written into host_rgb8 (a full width x height x 3 buffer), the rest of it is left untouched. n_gpus = 1: the whole frame. */
+int crh_framebuffer_strips_to_srgb8(crh_ctx *ctx, const float *dev_fb, int width, int height, int strip_rows, int g, int n_gpus, uint8_t *host_rgb8);
 
 /* THE hot path: replaces the renderThread() pixel x pass loop for one region (renderer.c:275-301).
  * dev_fb is the device running-mean buffer; asynchronous on the context's stream. */

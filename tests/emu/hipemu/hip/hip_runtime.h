@@ -239,6 +239,7 @@ hipError_t hipHostFree(void *p);
 hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned flags);
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemset(void *dst, int value, size_t bytes);
 hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);

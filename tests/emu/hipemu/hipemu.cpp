@@ -310,6 +310,10 @@ hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p,
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { if (!dev) return hipErrorInvalidValue; *dev = host; return hipSuccess; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+	for (size_t r = 0; r < height; ++r) memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
+	return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind k, hipStream_t) { return hipMemcpy(dst, src, bytes, k); }
 hipError_t hipMemset(void *dst, int value, size_t bytes) { if (bytes) memset(dst, value, bytes); return hipSuccess; }
 hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t) { return hipMemset(dst, value, bytes); }

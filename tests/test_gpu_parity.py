@@ -457,6 +457,21 @@ def test_srgb8_matches_oracle(pkg, ctx, oracle, manifest, golden_blob):
     g8 = ctx.to_srgb8(fb, m["width"], m["height"]).astype(np.int32)
     o8 = oracle.to_srgb8(img).astype(np.int32)
     assert np.array_equal(g8, o8)                                      # same powf bits: same 8-bit values
+    # a multi-GPU host's previews: GPU g of n fetches only the rows of ITS 4-row strips (one strided copy); together they are the frame, and a GPU touches no other row
+    w, h = m["width"], m["height"]
+    full = ctx.to_srgb8(fb, w, h)
+    for n in (2, 3, 8):
+        frame = np.full((h, w, 3), 7, np.uint8)
+        for g in range(n):
+            before = frame.copy()
+            ctx.strips_to_srgb8(fb, w, h, 4, g, n, frame)
+            owned = np.zeros(h, bool)
+            for y0 in range(g * 4, h, n * 4):
+                owned[h - min(y0 + 4, h):h - y0] = True
+            assert np.array_equal(frame[owned], full[owned]) and np.array_equal(frame[~owned], before[~owned]), (n, g)
+        assert np.array_equal(frame, full), n
+    with pytest.raises(pkg.api.CrhError):
+        ctx.strips_to_srgb8(fb, w, h, 4, 2, 2, np.zeros((h, w, 3), np.uint8))
 
 
 def test_error_paths(pkg, ctx, golden_blob):

@@ -184,10 +184,10 @@ class Context:
         """crh_context_prepare: per-wave buffers + code objects before the scene is there (optional)."""
         _check(self.L.crh_context_prepare(self.h), "crh_context_prepare")
 
-    def set_sched(self, node, tri, ctrl, swap_min, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=0):
+    def set_sched(self, node, tri, ctrl, swap_min, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=0, swap_in_run=20):
         """shade_min = 0 keeps the library's tuned value (include/cray_hip.h: CRH_OPT_SCHED_RUNS)."""
         self.set_option(abi.OPT_SCHED_WEIGHTS, node | (tri << 12) | (ctrl << 24) | (swap_min << 36))
-        self.set_option(abi.OPT_SCHED_RUNS, fill_to | (run_num << 12) | (tri_in_run << 16) | (ctrl_in_run << 24) | (shade_min << 32))
+        self.set_option(abi.OPT_SCHED_RUNS, fill_to | (run_num << 12) | (tri_in_run << 16) | (ctrl_in_run << 24) | (shade_min << 32) | (swap_in_run << 40))
 
     def set_sched_wg(self, linger=8, drain_at=192, max_drainers=1, partial_min=16, walk_min=32, fill_to=768):
         """Scheduler of the workgroup kernel (CRH_OPT_KERNEL = KERNEL_WG), see cray_hip.hip: k_pathtrace_wg."""

@@ -248,6 +248,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
 struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, shadeMin;
                int sortFrom;        /* CRH_OPT_SHADE_SORT: hits are shaded in batches of few shade classes in scenes with at least this many classes; 0 = never (default) */
+               int swapInRun;       /* finished + idle lanes from which a node run retires / refills in place (CRH_OPT_SCHED_RUNS << 40; default 20, 65: never; dev env CRH_SWAP_IN_RUN) */
                int rayFlags;        /* CRH_OPT_RENDER_SLABS: CRH_RAY_LITERAL or 0, given to every walk of the dispatch */
                int roundLimit; };   /* CRH_OPT_ROUND_LIMIT: scheduling rounds after which a wave gives up and flags the dispatch incomplete (k_pathtrace_roll) */
 /* scheduler of the workgroup-cooperative form (pathtrace_alt.h; a plain struct, so that the context and crh_set_option do not depend on the build) */
@@ -460,7 +461,7 @@ struct crh_ctx {
 	int passChunk = 64;
 	int unitItems = 2048;
 	int unitsPerWave = 8;
-	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12, 48, 0, 0, 2000000000};
+	Sched sched = {70, 160, 120, 16, 160, 4, 12, 12, 48, 0, 20, 0, 2000000000};
 	int kernel = CRH_KERNEL_ROLL;            /* CRH_OPT_KERNEL */
 	SchedWg schedWg = {70, 160, 120, 16, 768, 4, 12, 12, 8, 192, 1, 16, 32};
 	uint32_t *dOvf = nullptr;                /* workgroup kernel: traversal-stack overflow columns */
@@ -732,6 +733,8 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 	}
 	const char *env = getenv("CRH_BLOCKS_PER_CU");
 	if (env && atoi(env) > 0) c->blocksPerCU = atoi(env);
+	env = getenv("CRH_SWAP_IN_RUN");              /* dev: A/B of the in-run retire / refill threshold */
+	if (env && atoi(env) >= 1 && atoi(env) <= 65) c->sched.swapInRun = atoi(env);
 	env = getenv("CRH_TAIL_SPLIT");                 /* dev: the default of CRH_OPT_TAIL_SPLIT for this process (A/B runs of unmodified hosts) */
 	if (env && atoi(env) >= 0 && atoi(env) <= 64) c->tailSplit = atoi(env);
 	*out = c;
@@ -788,11 +791,12 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			c->schedWg.wNode = k.wNode; c->schedWg.wTri = k.wTri; c->schedWg.wCtrl = k.wCtrl; c->schedWg.swapMin = k.swapMin;
 			return CRH_OK;
 		}
-		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 | ctrlInRun << 24 | shadeMin << 32 (0: keep) */
+		case CRH_OPT_SCHED_RUNS: {     /* fillTo | runNum << 12 | triInRun << 16 | ctrlInRun << 24 | shadeMin << 32 (0: keep) | swapInRun << 40 (0: keep) */
 			Sched k = c->sched;
 			k.fillTo = (int)(value & 0xFFF); k.runNum = (int)((value >> 12) & 0xF); k.triInRun = (int)((value >> 16) & 0xFF); k.ctrlInRun = (int)((value >> 24) & 0xFF);
 			if ((value >> 32) & 0xFF) k.shadeMin = (int)((value >> 32) & 0xFF);
-			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65 || k.ctrlInRun < 1 || k.ctrlInRun > 65 || k.shadeMin < 1 || k.shadeMin > 128) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
+			if ((value >> 40) & 0xFF) k.swapInRun = (int)((value >> 40) & 0xFF);
+			if (value < 0 || k.fillTo > 192 || k.runNum < 1 || k.runNum > 8 || k.triInRun < 1 || k.triInRun > 65 || k.ctrlInRun < 1 || k.ctrlInRun > 65 || k.shadeMin < 1 || k.shadeMin > 128 || k.swapInRun < 1 || k.swapInRun > 65) return fail(CRH_ERR_INVALID, "bad scheduler run parameters");
 			c->sched = k;
 			c->schedWg.runNum = k.runNum; c->schedWg.triInRun = k.triInRun; c->schedWg.ctrlInRun = k.ctrlInRun;
 			return CRH_OK;

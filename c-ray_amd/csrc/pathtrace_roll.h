@@ -152,6 +152,66 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	uint32_t myPath = 0;
 	/* a wave that has run K.roundLimit scheduling rounds without finishing gives up — never a hung GPU — and says so: the dispatch's error word (host-visible) makes
 	 * crh_synchronize / crh_framebuffer_download return CRH_ERR_HIP "incomplete frame" (the default limit is hours of one wave's work; CRH_OPT_ROUND_LIMIT) */
+	/* retire + refill (ST_SWAP; round 4: also inside node runs): lanes whose walk ended leave the result in their path's record and push its id on the hit or the miss stack;
+	 * they and the idle lanes pop ray ids and start those walks. rq / hq / mq: the ray, hit and miss stack levels, updated here and in LDS */
+	auto retireRefill = [&](int &rq, int &hq, int &mq) __attribute__((always_inline)) {
+		const bool fin = (w.phase == PH_SHADE);
+		const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
+		const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
+		uint32_t cls = 0;
+		if (fin) {
+			f4 *q = ptab + myPath * CRH_PATH_F4;
+			q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
+			if (finHit) {
+				q[5].x = asF32((uint32_t)w.hit.inst);
+				if (sorted) cls = (uint32_t)((volatile __attribute__((address_space(3))) uint8_t *)s_cls)[w.hit.inst];
+				hits[(uint32_t)hq + laneRank(hm)] = (uint16_t)(myPath | (cls << 8));
+			} else {
+				ids[CRH_ROLL_IDS_MISSES + (uint32_t)mq + laneRank(mm)] = (uint8_t)myPath;
+			}
+			w.phase = PH_IDLE;
+		}
+		if (sorted && hm) {
+			uint32_t addLo = 0, addHi = 0;
+#pragma unroll
+			for (uint32_t b = 0; b < 8u; ++b) {
+				const uint32_t nb = (uint32_t)__popcll(__ballot(finHit && cls == b));
+				if (b < 4u) addLo += nb << (8u * b); else addHi += nb << (8u * (b - 4u));
+			}
+			if (lane == 0) { wq[RQ_CLS_LO] = wq[RQ_CLS_LO] + (int)addLo; wq[RQ_CLS_HI] = wq[RQ_CLS_HI] + (int)addHi; }
+		}
+		const bool idle = (w.phase == PH_IDLE);
+		const unsigned long long em = __ballot(idle);
+		const uint32_t er = laneRank(em);
+		const int take = min(rq, (int)__popcll(em));
+#if CRH_ROLL_FIFO
+		/* oldest rays first (k_pathtrace pops the newest): the last paths of an older job must not wait under the rays of the
+		 * job being generated, or its fold — and with it its slot — is held up for that job's whole length. The remaining ids move
+		 * down to close the gap: every entry is read, then written (LDS operations of a wave execute in program order). */
+		uint32_t myRay = 0;
+		if (idle && (int)er < take) myRay = ids[CRH_IDS_RAYS + er];
+		{
+			uint32_t mv[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const uint32_t i = (uint32_t)take + (uint32_t)k * 64u + lane; mv[k] = (int)i < rq ? (uint32_t)ids[CRH_IDS_RAYS + i] : 0u; }
+			CRH_LOCKSTEP();
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const uint32_t i = (uint32_t)take + (uint32_t)k * 64u + lane; if ((int)i < rq) ids[CRH_IDS_RAYS + i - (uint32_t)take] = (uint8_t)mv[k]; }
+		}
+		if (idle && (int)er < take) {
+			myPath = myRay;
+#else
+		if (idle && (int)er < take) {
+			myPath = ids[CRH_IDS_RAYS + (uint32_t)(rq - take) + er];
+#endif
+			const f4 *q = ptab + myPath * CRH_PATH_F4;
+			const f4 q0 = q[0], q1 = q[1];
+			{ TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port2, (uint32_t)K.rayFlags); }
+		}
+		hq += (int)__popcll(hm); mq += (int)__popcll(mm); rq -= take;
+		if (lane == 0) { wq[RQ_HITS] = hq; wq[RQ_MISSES] = mq; wq[RQ_RAYS] = rq; }
+		__threadfence_block();
+	};
 	uint32_t guard = (uint32_t)K.roundLimit;
 	for (;;) {
 		if (--guard == 0u) { if (lane == 0) atomicOr(errFlag, CRH_ERRFLAG_ROUND_LIMIT); break; }
@@ -224,6 +284,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				 * path and their thresholds are the unfused loop's (round 3; git history); what changes is that a triangle step's memory round trip overlaps the node step's instead of
 				 * following it — and that a lane does ONE step per iteration: 5-10 % more iterations, each with one round trip instead of up to two. Measured (profiles/r04b_ab_*.log,
 				 * r04c_ab_kept.log): hdr.json +1.4...2.6 %, statues +0.2...0.9 %, 1 M soup +1.0 %, venus -0.9...-1.3 %; the share of a frame's last 2 ms does not move (r04d_probe_share8.log). */
+				int rqRun = raysQ, hqRun = hitsQ, mqRun = missQn;          /* the stack levels as this run's in-place retire / refill steps leave them */
 				f4 q0 = f4{0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;          /* (defined once per run: a lane reads only what it loaded in the same iteration, but an
 				                                                                                            * undefined value that meets a loaded one at every join costs the register allocator 70 spills) */
 				do {
@@ -254,6 +315,16 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 #endif
 						if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
 					}
+					/* retire + refill inside the run (round 4): once K.swapInRun lanes have ended their walk or sit idle with rays waiting — and the hit / miss stacks have room for
+					 * one more batch — they are served here instead of ending the run for it; the lanes that start a walk join the next iteration */
+					{
+						const int nFi = (int)__popcll(__ballot(w.phase == PH_SHADE)), nEi = (int)__popcll(__ballot(w.phase == PH_IDLE));
+						if (nFi + nEi >= K.swapInRun && (nFi > 0 || rqRun > 0) && hqRun < 64 && mqRun < 64) {
+							if constexpr (LEVEL >= 2) { if (lane == 0) { CRH_WCTR(21, 1); CRH_WCTR(23, nFi + min(nEi + nFi, rqRun)); } }
+							retireRefill(rqRun, hqRun, mqRun);
+							port = TablePort<SAMP>{ptab + myPath * CRH_PATH_F4};
+						}
+					}
 					now = __popcll(__ballot(w.phase == PH_NODE));
 					/* (the lanes this iteration's node step sent to a leaf are served at the top of the next one: enough of them keep the run going, as their in-place
 					 * triangle step — after which they counted as node lanes again — did before the steps were fused) */
@@ -274,61 +345,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port); }
 				break;
 			case ST_SWAP: {
-				const bool fin = (ph == PH_SHADE);
-				const bool finHit = fin && w.hit.inst >= 0, finMiss = fin && w.hit.inst < 0;
-				const unsigned long long hm = __ballot(finHit), mm = __ballot(finMiss);
-				uint32_t cls = 0;
-				if (fin) {
-					f4 *q = ptab + myPath * CRH_PATH_F4;
-					q[4] = f4{w.hit.t, w.hit.u, w.hit.v, asF32((uint32_t)w.hit.slot)};
-					if (finHit) {
-						q[5].x = asF32((uint32_t)w.hit.inst);
-						if (sorted) cls = (uint32_t)((volatile __attribute__((address_space(3))) uint8_t *)s_cls)[w.hit.inst];
-						hits[(uint32_t)hitsQ + laneRank(hm)] = (uint16_t)(myPath | (cls << 8));
-					} else {
-						ids[CRH_ROLL_IDS_MISSES + (uint32_t)missQn + laneRank(mm)] = (uint8_t)myPath;
-					}
-					w.phase = PH_IDLE;
-				}
-				if (sorted && hm) {
-					uint32_t addLo = 0, addHi = 0;
-#pragma unroll
-					for (uint32_t b = 0; b < 8u; ++b) {
-						const uint32_t nb = (uint32_t)__popcll(__ballot(finHit && cls == b));
-						if (b < 4u) addLo += nb << (8u * b); else addHi += nb << (8u * (b - 4u));
-					}
-					if (lane == 0) { wq[RQ_CLS_LO] = wq[RQ_CLS_LO] + (int)addLo; wq[RQ_CLS_HI] = wq[RQ_CLS_HI] + (int)addHi; }
-				}
-				const bool idle = (w.phase == PH_IDLE);
-				const unsigned long long em = __ballot(idle);
-				const uint32_t er = laneRank(em);
-				const int take = min(raysQ, (int)__popcll(em));
-#if CRH_ROLL_FIFO
-				/* oldest rays first (k_pathtrace pops the newest): the last paths of an older job must not wait under the rays of the
-				 * job being generated, or its fold — and with it its slot — is held up for that job's whole length. The remaining ids move
-				 * down to close the gap: every entry is read, then written (LDS operations of a wave execute in program order). */
-				uint32_t myRay = 0;
-				if (idle && (int)er < take) myRay = ids[CRH_IDS_RAYS + er];
-				{
-					uint32_t mv[4];
-#pragma unroll
-					for (int k = 0; k < 4; ++k) { const uint32_t i = (uint32_t)take + (uint32_t)k * 64u + lane; mv[k] = (int)i < raysQ ? (uint32_t)ids[CRH_IDS_RAYS + i] : 0u; }
-					CRH_LOCKSTEP();
-#pragma unroll
-					for (int k = 0; k < 4; ++k) { const uint32_t i = (uint32_t)take + (uint32_t)k * 64u + lane; if ((int)i < raysQ) ids[CRH_IDS_RAYS + i - (uint32_t)take] = (uint8_t)mv[k]; }
-				}
-				if (idle && (int)er < take) {
-					myPath = myRay;
-#else
-				if (idle && (int)er < take) {
-					myPath = ids[CRH_IDS_RAYS + (uint32_t)(raysQ - take) + er];
-#endif
-					const f4 *q = ptab + myPath * CRH_PATH_F4;
-					const f4 q0 = q[0], q1 = q[1];
-					{ TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port2, (uint32_t)K.rayFlags); }
-				}
-				if (lane == 0) { wq[RQ_HITS] = hitsQ + (int)__popcll(hm); wq[RQ_MISSES] = missQn + (int)__popcll(mm); wq[RQ_RAYS] = raysQ - take; }
-				__threadfence_block();
+				int rq = raysQ, hq = hitsQ, mq = missQn;
+				retireRefill(rq, hq, mq);
 				break;
 			}
 			case ST_OPEN: {          /* the next job: the following chunk of the youngest job's unit, or a new unit from the queue */

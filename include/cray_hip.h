@@ -277,7 +277,8 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * | m<<16: inside a node run, triangles are tested as soon as m lanes wait for them (default 12; 65 = never)
                                    * | k<<24: likewise instance entries / sphere tests (control steps), as soon as k lanes wait (default 12; 65 = never)
                                    * | s<<32: a shading step starts once 64 hits wait; in scenes with four or more shade classes (instances whose hits run
-                                   *          the same shading code) it takes whole classes, largest first, until at least s lanes are busy (1..128, default 48; 0 = keep) */
+                                   *          the same shading code) it takes whole classes, largest first, until at least s lanes are busy (1..128, default 48; 0 = keep)
+                                   * | r<<40: inside a node run, lanes whose walk has ended are retired and idle lanes refilled in place once r of them wait (round 4; default 20; 65 = never; 0 = keep) */
 #define CRH_OPT_UNITS_PER_WAVE 8  /* shrink the pixel blocks until every wave gets at least this many work units (default 8) */
 #define CRH_OPT_SAMPLER       9   /* which sampler seeds a (pixel, pass): CRH_SAMPLER_RANDOM = renderThread (sampler.c:41-44, default),
                                    * CRH_SAMPLER_HALTON = renderThreadInteractive (renderer.c:204: Halton index = pass + 1, halton.c:16-31) */

@@ -181,7 +181,7 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
     ctx.set_option(pkg.abi.OPT_UNIT_ITEMS, 1024)
     ctx.set_option(pkg.abi.OPT_PASS_CHUNK, 64)
     # wave scheduler: which step kind runs when changes nothing a path computes
-    for sched in ((1, 1, 1, 1, 0, 8, 65, 65), (400, 10, 10, 64, 64, 1, 1, 1), (10, 10, 400, 8, 192, 4, 20, 40)):
+    for sched in ((1, 1, 1, 1, 0, 8, 65, 65, 0, 65), (400, 10, 10, 64, 64, 1, 1, 1, 0, 1), (10, 10, 400, 8, 192, 4, 20, 40, 0, 7), (70, 160, 120, 16, 160, 4, 12, 12, 0, 64)):          # (the last field: retire / refill inside node runs)
         ctx.set_sched(*sched)
         ctx.clear(fb, w, h)
         ctx.render_region(fb, w, h, s, b)

@@ -51,6 +51,7 @@ for seed in range(lo, hi):
     cuts = sorted(set([0, s] + [rng.randrange(0, s + 1) for _ in range(rng.choice([0, 1, 2]))]))
     cfg["tiles"] = len(rects); cfg["pass_cuts"] = cuts
     cfg["tail_split"] = rng.choice([0, 1, 4, 64])          # (the rolling kernel's 64-path units at the end of the queue; pass segments of split pixels: tools/emu_fuzz_split.py)
+    cfg["swap_in_run"] = rng.choice([1, 4, 20, 33, 65])          # (drawn after everything else: the earlier fields of a seed stay what they were)
     os.environ["HIPEMU_CUS"] = str(cfg["cus"])
     pkg = load_package(); api, abi = pkg.api, pkg.abi
     t0 = time.time()
@@ -65,7 +66,7 @@ for seed in range(lo, hi):
     ctx.set_option(abi.OPT_UNIT_ITEMS, cfg["unit_items"]); ctx.set_option(abi.OPT_UNITS_PER_WAVE, cfg["units_per_wave"])
     ctx.set_option(abi.OPT_PASS_CHUNK, cfg["pass_chunk"]); ctx.set_option(abi.OPT_TAIL_PERCENT, cfg["tail"])
     ctx.set_sched(cfg["w_node"], cfg["w_tri"], cfg["w_ctrl"], cfg["swap_min"], fill_to=cfg["fill_to"], run_num=cfg["run_num"],
-                  tri_in_run=cfg["tri_in_run"], ctrl_in_run=cfg["ctrl_in_run"], shade_min=cfg["shade_min"])
+                  tri_in_run=cfg["tri_in_run"], ctrl_in_run=cfg["ctrl_in_run"], shade_min=cfg["shade_min"], swap_in_run=cfg["swap_in_run"])
     ctx.set_option(abi.OPT_SHADE_SORT, cfg["sort_from"])
     ctx.set_option(abi.OPT_TAIL_SPLIT, cfg["tail_split"])
     if cfg["kernel"] == 1:

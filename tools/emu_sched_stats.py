@@ -33,7 +33,7 @@ if "units_per_wave" in opts: ctx.set_option(abi.OPT_UNITS_PER_WAVE, int(opts["un
 if "pass_chunk" in opts: ctx.set_option(abi.OPT_PASS_CHUNK, int(opts["pass_chunk"]))
 if "kernel" in opts: ctx.set_option(abi.OPT_KERNEL, int(opts["kernel"]))        # 0 = one unit at a time, 1 = workgroup form, 2 = rolling units (the default)
 if "tail" in opts: ctx.set_option(abi.OPT_TAIL_PERCENT, int(opts["tail"]))
-sched = dict(node=70, tri=160, ctrl=120, swap_min=16, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=48)
+sched = dict(node=70, tri=160, ctrl=120, swap_min=16, fill_to=160, run_num=4, tri_in_run=12, ctrl_in_run=12, shade_min=48, swap_in_run=20)
 sched.update({k: int(v) for k, v in opts.items() if k in sched})
 ctx.set_sched(**sched)
 scene = api.Scene(path)

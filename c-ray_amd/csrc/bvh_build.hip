@@ -45,7 +45,9 @@ namespace crhb {
 #define CRH_BVH_BINS 32
 #define CRH_BVH_MAX_DEPTH 64u
 #define CRH_BVH_MAX_LEAF 16u
+#ifndef CRH_BVH_SMALL
 #define CRH_BVH_SMALL 512u          /* subtrees of at most this many primitives are built by one wave */
+#endif
 #define CRH_BVH_CHUNK 2048u         /* primitives per workgroup in the large phase */
 
 /* ---- order-independent folds with the reference's tie rule ----------------------------------------------------- */
@@ -236,6 +238,81 @@ __device__ inline Decision waveDecide(const BinKeys *bins, const uint32_t *cnts,
 		d.childR[2 * k] = split < CRH_BVH_BINS ? r.lo[k] : FLT_MAX; d.childR[2 * k + 1] = split < CRH_BVH_BINS ? r.hi[k] : -FLT_MAX;
 	}
 	return d;
+}
+
+/* ---- the decision of a TINY node (at most CRH_BVH_TINY = 8 primitives), lane-parallel (round 4) -------------------------------------------
+ * Seven in ten inner nodes of a subtree hold at most eight primitives (85 % at most sixteen), and waveDecide costs them what it costs the root: three scans over 32 bins that are almost all
+ * empty, behind a binning pass of 21 LDS atomics per primitive. For such a node the SAME outcome follows from the primitives directly:
+ *   - bvh.c:170-191's cost of split i (left = bins 0 .. i-1) changes only behind an OCCUPIED bin, and of equal costs the lowest i wins: the candidates are i = bin(p) + 1 of
+ *     the node's primitives p; a candidate whose right side is empty has the cost NaN (0 x the area of the empty box: inf), as in the sweeps, and loses;
+ *   - a cost needs the two sides' boxes only as VALUES (which zero of a -0 / +0 tie survives changes an extent by the sign of a zero at most, and no comparison sees that):
+ *     lane (side, axis, p) folds the boxes of its side of candidate (axis, p) over the node's primitives — 48 lanes, one pass per eight candidates;
+ *   - the two child boxes, whose BIT PATTERNS go into the tree, are folded with the keys the binning uses (keyLo / keyHi: on a tie the later operand wins), the sequence number
+ *     being (bin, position): the bins' own folds run in position order and bvh.c:226-233 folds the bins in ascending order.
+ * Returns false (every lane the same) when no candidate is valid — the caller then takes the wave-wide path, which also holds the reference's fallbacks for that case. */
+#ifndef CRH_BVH_TINY
+#define CRH_BVH_TINY 8u          /* 8 or 16 (with 16 the candidates of primitives 8 .. 15 take a second pass of the same 48 lanes). Measured on the 10 M soup (profiles/r04k_bvh_variants.log): 8 -> 21.6 ms, 16 -> 21.7 ms — a node of 9 .. 16 primitives is no cheaper in two passes than in the wave-wide path */
+#endif
+struct TinyPrim { float lo[3], hi[3]; uint32_t bin[3], pos, pad[2]; };
+__device__ inline bool tinyDecide(const TinyPrim *T, const float *bounds, uint32_t n, Decision *out) {
+	const uint32_t lane = threadIdx.x;
+	const uint32_t side = lane / 24u, rem = lane % 24u, a = rem >> 3;
+	float c = __builtin_inff();
+	uint32_t at = 0u;
+	for (uint32_t pBase = 0; pBase < n; pBase += 8u) {                    /* (n <= 8: one pass) */
+		const uint32_t p = pBase + (rem & 7u);
+		const bool act = lane < 48u && p < n;
+		const uint32_t myBin = act ? T[p].bin[a] : 0u;
+		float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		uint32_t cnt = 0;
+		for (uint32_t q = 0; q < n; ++q) {
+			const bool in = act && ((T[q].bin[a] <= myBin) == (side == 0u));
+			if (in) {
+				for (int k = 0; k < 3; ++k) { lo[k] = pickLo(lo[k], T[q].lo[k]); hi[k] = pickHi(hi[k], T[q].hi[k]); }
+				++cnt;
+			}
+		}
+		const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+		const float part = cnt * (ex * (ey + ez) + ey * ez);             /* bvh.c:176 / 187: count x half area (bbox.h:25-28) */
+		const float partR = __shfl(part, (int)((lane + 24u) & 63u), 64);
+		const float cost = part + partR;
+		/* the first split (axis-major, as bvh.c:195-197 prefers the lower axis on a tie, then the lowest bin) with the smallest cost below FLT_MAX */
+		const float c1 = (act && side == 0u && myBin <= 30u && cost < FLT_MAX) ? cost : __builtin_inff();
+		const uint32_t at1 = a * 32u + myBin;
+		if (c1 < c || (c1 == c && at1 < at)) { c = c1; at = at1; }
+	}
+	for (int off = 16; off > 0; off >>= 1) {
+		const float c2 = __shfl_xor(c, off, 64);
+		const uint32_t at2 = (uint32_t)__shfl_xor((int)at, off, 64);
+		if (c2 < c || (c2 == c && at2 < at)) { c = c2; at = at2; }
+	}
+	c = __shfl(c, 0, 64); at = (uint32_t)__shfl((int)at, 0, 64);
+	if (!(c < FLT_MAX)) return false;
+	const uint32_t ax = at >> 5, split = (at & 31u) + 1u;
+	Box self;
+	for (int k = 0; k < 3; ++k) { self.lo[k] = bounds[2 * k]; self.hi[k] = bounds[2 * k + 1]; }
+	const float leafCost = boxHalfArea(self) * (n - 1.5f);               /* bvh.c:200 */
+	if (c > leafCost) {                                                  /* bvh.c:212-214 (n <= CRH_BVH_MAX_LEAF): a leaf */
+		if (lane == 0) { out->leaf = 1; out->axis = ax; out->split = split; out->nLeft = 0; }
+		if (lane < 12u) { if (lane < 6u) out->childL[lane] = 0.0f; else out->childR[lane - 6u] = 0.0f; }
+		return true;
+	}
+	const uint32_t nLeft = (uint32_t)__popcll(__ballot(lane < n && T[lane < n ? lane : 0u].bin[ax] < split));
+	if (lane < 12u) {                                                    /* bvh.c:226-233: lane (child, bound) */
+		const uint32_t child = lane / 6u, k = lane % 6u, c3 = k >> 1;          /* bounds are {minx, maxx, miny, maxy, minz, maxz} */
+		const bool isLo = (k & 1u) == 0u;
+		unsigned long long best = isLo ? CRH_KEY_LO_EMPTY : CRH_KEY_HI_EMPTY;
+		for (uint32_t q = 0; q < n; ++q) {
+			if ((T[q].bin[ax] < split) != (child == 0u)) continue;
+			const uint32_t seq = (T[q].bin[ax] << 10) | T[q].pos;
+			const unsigned long long key = isLo ? keyLo(T[q].lo[c3], seq) : keyHi(T[q].hi[c3], seq);
+			if (isLo ? key < best : key > best) best = key;
+		}
+		const float v = keyValue(best);
+		if (child == 0u) out->childL[k] = v; else out->childR[k] = v;
+	}
+	if (lane == 0) { out->leaf = nLeft == 0u ? 1u : 0u; out->axis = ax; out->split = split; out->nLeft = nLeft; }
+	return true;
 }
 
 __device__ inline Box binBox(const BinKeys &k) {
@@ -506,7 +583,27 @@ __global__ __launch_bounds__(64) void k_small(const SmallRoot *roots, uint32_t n
 		float bounds[6];
 		for (int k = 0; k < 6; ++k) bounds[k] = j.bounds[k];
 		bool leaf = (j.depth >= CRH_BVH_MAX_DEPTH || n < 2);                 /* bvh.c:143-146 */
-		if (!leaf) {
+		bool decided = false;
+		if (!leaf && n <= CRH_BVH_TINY) {                                    /* tiny node: decided from its primitives directly (tinyDecide) */
+			TinyPrim *T = reinterpret_cast<TinyPrim *>(s_bins);
+			if (lane < n) {
+				const uint32_t q = first + lane;
+				const size_t at = (size_t)base + s_prim[q];
+				TinyPrim t;
+				for (int k = 0; k < 3; ++k) { t.lo[k] = boxes[6 * at + k]; t.hi[k] = boxes[6 * at + 3 + k]; t.bin[k] = binOf(centers[3 * at + k], bounds[2 * k], bounds[2 * k + 1]); }
+				t.pos = q; t.pad[0] = t.pad[1] = 0;
+				T[lane] = t;
+			}
+			__syncthreads();
+			decided = tinyDecide(T, bounds, n, &s_dec);
+			__syncthreads();
+			CRH_PROF(3);
+			if (decided) {
+				leaf = s_dec.leaf != 0;
+				if (!leaf && used + 2u > cap) { leaf = true; if (lane == 0) atomicOr(overflow, 1u); }
+			}
+		}
+		if (!leaf && !decided) {
 			for (uint32_t i = lane; i < 3 * CRH_BVH_BINS; i += 64) {
 				for (int c = 0; c < 3; ++c) { s_bins[i].lo[c] = CRH_KEY_LO_EMPTY; s_bins[i].hi[c] = CRH_KEY_HI_EMPTY; }
 				s_cnt[i] = 0;

@@ -732,7 +732,7 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 		return fail(CRH_ERR_HIP, msg);
 	}
 	const char *env = getenv("CRH_BLOCKS_PER_CU");
-	if (env && atoi(env) > 0) c->blocksPerCU = atoi(env);
+	if (env && atoi(env) > 0) c->blocksPerCU = atoi(env) > 8 ? 8 : atoi(env);          /* (1..8, like CRH_OPT_BLOCKS_PER_CU: the counter block is sized for 8) */
 	env = getenv("CRH_SWAP_IN_RUN");              /* dev: A/B of the in-run retire / refill threshold */
 	if (env && atoi(env) >= 1 && atoi(env) <= 65) c->sched.swapInRun = atoi(env);
 	env = getenv("CRH_TAIL_SPLIT");                 /* dev: the default of CRH_OPT_TAIL_SPLIT for this process (A/B runs of unmodified hosts) */

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -875,7 +876,22 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	std::string err;
 	const auto tUp0 = std::chrono::steady_clock::now();
 	auto upMs = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tUp0).count(); };
-	rc = compile_scene(scene, cs, err);
+	/* the texels — nine tenths of a textured scene's bytes, and the first thing the compiler finishes — are copied by a helper thread WHILE the BVHs and triangles are
+	 * prepared (round 4: traced in the drop-in, the pageable copies' DMA was still under way 21 ms after hipMemcpy had returned, in front of the first dispatch) */
+	struct TexelJob {                   /* joined, and its memory released unless the scene took it, on every way out of this function */
+		std::thread thread;
+		void *dev = nullptr;
+		hipError_t status = hipSuccess;
+		~TexelJob() { if (thread.joinable()) thread.join(); if (dev) (void)hipFree(dev); }
+	} texelJob;
+	rc = compile_scene(scene, cs, err, [&]() {
+		texelJob.thread = std::thread([&]() {
+			texelJob.status = hipSetDevice(c->device);
+			const size_t bytes = std::max<size_t>(cs.texels.size(), 1) * sizeof(f4);
+			if (texelJob.status == hipSuccess) texelJob.status = hipMalloc(&texelJob.dev, bytes);
+			if (texelJob.status == hipSuccess) texelJob.status = hipMemcpy(texelJob.dev, cs.texels.data(), cs.texels.size() * sizeof(f4), hipMemcpyHostToDevice);
+		});
+	});
 	if (rc != CRH_OK) return fail(rc, "crh_scene_upload: " + err);
 	const double tCompile = upMs();
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -906,7 +922,13 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(images, cs.images.data(), cs.images.size());
 	UP(prog, cs.prog.data(), cs.prog.size());
 	UP(textures, cs.textures.data(), cs.textures.size());
-	UP(texels, cs.texels.data(), cs.texels.size());
+	if (texelJob.thread.joinable()) {
+		texelJob.thread.join();
+		if (texelJob.status != hipSuccess) { freeScene(c); return fail(CRH_ERR_HIP, std::string("crh_scene_upload: texels: ") + hipGetErrorString(texelJob.status)); }
+		c->sceneAllocs.push_back(texelJob.dev);
+		d.texels = (const f4 *)texelJob.dev;
+		texelJob.dev = nullptr;
+	} else UP(texels, cs.texels.data(), cs.texels.size());
 #undef UP
 	d.tlas_first = cs.tlas_first;
 	d.material_count = (uint32_t)cs.materials.size(); d.bsdf_count = (uint32_t)cs.bsdfs.size(); d.const_count = (uint32_t)cs.consts.size();

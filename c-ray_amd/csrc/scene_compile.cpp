@@ -63,6 +63,7 @@ struct Compiler {
 	CompiledScene &out;
 	std::map<uint32_t, uint32_t> oprMemo;
 	std::vector<uint8_t> needUv;          /* per bsdf gnode: its graph reads the hit's uv */
+	std::function<void()> texelsReady;
 
 	Compiler(const crh_scene_desc *scene, CompiledScene &o) : s(scene), out(o) {}
 
@@ -350,6 +351,7 @@ struct Compiler {
 		}
 		if (out.textures.empty()) { DTexture d; memset(&d, 0, sizeof(d)); d.width = d.height = 1; out.textures.push_back(d); }
 		if (out.texels.empty()) out.texels.push_back(f4{0, 0, 0, 0});
+		if (texelsReady) texelsReady();
 
 		const double tTex = lap();
 		compileGraph();
@@ -555,10 +557,11 @@ struct Compiler {
 
 }  // namespace
 
-int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &err) {
+int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &err, const std::function<void()> &texelsReady) {
 	if (!scene) { err = "null scene"; return CRH_ERR_INVALID; }
 	try {
 		Compiler c(scene, out);
+		c.texelsReady = texelsReady;
 		c.run();
 		/* the kernels address a record as (array base) + a 32-BIT byte offset (pt_device.h: one scalar base, one vector offset per load): no device array of
 		 * 4 GB or more — 134 M BVH nodes, 89 M triangles, 67 M shading records, 268 M texels per scene */

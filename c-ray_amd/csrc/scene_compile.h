@@ -22,6 +22,7 @@
  */
 #pragma once
 #include <cstdlib>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -80,6 +81,8 @@ struct CompiledScene {
 };
 
 /* Returns CRH_OK or a negative CRH_ERR_* with a message in `err`. */
-int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &err);
+/* texelsReady (optional) is called — on the compiling thread — as soon as out.textures / out.texels are final, while the BVHs and triangles are still to be prepared: the
+ * uploader starts the copy of the texels (nine tenths of a textured scene's bytes) beside the rest of the compile. */
+int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &err, const std::function<void()> &texelsReady = std::function<void()>());
 
 }  // namespace crh

@@ -251,7 +251,10 @@ __device__ inline Decision waveDecide(const BinKeys *bins, const uint32_t *cnts,
  *     being (bin, position): the bins' own folds run in position order and bvh.c:226-233 folds the bins in ascending order.
  * Returns false (every lane the same) when no candidate is valid — the caller then takes the wave-wide path, which also holds the reference's fallbacks for that case. */
 #ifndef CRH_BVH_TINY
-#define CRH_BVH_TINY 8u          /* 8 or 16 (with 16 the candidates of primitives 8 .. 15 take a second pass of the same 48 lanes). Measured on the 10 M soup (profiles/r04k_bvh_variants.log): 8 -> 21.6 ms, 16 -> 21.7 ms — a node of 9 .. 16 primitives is no cheaper in two passes than in the wave-wide path */
+#define CRH_BVH_TINY 8u
+#ifndef CRH_BVH_FOLD_NODES
+#define CRH_BVH_FOLD_NODES 16u       /* levels of at most this many nodes fold per-chunk bin rows instead of flushing with global atomics */
+#endif          /* 8 or 16 (with 16 the candidates of primitives 8 .. 15 take a second pass of the same 48 lanes). Measured on the 10 M soup (profiles/r04k_bvh_variants.log): 8 -> 21.6 ms, 16 -> 21.7 ms — a node of 9 .. 16 primitives is no cheaper in two passes than in the wave-wide path */
 #endif
 struct TinyPrim { float lo[3], hi[3]; uint32_t bin[3], pos, pad[2]; };
 __device__ inline bool tinyDecide(const TinyPrim *T, const float *bounds, uint32_t n, Decision *out) {
@@ -362,7 +365,7 @@ __global__ void k_init_bins(BinKeys *bins, uint32_t *counts, uint32_t nBins) {
 
 /* (1) bins of every large node of the level: workgroup-private bins in LDS, flushed with one atomic per non-empty bin */
 __global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk *chunks, const int32_t *prims, const float *boxes, const float *centers,
-											 BinKeys *gbins, uint32_t *gcounts) {
+											 BinKeys *gbins, uint32_t *gcounts, BinKeys *pbins, uint32_t *pcounts) {
 	__shared__ BinKeys s_bins[3 * CRH_BVH_BINS];
 	__shared__ uint32_t s_cnt[3 * CRH_BVH_BINS];
 	const Chunk ch = chunks[blockIdx.x];
@@ -385,6 +388,11 @@ __global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < 3 * CRH_BVH_BINS; i += blockDim.x) {
 		const size_t g = (size_t)ch.node * 3 * CRH_BVH_BINS + i;
+		if (pbins) {                     /* a level of few, huge nodes: the chunk's bins go to its own row and k_fold_bins folds the rows (below) */
+			pbins[(size_t)blockIdx.x * 3 * CRH_BVH_BINS + i] = s_bins[i];
+			pcounts[(size_t)blockIdx.x * 3 * CRH_BVH_BINS + i] = s_cnt[i];
+			continue;
+		}
 		if (ch.single) {                 /* the node's only chunk: these ARE its bins (most nodes of the deep levels) — plain stores, no atomics */
 			gbins[g] = s_bins[i];
 			gcounts[g] = s_cnt[i];
@@ -394,6 +402,33 @@ __global__ __launch_bounds__(256) void k_bin(const LargeNode *nodes, const Chunk
 		for (int c = 0; c < 3; ++c) { atomicMin(&gbins[g].lo[c], s_bins[i].lo[c]); atomicMax(&gbins[g].hi[c], s_bins[i].hi[c]); }
 		atomicAdd(&gcounts[g], s_cnt[i]);
 	}
+}
+
+/* (1b) the top levels: thousands of chunks of ONE node flushing into the same 96 x 7 words serialise on device-scope atomics (level 1 of the 10 M soup took 1.0 ms where a
+ * middle level takes 0.55, round 4) — there every chunk stores its bins as a row and one block per (node, bin) folds that column. min / max of keys and a sum: any order. */
+__global__ __launch_bounds__(256) void k_fold_bins(const uint32_t *nodeChunk0, const BinKeys *pbins, const uint32_t *pcounts, BinKeys *gbins, uint32_t *gcounts) {
+	__shared__ BinKeys s_bin;
+	__shared__ uint32_t s_n;
+	const uint32_t node = blockIdx.x / (3 * CRH_BVH_BINS), i = blockIdx.x % (3 * CRH_BVH_BINS);
+	if (threadIdx.x == 0) { for (int c = 0; c < 3; ++c) { s_bin.lo[c] = CRH_KEY_LO_EMPTY; s_bin.hi[c] = CRH_KEY_HI_EMPTY; } s_n = 0; }
+	__syncthreads();
+	BinKeys mine;
+	for (int c = 0; c < 3; ++c) { mine.lo[c] = CRH_KEY_LO_EMPTY; mine.hi[c] = CRH_KEY_HI_EMPTY; }
+	uint32_t n = 0;
+	for (uint32_t ch = nodeChunk0[node] + threadIdx.x; ch < nodeChunk0[node + 1]; ch += blockDim.x) {
+		const size_t r = (size_t)ch * 3 * CRH_BVH_BINS + i;
+		const uint32_t k = pcounts[r];
+		if (!k) continue;
+		const BinKeys b = pbins[r];
+		for (int c = 0; c < 3; ++c) { mine.lo[c] = b.lo[c] < mine.lo[c] ? b.lo[c] : mine.lo[c]; mine.hi[c] = b.hi[c] > mine.hi[c] ? b.hi[c] : mine.hi[c]; }
+		n += k;
+	}
+	if (n) {
+		for (int c = 0; c < 3; ++c) { atomicMin(&s_bin.lo[c], mine.lo[c]); atomicMax(&s_bin.hi[c], mine.hi[c]); }
+		atomicAdd(&s_n, n);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { gbins[(size_t)node * 3 * CRH_BVH_BINS + i] = s_bin; gcounts[(size_t)node * 3 * CRH_BVH_BINS + i] = s_n; }
 }
 
 /* (2) one wave per node: lanes 0..2 sweep one axis each, lane 0 decides */
@@ -732,6 +767,10 @@ template <class T> struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; }
 	hipError_t alloc(size_t n) { release(); return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
 };
+struct DecisionEvent {             /* recorded behind a level's decisions: the host prepares the next level while the partition kernels run */
+	hipEvent_t e = nullptr;
+	~DecisionEvent() { if (e) (void)hipEventDestroy(e); }
+};
 #define BVH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return crh_internal_fail(CRH_ERR_HIP, (std::string("crh_bvh_build_triangles: ") + #expr + ": " + hipGetErrorString(e_)).c_str()); } while (0)
 }  // namespace
 
@@ -799,6 +838,9 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	auto tl = std::chrono::steady_clock::now();
 	DevBuf<LargeNode> dLevel; DevBuf<Chunk> dChunks; DevBuf<BinKeys> dBins; DevBuf<uint32_t> dCounts, dChunkML, dChunkMR, dNodeChunk0, dNodeSwaps; DevBuf<Decision> dDec;
 	size_t capNodes = 0, capChunks = 0;
+	DevBuf<BinKeys> dRowBins; DevBuf<uint32_t> dRowCounts;          /* per-chunk bin rows of the top levels (k_fold_bins) */
+	const size_t capRows = (size_t)N / CRH_BVH_CHUNK + CRH_BVH_FOLD_NODES + 1;
+	const uint32_t foldMinChunks = getenv("CRH_BVH_FOLD_MIN_CHUNKS") ? (uint32_t)atoi(getenv("CRH_BVH_FOLD_MIN_CHUNKS")) : 64u;          /* (tests: 1 sends small meshes through k_fold_bins) */
 	{	/* level scratch for the whole build at once (a level's nodes hold > CRH_BVH_SMALL primitives each, its chunks are whole or node tails):
 		 * growing it level by level put a hipFree + hipMalloc into every second level */
 		capNodes = (size_t)N / CRH_BVH_SMALL + 64;
@@ -808,47 +850,74 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 		BVH_TRY(dChunks.alloc(capChunks)); BVH_TRY(dChunkML.alloc(capChunks)); BVH_TRY(dChunkMR.alloc(capChunks));
 	}
 	const uint32_t chunkLen = CRH_BVH_CHUNK;      /* larger chunks for the top levels (fewer global-atomic flushes) were measured: slower from level 3 on */
+	/* A level's lists go up from, and its decisions come down into, page-locked memory of the context (round 4: the copies are asynchronous for real), and the decisions are
+	 * fetched right behind k_decide: the host routes the children and writes the next level's lists WHILE the four partition kernels of this level run — until then every level
+	 * ended with the device idle for a stream synchronisation, a loop over the level on the host, three staged copies and seven launches. */
+	DecisionEvent decided;
+	BVH_TRY(hipEventCreateWithFlags(&decided.e, hipEventDisableTiming));
+	LargeNode *hNodes = nullptr; Chunk *hChunks = nullptr; uint32_t *hChunk0 = nullptr; Decision *hDec = nullptr;
+	auto carveStaging = [&]() -> bool {
+		const size_t bytes = capNodes * (sizeof(LargeNode) + sizeof(Decision)) + capChunks * sizeof(Chunk) + (capNodes + 1) * sizeof(uint32_t) + 64;
+		char *base = (char *)crh_internal_pinned(ctx, bytes);
+		if (!base) return false;
+		hDec = (Decision *)base; base += capNodes * sizeof(Decision);
+		hNodes = (LargeNode *)base; base += capNodes * sizeof(LargeNode);
+		hChunks = (Chunk *)base; base += capChunks * sizeof(Chunk);
+		hChunk0 = (uint32_t *)base;
+		return true;
+	};
+	if (!carveStaging()) return crh_internal_fail(CRH_ERR_HIP, "crh_bvh_build_triangles: no page-locked host memory for the level lists");
 	while (!level.empty()) {
 		++levels;
 		const std::vector<uint32_t> cur = level;
 		level.clear();
 		const uint32_t nNodes = (uint32_t)cur.size();
-		std::vector<LargeNode> hNodes(nNodes);
-		std::vector<Chunk> hChunks;
-		std::vector<uint32_t> hChunk0(nNodes + 1);
+		size_t wantChunks = 0;
+		for (uint32_t i = 0; i < nNodes; ++i) wantChunks += (upper[cur[i]].end - upper[cur[i]].begin + chunkLen - 1) / chunkLen;
+		if (nNodes > capNodes || wantChunks > capChunks) {          /* (rare: chains of lopsided splits) the previous level's partition kernels still use the scratch */
+			BVH_TRY(hipStreamSynchronize(st));
+			if (nNodes > capNodes) {
+				capNodes = (size_t)nNodes * 2;
+				BVH_TRY(dLevel.alloc(capNodes)); BVH_TRY(dBins.alloc(capNodes * 3 * CRH_BVH_BINS)); BVH_TRY(dCounts.alloc(capNodes * 3 * CRH_BVH_BINS));
+				BVH_TRY(dDec.alloc(capNodes)); BVH_TRY(dNodeChunk0.alloc(capNodes + 1)); BVH_TRY(dNodeSwaps.alloc(capNodes));
+			}
+			if (wantChunks > capChunks) {
+				capChunks = wantChunks * 2;
+				BVH_TRY(dChunks.alloc(capChunks)); BVH_TRY(dChunkML.alloc(capChunks)); BVH_TRY(dChunkMR.alloc(capChunks));
+			}
+			if (!carveStaging()) return crh_internal_fail(CRH_ERR_HIP, "crh_bvh_build_triangles: no page-locked host memory for the level lists");
+		}
+		uint32_t nChunks = 0;
 		for (uint32_t i = 0; i < nNodes; ++i) {
 			const UpperNode &u = upper[cur[i]];
 			memcpy(hNodes[i].bounds, u.bounds, sizeof(u.bounds));
 			hNodes[i].begin = u.begin; hNodes[i].end = u.end;
-			hChunk0[i] = (uint32_t)hChunks.size();
-			for (uint32_t s = u.begin; s < u.end; s += chunkLen) hChunks.push_back(Chunk{i, s, std::min(chunkLen, u.end - s), u.end - u.begin <= chunkLen ? 1u : 0u});
+			hChunk0[i] = nChunks;
+			for (uint32_t s = u.begin; s < u.end; s += chunkLen) hChunks[nChunks++] = Chunk{i, s, std::min(chunkLen, u.end - s), u.end - u.begin <= chunkLen ? 1u : 0u};
 		}
-		hChunk0[nNodes] = (uint32_t)hChunks.size();
-		const uint32_t nChunks = (uint32_t)hChunks.size();
-		if (nNodes > capNodes) {
-			capNodes = (size_t)nNodes * 2;
-			BVH_TRY(dLevel.alloc(capNodes)); BVH_TRY(dBins.alloc(capNodes * 3 * CRH_BVH_BINS)); BVH_TRY(dCounts.alloc(capNodes * 3 * CRH_BVH_BINS));
-			BVH_TRY(dDec.alloc(capNodes)); BVH_TRY(dNodeChunk0.alloc(capNodes + 1)); BVH_TRY(dNodeSwaps.alloc(capNodes));
-		}
-		if (nChunks > capChunks) {
-			capChunks = (size_t)nChunks * 2;
-			BVH_TRY(dChunks.alloc(capChunks)); BVH_TRY(dChunkML.alloc(capChunks)); BVH_TRY(dChunkMR.alloc(capChunks));
-		}
-		BVH_TRY(hipMemcpyAsync(dLevel.p, hNodes.data(), nNodes * sizeof(LargeNode), hipMemcpyHostToDevice, st));
-		BVH_TRY(hipMemcpyAsync(dChunks.p, hChunks.data(), nChunks * sizeof(Chunk), hipMemcpyHostToDevice, st));
-		BVH_TRY(hipMemcpyAsync(dNodeChunk0.p, hChunk0.data(), (nNodes + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+		hChunk0[nNodes] = nChunks;
+		BVH_TRY(hipMemcpyAsync(dLevel.p, hNodes, nNodes * sizeof(LargeNode), hipMemcpyHostToDevice, st));
+		BVH_TRY(hipMemcpyAsync(dChunks.p, hChunks, nChunks * sizeof(Chunk), hipMemcpyHostToDevice, st));
+		BVH_TRY(hipMemcpyAsync(dNodeChunk0.p, hChunk0, (nNodes + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 		const uint32_t nBins = nNodes * 3 * CRH_BVH_BINS;
-		hipLaunchKernelGGL(k_init_bins, dim3((nBins + 255) / 256), dim3(256), 0, st, dBins.p, dCounts.p, nBins);
-		hipLaunchKernelGGL(k_bin, dim3(nChunks), dim3(256), 0, st, dLevel.p, dChunks.p, dPrims.p, dBoxes.p, dCenters.p, dBins.p, dCounts.p);
+		const bool foldRows = nNodes <= CRH_BVH_FOLD_NODES && nChunks >= foldMinChunks * nNodes && nChunks <= capRows;          /* few nodes of very many chunks each */
+		if (foldRows) {
+			if (!dRowBins.p) { BVH_TRY(dRowBins.alloc(capRows * 3 * CRH_BVH_BINS)); BVH_TRY(dRowCounts.alloc(capRows * 3 * CRH_BVH_BINS)); }
+			hipLaunchKernelGGL(k_bin, dim3(nChunks), dim3(256), 0, st, dLevel.p, dChunks.p, dPrims.p, dBoxes.p, dCenters.p, dBins.p, dCounts.p, dRowBins.p, dRowCounts.p);
+			hipLaunchKernelGGL(k_fold_bins, dim3(nBins), dim3(256), 0, st, dNodeChunk0.p, dRowBins.p, dRowCounts.p, dBins.p, dCounts.p);
+		} else {
+			hipLaunchKernelGGL(k_init_bins, dim3((nBins + 255) / 256), dim3(256), 0, st, dBins.p, dCounts.p, nBins);
+			hipLaunchKernelGGL(k_bin, dim3(nChunks), dim3(256), 0, st, dLevel.p, dChunks.p, dPrims.p, dBoxes.p, dCenters.p, dBins.p, dCounts.p, (BinKeys *)nullptr, (uint32_t *)nullptr);
+		}
 		hipLaunchKernelGGL(k_decide, dim3(nNodes), dim3(64), 0, st, dLevel.p, nNodes, dBins.p, dCounts.p, dDec.p);
+		BVH_TRY(hipMemcpyAsync(hDec, dDec.p, nNodes * sizeof(Decision), hipMemcpyDeviceToHost, st));
+		BVH_TRY(hipEventRecord(decided.e, st));
 		hipLaunchKernelGGL(k_count_misplaced, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dPrims.p, dCenters.p, dChunkML.p, dChunkMR.p);
 		hipLaunchKernelGGL(k_scan_chunks, dim3(nNodes), dim3(64), 0, st, dNodeChunk0.p, nNodes, dChunkML.p, dChunkMR.p, dNodeSwaps.p);
 		hipLaunchKernelGGL(k_list_misplaced, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dPrims.p, dCenters.p, dChunkML.p, dChunkMR.p, dListL.p, dListR.p);
 		hipLaunchKernelGGL(k_swap, dim3(nChunks), dim3(256), 0, st, dLevel.p, dDec.p, dChunks.p, dNodeSwaps.p, dListL.p, dListR.p, dPrims.p, dBoxes.p, dCenters.p);
 		BVH_TRY(hipGetLastError());
-		std::vector<Decision> hDec(nNodes);
-		BVH_TRY(hipMemcpyAsync(hDec.data(), dDec.p, nNodes * sizeof(Decision), hipMemcpyDeviceToHost, st));
-		BVH_TRY(hipStreamSynchronize(st));
+		BVH_TRY(hipEventSynchronize(decided.e));
 		for (uint32_t i = 0; i < nNodes; ++i) {
 			const uint32_t u = cur[i];
 			const Decision &d = hDec[i];
@@ -867,25 +936,31 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 		}
 		for (uint32_t u : level_leaves) route(u, true);
 		level_leaves.clear();
-		if (trace) { const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh level %u: %u nodes %u chunks %.3f ms\n", levels, nNodes, nChunks, std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
+		if (trace) { BVH_TRY(hipStreamSynchronize(st));          /* (tracing gives up the overlap: a level's time is all of its kernels) */
+			const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "bvh level %u: %u nodes %u chunks%s %.3f ms\n", levels, nNodes, nChunks, foldRows ? " (bin rows folded)" : "", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
 	}
 
 	/* small phase: one wave per subtree */
 	const uint32_t nRoots = (uint32_t)smallRoots.size();
 	DevBuf<SmallRoot> dRoots; DevBuf<uint32_t> dLocalCount, dRootId, dFirstId;
 	BVH_TRY(dLocal.alloc(localNodes)); BVH_TRY(dRoots.alloc(nRoots)); BVH_TRY(dLocalCount.alloc(nRoots)); BVH_TRY(dRootId.alloc(nRoots)); BVH_TRY(dFirstId.alloc(nRoots));
-	BVH_TRY(hipMemcpyAsync(dRoots.p, smallRoots.data(), nRoots * sizeof(SmallRoot), hipMemcpyHostToDevice, st));
+	/* (the level lists are dead: their copies ran before the last decisions came back) the same page-locked scratch carries the subtree roots, their node counts and their numbers */
+	char *const hSmall = (char *)crh_internal_pinned(ctx, (size_t)nRoots * (sizeof(SmallRoot) + 3 * sizeof(uint32_t)) + 64);
+	if (!hSmall) return crh_internal_fail(CRH_ERR_HIP, "crh_bvh_build_triangles: no page-locked host memory for the subtree lists");
+	uint32_t *const localCount = (uint32_t *)hSmall, *const rootId = localCount + nRoots, *const firstId = rootId + nRoots, *const overflowedWord = firstId + nRoots;
+	SmallRoot *const hRoots = (SmallRoot *)(hSmall + (((size_t)nRoots * 3 + 1) * sizeof(uint32_t) + 15u & ~(size_t)15u));
+	memcpy(hRoots, smallRoots.data(), nRoots * sizeof(SmallRoot));
+	BVH_TRY(hipMemcpyAsync(dRoots.p, hRoots, nRoots * sizeof(SmallRoot), hipMemcpyHostToDevice, st));
 	DevBuf<unsigned long long> dProf;
 	if (trace) { BVH_TRY(dProf.alloc(8)); BVH_TRY(hipMemsetAsync(dProf.p, 0, 8 * sizeof(unsigned long long), st)); }
 	DevBuf<uint32_t> dOverflow;
 	BVH_TRY(dOverflow.alloc(1)); BVH_TRY(hipMemsetAsync(dOverflow.p, 0, sizeof(uint32_t), st));
 	hipLaunchKernelGGL(k_small, dim3(nRoots), dim3(64), 0, st, dRoots.p, nRoots, dPrims.p, dBoxes.p, dCenters.p, dLocal.p, dLocalCount.p, trace ? dProf.p : nullptr, dOverflow.p);
 	BVH_TRY(hipGetLastError());
-	std::vector<uint32_t> localCount(nRoots);
-	uint32_t overflowed = 0;
-	BVH_TRY(hipMemcpyAsync(localCount.data(), dLocalCount.p, nRoots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	BVH_TRY(hipMemcpyAsync(&overflowed, dOverflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipMemcpyAsync(localCount, dLocalCount.p, nRoots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	BVH_TRY(hipMemcpyAsync(overflowedWord, dOverflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	BVH_TRY(hipStreamSynchronize(st));
+	const uint32_t overflowed = *overflowedWord;
 	static const char *const kNoReferenceTree = "crh_bvh_build_triangles: degenerate mesh — the reference's builder needs more than the 2 n - 1 nodes it allocates "
 		"(bvh.c:271; clusters of more than 16 coincident primitives are split into (all | none) down to the depth limit): no reference tree exists";
 	if (overflowed) return crh_internal_fail(CRH_ERR_UNSUPPORTED, kNoReferenceTree);
@@ -898,7 +973,6 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	}
 
 	/* numbering (bvh.c:221-223, 237-238): depth-first, a pair per split, left subtree before the right one */
-	std::vector<uint32_t> rootId(nRoots), firstId(nRoots);
 	uint32_t next = 1;
 	{
 		std::vector<uint32_t> stack{0u};
@@ -921,8 +995,8 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	}
 	const uint32_t nodeCount = next;
 	if ((size_t)nodeCount > 2 * (size_t)N - 1) return crh_internal_fail(CRH_ERR_UNSUPPORTED, kNoReferenceTree);      /* the same, with the chains in the upper tree */
-	BVH_TRY(hipMemcpyAsync(dRootId.p, rootId.data(), nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-	BVH_TRY(hipMemcpyAsync(dFirstId.p, firstId.data(), nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	BVH_TRY(hipMemcpyAsync(dRootId.p, rootId, nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	BVH_TRY(hipMemcpyAsync(dFirstId.p, firstId, nRoots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_emit, dim3(std::min<uint32_t>(nRoots, 65535u)), dim3(256), 0, st, dRoots.p, nRoots, dLocalCount.p, dRootId.p, dFirstId.p, dLocal.p, dNodes.p);
 	BVH_TRY(hipGetLastError());
 	BVH_TRY(hipStreamSynchronize(st));

@@ -454,6 +454,8 @@ __global__ void k_eval_math(int fn, const float *x, const float *y, uint64_t n, 
 /* ---- context ------------------------------------------------------------------------------------ */
 struct crh_ctx {
 	int device = 0;
+	void *pinned = nullptr;                  /* page-locked host scratch of the BVH builder (crh_internal_pinned) */
+	size_t pinnedBytes = 0;
 	hipStream_t stream = nullptr;
 	bool ownStream = false;
 	int cuCount = 0;
@@ -761,6 +763,7 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dQueues) (void)hipFree(c->dQueues);
 	if (c->dOvf) (void)hipFree(c->dOvf);
 	if (c->hErr) (void)hipHostFree(c->hErr);
+	if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->dSrgb) (void)hipFree(c->dSrgb);
 	if (c->dGather) (void)hipFree(c->dGather);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1643,6 +1646,15 @@ int crh_debug_eval_math(crh_ctx *c, int function, const float *x_host, const flo
 int crh_internal_device(crh_ctx *c) { return c->device; }
 void *crh_internal_stream(crh_ctx *c) { return (void *)c->stream; }
 int crh_internal_fail(int code, const char *message) { return fail(code, message); }
+void *crh_internal_pinned(crh_ctx *c, size_t bytes) {
+	if (bytes <= c->pinnedBytes) return c->pinned;
+	if (c->pinned) (void)hipHostFree(c->pinned);
+	c->pinned = nullptr; c->pinnedBytes = 0;
+	bytes = (bytes + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+	if (hipHostMalloc(&c->pinned, bytes, hipHostMallocDefault) != hipSuccess) { c->pinned = nullptr; return nullptr; }
+	c->pinnedBytes = bytes;
+	return c->pinned;
+}
 
 int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits_host) {
 	if (!c || (!rays_host && n) || (!hits_host && n)) return fail(CRH_ERR_INVALID, "crh_trace_rays: NULL argument");

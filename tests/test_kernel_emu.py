@@ -56,9 +56,9 @@ def children(emu_lib):
     env = dict(os.environ, CRH_LIB=emu_lib, CRH_ALLOW_EMULATION="1", CRH_DROPIN_LIBDIR=os.path.join(EMU_DIR, "_dropin_libs"), HIPEMU_CUS="2", HIPEMU_THREADS="3")
     procs = {}
 
-    def start(name, cmd):
+    def start(name, cmd, **more_env):
         out = tempfile.TemporaryFile(mode="w+")
-        procs[name] = (subprocess.Popen(cmd, env=env, cwd=REPO, stdout=out, stderr=subprocess.STDOUT, text=True), out)
+        procs[name] = (subprocess.Popen(cmd, env=dict(env, **more_env), cwd=REPO, stdout=out, stderr=subprocess.STDOUT, text=True), out)
 
     for name, (files, select, _) in GPU_TIER_JOBS.items():
         start(name, [sys.executable, "-m", "pytest", *[os.path.join(REPO, "tests", f) for f in files], "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select])
@@ -67,6 +67,8 @@ def children(emu_lib):
     start("fuzz", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:9"])
     start("fuzz_split", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_split.py"), "--seeds", "0:8"])
     start("fuzz_bvh", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:19"])
+    # the top levels' path (per-chunk bin rows + k_fold_bins instead of global atomics) is taken from 64 chunks per node on: CRH_BVH_FOLD_MIN_CHUNKS=1 sends these small meshes through it
+    start("fuzz_bvh_fold", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "20:33"], CRH_BVH_FOLD_MIN_CHUNKS="1")
     start("fuzz_rays", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_rays.py"), "--seeds", "0:6"])
 
     def finish(name, timeout=1700):
@@ -155,6 +157,15 @@ def test_bvh_builder_fuzz_on_emulation(children):
     rc, text = children("fuzz_bvh")
     assert rc == 0, text[-4000:]
     assert text.count('"ok": true') == 19 and '"refused": true' in text, text[-4000:]
+
+
+def test_bvh_builder_top_level_bin_rows_on_emulation(children):
+    """Levels of few, huge nodes (the top of a 10 M-triangle mesh) do not flush their chunks' bins into one node's words with global atomics: every chunk stores a row and
+    k_fold_bins folds the columns (bvh_build.hip, round 4). The GPU tier reaches that path with the 524 288-triangle stand-in and the soups; here the threshold is lowered
+    so that 13 seeded fuzz meshes take it at every level of at most 16 nodes: the reference's tree."""
+    rc, text = children("fuzz_bvh_fold")
+    assert rc == 0, text[-4000:]
+    assert text.count('"ok": true') == 13, text[-4000:]
 
 
 def test_one_unit_at_a_time_kernel_on_emulation(children):

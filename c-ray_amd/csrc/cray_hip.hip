@@ -28,6 +28,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -258,6 +261,7 @@ struct SchedWg { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrl
 /* bits of a context's error word (host-visible memory; a kernel ORs them in, crh_synchronize / crh_framebuffer_download report and clear them) */
 #define CRH_ERRFLAG_WG_WATCHDOG 1u
 #define CRH_ERRFLAG_ROUND_LIMIT 2u
+#define CRH_JANITOR_MIN_PATHS ((uint64_t)1 << 22)      /* a dispatch of at least this many paths (milliseconds of device time) hides the release of an upload's host arrays */
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -455,6 +459,14 @@ __global__ void k_eval_math(int fn, const float *x, const float *y, uint64_t n, 
 struct crh_ctx {
 	int device = 0;
 	void *pinned = nullptr;                  /* page-locked host scratch of the BVH builder (crh_internal_pinned) */
+	/* The last upload's compiled host arrays (150 MB of touched pages for hdr.json) are released by this thread, and only once a dispatch of some length is on the device
+	 * (or the next upload / the context's end asks for it): giving pages back takes 20 ms in a process that has the GPU open, and every launch or synchronisation of the
+	 * caller that falls into that time waits for it (round 4, profiles/r04q_*, r04r_*) — while the device traces a frame the host has nothing else to do. */
+	std::thread janitor;
+	std::mutex janitorMu;
+	std::condition_variable janitorCv;
+	bool janitorGo = false;
+	std::atomic<bool> janitorWaiting{false};
 	size_t pinnedBytes = 0;
 	hipStream_t stream = nullptr;
 	bool ownStream = false;
@@ -744,6 +756,15 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 	return CRH_OK;
 }
 
+/* lets the janitor thread (see crh_ctx) go; join: the caller needs it gone (next upload, end of the context) */
+static void releaseJanitor(crh_ctx *c, bool join) {
+	if (c->janitorWaiting.exchange(false)) {
+		{ std::lock_guard<std::mutex> lk(c->janitorMu); c->janitorGo = true; }
+		c->janitorCv.notify_one();
+	}
+	if (join && c->janitor.joinable()) c->janitor.join();
+}
+
 int crh_context_destroy(crh_ctx *c) {
 	if (!c) return CRH_OK;
 	(void)hipSetDevice(c->device);
@@ -764,6 +785,7 @@ int crh_context_destroy(crh_ctx *c) {
 	if (c->dOvf) (void)hipFree(c->dOvf);
 	if (c->hErr) (void)hipHostFree(c->hErr);
 	if (c->pinned) (void)hipHostFree(c->pinned);
+	releaseJanitor(c, true);
 	if (c->dSrgb) (void)hipFree(c->dSrgb);
 	if (c->dGather) (void)hipFree(c->dGather);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -875,7 +897,8 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	if (!c || !scene) return fail(CRH_ERR_INVALID, "crh_scene_upload: NULL argument");
 	int rc = setDevice(c);
 	if (rc) return rc;
-	CompiledScene cs;
+	std::unique_ptr<CompiledScene> compiled(new CompiledScene);
+	CompiledScene &cs = *compiled;
 	std::string err;
 	const auto tUp0 = std::chrono::steady_clock::now();
 	auto upMs = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tUp0).count(); };
@@ -955,6 +978,14 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	if (getenv("CRH_TRACE_UPLOAD"))         /* dev: where crh_scene_upload's time goes */
 		fprintf(stderr, "crh_scene_upload trace: layout compile %.1f ms, allocations + copies %.1f ms (%.1f MB), code object + barrier %.1f ms\n", tCompile, tCopies - tCompile,
 				(double)(cs.nodes.size() * 16 + cs.tris.size() * 16 + cs.shade.size() * sizeof(DShadeTri) + cs.texels.size() * 16) / 1e6, upMs() - tCopies);
+	releaseJanitor(c, true);
+	CompiledScene *const trash = compiled.release();
+	c->janitorGo = false;
+	c->janitorWaiting.store(true);
+	c->janitor = std::thread([c, trash]() {
+		{ std::unique_lock<std::mutex> lk(c->janitorMu); c->janitorCv.wait(lk, [c]() { return c->janitorGo; }); }
+		delete trash;
+	});
 	return CRH_OK;
 }
 
@@ -1367,6 +1398,11 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	ts.inFlight = true;
 	c->pendingTimes.push_back(ev);
 	c->launches++;
+	if (c->janitorWaiting.load(std::memory_order_relaxed)) {          /* a dispatch of some length is on the device: the host memory of the last upload can go back now */
+		uint64_t paths = 0;
+		for (const crh_tile &t : work) paths += (uint64_t)(t.x1 - t.x0) * (uint64_t)(t.y1 - t.y0);
+		if (paths * (uint64_t)P->pass_count >= CRH_JANITOR_MIN_PATHS) releaseJanitor(c, false);
+	}
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_pathtrace launch: ") + hipGetErrorString(e));
 	return CRH_OK;
 }

@@ -343,7 +343,7 @@ def dropin_timing(workload):
         if proc.returncode != 0 or not os.path.exists(stats):
             return {"failed": proc.stdout.decode(errors="replace")[-300:]}
         st = json.load(open(stats))
-        if os.environ.get("CRH_TRACE_SYNC"):            # dev: the library's launch / synchronize trace lines of the child
+        if os.environ.get("CRH_TRACE_SYNC") or os.environ.get("CRH_TRACE_UPLOAD"):            # dev: the library's launch / synchronize / upload trace lines of the child
             st["trace"] = [l for l in proc.stdout.decode(errors="replace").splitlines() if "trace" in l]
     phase = st.get("render_phase_ms", st["render_ms"])
     return {"program": "c-ray_amd/_lib/c-ray-hip < hdr.json (1 GPU)",
@@ -351,10 +351,11 @@ def dropin_timing(workload):
             "mrays_over_frame_ms": round(st["rays"] / st["frame_ms"] / 1e3, 1) if st.get("frame_ms") else None,
             "render_ms": st["render_ms"], "kernel_ms": st.get("kernel_ms"), "dispatches": st.get("dispatches"), "launch_host_ms": st.get("launch_host_ms"),
             "resolve_srgb_ms": st["resolve_srgb_ms"], "download_ms": st.get("download_ms"), "gather_ms": st.get("gather_ms"),
-            "frame_ms": st.get("frame_ms"), "setup_ms": st.get("setup_ms"), "flatten_ms": st["flatten_ms"], "context_ms": st.get("context_ms"),
+            "frame_ms": st.get("frame_ms"), "teardown_ms": st.get("teardown_ms"), "setup_ms": st.get("setup_ms"), "flatten_ms": st["flatten_ms"], "context_ms": st.get("context_ms"),
             "upload_ms": st.get("upload_ms"), "process_wall_s": round(wall, 2), "rays": st["rays"],
             "phase_vs_kernel": round(phase / st["kernel_ms"], 4) if st.get("kernel_ms") else None, **({"trace": st["trace"]} if st.get("trace") else {}),
-            "note": "render_phase_ms = SURVEY 8(d)'s phase: the timer of src/c-ray.c:279-281 around renderFrame() (frame_ms) minus the set-up (setup_ms: everything "
+            "note": "render_phase_ms = SURVEY 8(d)'s phase: the timer of src/c-ray.c:279-281 around renderFrame() (frame_ms: ALL of it, since round 4 the teardown too — teardown_ms: the contexts, "
+                    "the framebuffers) minus the set-up and the teardown (setup_ms: everything "
                     "before the GPU was ready to dispatch — context + code objects + per-wave buffers, which run beside the flattener, then the scene upload); it holds "
                     "the dispatch (render_ms; kernel_ms = its GPU time), the 8-bit conversion on the device + its download (resolve_srgb_ms), the float "
                     "buffer's download and the host in between; mrays = rays / render_phase_ms. mrays_over_frame_ms = rays / frame_ms: the rate over what the REFERENCE's own "

@@ -1401,7 +1401,8 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (c->janitorWaiting.load(std::memory_order_relaxed)) {          /* a dispatch of some length is on the device: the host memory of the last upload can go back now */
 		uint64_t paths = 0;
 		for (const crh_tile &t : work) paths += (uint64_t)(t.x1 - t.x0) * (uint64_t)(t.y1 - t.y0);
-		if (paths * (uint64_t)P->pass_count >= CRH_JANITOR_MIN_PATHS) releaseJanitor(c, false);
+		static const uint64_t minPaths = getenv("CRH_JANITOR_MIN_PATHS") ? strtoull(getenv("CRH_JANITOR_MIN_PATHS"), nullptr, 10) : CRH_JANITOR_MIN_PATHS;      /* (tests: 1 = at the first dispatch) */
+		if (paths * (uint64_t)P->pass_count >= minPaths) releaseJanitor(c, false);
 	}
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_pathtrace launch: ") + hipGetErrorString(e));
 	return CRH_OK;

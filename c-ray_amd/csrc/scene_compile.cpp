@@ -310,6 +310,14 @@ struct Compiler {
 		CHECK(s->camera.width > 0 && s->camera.height > 0, CRH_ERR_INVALID, "camera has no image size");
 		out.camera = s->camera;
 
+		{	/* the totals first: the big arrays are allocated once (PodBuf: huge pages; growth would copy) */
+			uint64_t texelTotal = 0, nodeTotal = 4;
+			for (uint64_t t = 0; t < s->texture_count; ++t) texelTotal += (uint64_t)s->textures[t].width * s->textures[t].height;
+			for (uint64_t m = 0; m < s->mesh_count; ++m) nodeTotal += ((uint64_t)s->meshes[m].node_count + 3) * 2;
+			nodeTotal += ((uint64_t)s->tlas_node_count + 3) * 2;
+			if (texelTotal < 0xFFFFFFFFull) out.texels.reserve((size_t)std::max<uint64_t>(texelTotal, 1));
+			if (nodeTotal < 0xFFFFFFFFull) out.nodes.reserve((size_t)nodeTotal);
+		}
 		for (uint64_t t = 0; t < s->texture_count; ++t) {
 			const crh_texture &tx = s->textures[t];
 			CHECK(tx.width > 0 && tx.height > 0 && (tx.channels == 1 || tx.channels == 3 || tx.channels == 4), CRH_ERR_INVALID, "texture %llu has a bad shape", (unsigned long long)t);

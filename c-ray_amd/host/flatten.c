@@ -9,6 +9,8 @@
  * indices are bit-exact by construction. mesh->rayOffset / sphere->rayOffset are read here, i.e.
  * AFTER the TLAS build wrote them (instance.c:106,227).
  */
+#include <sys/mman.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -76,6 +78,33 @@ struct flat {
 	int error;
 };
 
+/* The big arrays of a flattened scene (BVH nodes, polygons, texture bytes: 70 MB for hdr.json) come as zero pages straight from mmap, on 2 MB boundaries, with
+ * transparent huge pages asked for: written first touch by first touch by one thread, 4 KB pages cost 17 000 page faults — more than the copying (round 4; the same
+ * finding as for the layout compile, scene_compile.h: PodBuf). A 64-byte header in front of the block tells big_free how to let it go. */
+#define BIG_FROM ((size_t)4 << 20)
+#define BIG_PAGE ((size_t)2 << 20)
+#define BIG_MAGIC 0x4352482d42494721ull
+struct big_hdr { uint64_t magic; void *map; size_t span; char pad[40]; };
+static void *big_zalloc(size_t bytes) {
+	if (bytes < BIG_FROM) return calloc(bytes ? bytes : 1, 1);
+	const size_t span = ((bytes + BIG_PAGE - 1) & ~(BIG_PAGE - 1)) + BIG_PAGE;
+	char *map = mmap(NULL, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (map == MAP_FAILED) return calloc(bytes, 1);
+	char *data = (char *)(((uintptr_t)map + sizeof(struct big_hdr) + BIG_PAGE - 1) & ~(uintptr_t)(BIG_PAGE - 1));
+	(void)madvise(data, span - (size_t)(data - map), MADV_HUGEPAGE);
+	struct big_hdr *h = (struct big_hdr *)(data - sizeof(struct big_hdr));
+	h->magic = BIG_MAGIC; h->map = map; h->span = span;
+	return data;
+}
+static void big_free(const void *p) {
+	if (!p) return;
+	if (((uintptr_t)p & (BIG_PAGE - 1)) == 0) {          /* (malloc never returns a 2 MB-aligned pointer for the sizes that stay below BIG_FROM: its own header sits in front) */
+		const struct big_hdr *h = (const struct big_hdr *)((const char *)p - sizeof(struct big_hdr));
+		if (h->magic == BIG_MAGIC) { munmap(h->map, h->span); return; }
+	}
+	free((void *)p);
+}
+
 static uint32_t add_texture(struct flat *f, const struct texture *t) {
 	if (!t) return CRH_NODE_NONE;
 	uint32_t idx;
@@ -89,7 +118,10 @@ static uint32_t add_texture(struct flat *f, const struct texture *t) {
 	size_t off = (f->texbytes + 15) & ~(size_t)15;
 	if (off + bytes > f->texcap) {
 		f->texcap = (off + bytes) * 2;
-		f->texdata = realloc(f->texdata, f->texcap);
+		uint8_t *grown = big_zalloc(f->texcap);
+		if (f->texbytes) memcpy(grown, f->texdata, f->texbytes);
+		big_free(f->texdata);
+		f->texdata = grown;
 	}
 	memset(f->texdata + f->texbytes, 0, off - f->texbytes);
 	memcpy(f->texdata + off, t->data.byte_p, bytes);
@@ -178,9 +210,9 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 		totalPolys += (size_t)w->meshes[m].polyCount;
 		totalMats += (size_t)w->meshes[m].materialCount;
 	}
-	crh_bvh_node *nodes = calloc(totalNodes ? totalNodes : 1, sizeof(*nodes));
-	int32_t *prims = calloc(totalPrims ? totalPrims : 1, sizeof(*prims));
-	crh_poly *polys = calloc(totalPolys ? totalPolys : 1, sizeof(*polys));
+	crh_bvh_node *nodes = big_zalloc((totalNodes ? totalNodes : 1) * sizeof(*nodes));
+	int32_t *prims = big_zalloc((totalPrims ? totalPrims : 1) * sizeof(*prims));
+	crh_poly *polys = big_zalloc((totalPolys ? totalPolys : 1) * sizeof(*polys));
 	crh_mesh *meshes = calloc(w->meshCount ? w->meshCount : 1, sizeof(*meshes));
 	crh_sphere *spheres = calloc(w->sphereCount ? w->sphereCount : 1, sizeof(*spheres));
 	crh_material *materials = calloc(totalMats ? totalMats : 1, sizeof(*materials));
@@ -251,9 +283,9 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 
 	/* --- global vertex buffers; slots no polygon references are zeroed (the loader over-allocates:
 	 * wavefront.c:148 counts every line starting with 'v') so the blob is deterministic --- */
-	float *verts = calloc((size_t)(vertexCount > 0 ? vertexCount : 1) * 3, sizeof(float));
-	float *norms = calloc((size_t)(normalCount > 0 ? normalCount : 1) * 3, sizeof(float));
-	float *texs = calloc((size_t)(textureCount > 0 ? textureCount : 1) * 2, sizeof(float));
+	float *verts = big_zalloc((size_t)(vertexCount > 0 ? vertexCount : 1) * 3 * sizeof(float));
+	float *norms = big_zalloc((size_t)(normalCount > 0 ? normalCount : 1) * 3 * sizeof(float));
+	float *texs = big_zalloc((size_t)(textureCount > 0 ? textureCount : 1) * 2 * sizeof(float));
 	for (size_t p = 0; p < polyAt; ++p) {
 		for (int k = 0; k < 3; ++k) {
 			int vi = polys[p].v[k], ni = polys[p].n[k], ti = polys[p].t[k];
@@ -295,11 +327,11 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 
 void crh_flatten_free(crh_scene_desc *d) {
 	if (!d) return;
-	free((void *)d->nodes); free((void *)d->prim_indices); free((void *)d->polys);
-	free((void *)d->vertices); free((void *)d->normals); free((void *)d->texcoords);
+	big_free(d->nodes); big_free(d->prim_indices); big_free(d->polys);
+	big_free(d->vertices); big_free(d->normals); big_free(d->texcoords);
 	free((void *)d->instances); free((void *)d->meshes); free((void *)d->spheres);
 	free((void *)d->materials); free((void *)d->gnodes); free((void *)d->textures);
-	free((void *)d->texture_data);
+	big_free(d->texture_data);
 	memset(d, 0, sizeof(*d));
 }
 

@@ -70,6 +70,7 @@ struct frameSync {
 	pthread_cond_t cv;
 	int sceneReady;          /* 1: flattened, -1: the flattener failed */
 	int finished;
+	int launched;            /* GPU threads whose first dispatch is on its device (or that ended before one): the flattened scene has been read for the last time */
 };
 
 struct gpuWorker {
@@ -85,6 +86,7 @@ struct gpuWorker {
 	int failed;
 	char error[256];      /* crh_last_error() is per thread: the failing dispatch thread keeps its message here */
 	uint64_t rays;
+	int announced;                        /* sync->launched counts this thread */
 	long contextUs, uploadUs, renderUs;   /* context + buffers + code objects (beside the flattener); scene upload + framebuffer; dispatch loop (first launch to last sync) */
 	long readyUs;             /* renderFrame() entry -> this GPU ready to dispatch */
 	double kernelMs;          /* GPU time of the dispatches (HIP events around the kernels) */
@@ -136,7 +138,95 @@ static void warmUp(crh_ctx *ctx, float *fb, const crh_render_params *p, int devi
 		logr(warning, "GPU %d: warm-up dispatch: %s\n", device, crh_last_error());
 }
 
+/* ---- the process's render contexts ------------------------------------------------------------------------------------------------------------
+ * A context ready to dispatch — stream, counters, code objects, 600 MB of per-wave buffers — takes 13-30 ms to make (round 4, CRH_TRACE_UPLOAD: 8 ms until it
+ * exists, 5-21 ms until crh_context_prepare returns) and 5 ms to take down, and none of it depends on the scene. GPU 0's is therefore made by a thread that
+ * newRenderer() starts — the program then spends hundreds of milliseconds parsing JSON and OBJ files — and a frame's contexts go back to this pool instead of being
+ * destroyed inside renderFrame(); destroyRenderer() ends them. (The other GPUs' contexts are made by their dispatch threads beside the flattener, as before: how
+ * many GPUs the scene file asks for is not known when the program starts.) CRH_DROPIN_NO_PREFETCH=1: every context is made inside renderFrame(). */
+static struct {
+	pthread_mutex_t mu;
+	crh_ctx *ctx[MAX_GPUS];
+	pthread_t thread;
+	int threadLive;
+} g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER};
+
+static crh_ctx *makeContext(int device) {
+	crh_ctx *c = NULL;
+	/* counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
+	if (crh_context_create(device, NULL, &c) != CRH_OK) return NULL;
+	if (crh_set_option(c, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || (!getenv("CRH_DROPIN_NO_PREPARE") && crh_context_prepare(c) != CRH_OK)) {
+		crh_context_destroy(c);
+		return NULL;
+	}
+	return c;
+}
+
+static void *prefetchThread(void *arg) {
+	(void)arg;
+	crh_ctx *c = makeContext(0);
+	pthread_mutex_lock(&g_pool.mu);
+	g_pool.ctx[0] = c;
+	pthread_mutex_unlock(&g_pool.mu);
+	return NULL;
+}
+
+static void poolPrefetch(void) {
+	if (getenv("CRH_DROPIN_NO_PREFETCH")) return;
+	pthread_mutex_lock(&g_pool.mu);
+	if (!g_pool.threadLive && !g_pool.ctx[0] && pthread_create(&g_pool.thread, NULL, prefetchThread, NULL) == 0) g_pool.threadLive = 1;
+	pthread_mutex_unlock(&g_pool.mu);
+}
+
+static void poolJoin(void) {
+	pthread_mutex_lock(&g_pool.mu);
+	const int live = g_pool.threadLive;
+	g_pool.threadLive = 0;
+	pthread_mutex_unlock(&g_pool.mu);
+	if (live) pthread_join(g_pool.thread, NULL);
+}
+
+/* a context for `device`, ready to dispatch: the pool's, or a new one (NULL: crh_last_error() of the calling thread says why) */
+static crh_ctx *poolAcquire(int device) {
+	if (device == 0) poolJoin();
+	pthread_mutex_lock(&g_pool.mu);
+	crh_ctx *c = g_pool.ctx[device];
+	g_pool.ctx[device] = NULL;
+	pthread_mutex_unlock(&g_pool.mu);
+	return c ? c : makeContext(device);
+}
+
+static void poolRelease(int device, crh_ctx *c, int healthy) {
+	if (!c) return;
+	pthread_mutex_lock(&g_pool.mu);
+	const int keep = healthy && !g_pool.ctx[device];
+	if (keep) g_pool.ctx[device] = c;
+	pthread_mutex_unlock(&g_pool.mu);
+	if (!keep) crh_context_destroy(c);
+}
+
+static void poolDestroy(void) {
+	poolJoin();
+	for (int g = 0; g < MAX_GPUS; ++g) {
+		pthread_mutex_lock(&g_pool.mu);
+		crh_ctx *c = g_pool.ctx[g];
+		g_pool.ctx[g] = NULL;
+		pthread_mutex_unlock(&g_pool.mu);
+		if (c) crh_context_destroy(c);
+	}
+}
+
+static void announceLaunch(struct gpuWorker *w) {
+	if (w->announced) return;
+	w->announced = 1;
+	pthread_mutex_lock(&w->sync->mu);
+	w->sync->launched++;
+	pthread_cond_broadcast(&w->sync->cv);
+	pthread_mutex_unlock(&w->sync->mu);
+}
+
 static void gpuThreadDone(struct gpuWorker *w) {
+	announceLaunch(w);
 	w->state->currentTileNum = -1;
 	w->state->threadComplete = true;
 	pthread_mutex_lock(&w->sync->mu);
@@ -160,8 +250,12 @@ static void *gpuThread(void *arg) {
 
 	/* beside the flattener: the context, the per-wave buffers, the code objects.
 	 * counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
-	int ok = crh_context_create(w->device, NULL, &w->ctx) == CRH_OK && crh_set_option(w->ctx, CRH_OPT_COUNTER_LEVEL, 1) == CRH_OK &&
-			 (getenv("CRH_DROPIN_NO_PREPARE") || crh_context_prepare(w->ctx) == CRH_OK) && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
+	w->ctx = poolAcquire(w->device);
+	const long preparedUs = getUs(phase);
+	int ok = w->ctx != NULL && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
+	if (getenv("CRH_TRACE_UPLOAD"))
+		fprintf(stderr, "gpuThread trace: GPU %d has its context (pool, or created + code objects + per-wave buffers) after %.1f ms, its framebuffer after %.1f ms\n",
+				w->device, preparedUs / 1e3, getUs(phase) / 1e3);
 	if (!ok) snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 	w->contextUs = getUs(phase);
 	pthread_mutex_lock(&w->sync->mu);
@@ -201,6 +295,7 @@ static void *gpuThread(void *arg) {
 		startTimer(&tl);
 		int rc = n ? crh_render_tiles(w->ctx, &p, share, n, w->fb) : CRH_OK;
 		w->launchUs += getUs(tl);
+		announceLaunch(w);
 		if (n && (rc != CRH_OK || crh_synchronize(w->ctx) != CRH_OK)) {
 			snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 			logr(warning, "GPU %d: %s\n", w->device, w->error);
@@ -457,7 +552,7 @@ struct texture *renderFrame(struct renderer *r) {
 	struct frameSync sync;
 	pthread_mutex_init(&sync.mu, NULL);
 	pthread_cond_init(&sync.cv, NULL);
-	sync.sceneReady = 0; sync.finished = 0;
+	sync.sceneReady = 0; sync.finished = 0; sync.launched = 0;
 	struct gpuWorker workers[MAX_GPUS];
 	memset(workers, 0, sizeof(workers));
 	for (int i = 0; i < r->state.tileCount; ++i) r->state.renderTiles[i].isRendering = true;      /* every GPU works on the whole frame (strips): all tiles are "being rendered" until the frame is done */
@@ -487,8 +582,11 @@ struct texture *renderFrame(struct renderer *r) {
 			if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
 			pthread_cond_timedwait(&sync.cv, &sync.mu, &until);
 		}
-		const int finished = sync.finished;
+		const int finished = sync.finished, launched = sync.launched;
 		pthread_mutex_unlock(&sync.mu);
+		/* every GPU has its copy of the scene and is busy with its first dispatch: the flattened arrays (70 MB for hdr.json) go back NOW, while this thread has nothing
+		 * to do — at the end of renderFrame() the same free() is milliseconds of the frame (a process that has the GPU open gives pages back slowly) */
+		if (launched == gpus && scene.struct_size) crh_flatten_free(&scene);
 		if (finished == gpus) break;
 		getKeyboardInput(r);
 		drawWindow(r, output);
@@ -538,7 +636,22 @@ struct texture *renderFrame(struct renderer *r) {
 			logr(error, "c-ray-hip: framebuffer download failed: %s\n", crh_last_error());
 		downloadUs = getUs(phase);
 	}
-	const long frameUs = getUs(frame);
+	const long workUs = getUs(frame);            /* set-up + dispatches + gather + conversion + downloads */
+	const char *dump = getenv("CRH_DUMP_F32");
+	if (dump) {
+		FILE *f = fopen(dump, "wb");
+		if (f) { fwrite(buf->data.float_p, sizeof(float), (size_t)W * H * 3, f); fclose(f); }
+	}
+	logr(info, "%llu rays traced on %i GPU%s.\n", (unsigned long long)rays, gpus, PLURAL(gpus));
+
+	for (int g = 0; g < gpus; ++g) {
+		if (workers[g].ctx && workers[g].fb) crh_framebuffer_free(workers[g].ctx, workers[g].fb);
+		poolRelease(g, workers[g].ctx, !workers[g].failed);
+	}
+	pthread_mutex_destroy(&sync.mu);
+	pthread_cond_destroy(&sync.cv);
+	crh_flatten_free(&scene);
+	const long frameUs = getUs(frame);          /* the whole of renderFrame(), teardown included: what the timer of c-ray.c:279-281 sees */
 	/* CRH_DUMP_STATS=<path>: where the frame went, for bench.py's `dropin` object. render_phase_ms is SURVEY.md 8(d)'s phase — the timer
 	 * of src/c-ray.c:279-281 around renderFrame() minus the set-up (flatten / context / upload: everything before the slowest GPU was ready
 	 * to dispatch): dispatches + gather + 8-bit conversion + downloads + the host in between. */
@@ -561,28 +674,14 @@ struct texture *renderFrame(struct renderer *r) {
 			fprintf(f, "{\"gpus\": %d, \"width\": %d, \"height\": %d, \"samples\": %d, \"bounces\": %d, \"rays\": %llu, \"flatten_ms\": %.3f, "
 					"\"context_ms\": %.3f, \"upload_ms\": %.3f, \"context_upload_ms\": %.3f, \"setup_ms\": %.3f, \"render_ms\": %.3f, \"kernel_ms\": %.3f, \"launch_host_ms\": %.3f, "
 					"\"dispatches\": %d, \"reduce_download_ms\": %.3f, \"gather_ms\": %.3f, \"resolve_srgb_ms\": %.3f, \"download_ms\": %.3f, \"rccl_setup_ms\": %.3f, "
-					"\"frame_ms\": %.3f, \"render_phase_ms\": %.3f}\n",
+					"\"frame_ms\": %.3f, \"teardown_ms\": %.3f, \"render_phase_ms\": %.3f}\n",
 					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, contextUs / 1e3, uploadUs / 1e3,
 					(contextUs + uploadUs) / 1e3, readyUs / 1e3, renderUs / 1e3, kernelMs, launchUs / 1e3, dispatches, (gatherUs + downloadUs) / 1e3, gatherUs / 1e3,
-					resolveUs / 1e3, downloadUs / 1e3, warm.us / 1e3, frameUs / 1e3, (frameUs - readyUs) / 1e3);
+					resolveUs / 1e3, downloadUs / 1e3, warm.us / 1e3, frameUs / 1e3, (frameUs - workUs) / 1e3, (workUs - readyUs) / 1e3);
 			fclose(f);
 		}
 	}
 
-	const char *dump = getenv("CRH_DUMP_F32");
-	if (dump) {
-		FILE *f = fopen(dump, "wb");
-		if (f) { fwrite(buf->data.float_p, sizeof(float), (size_t)W * H * 3, f); fclose(f); }
-	}
-	logr(info, "%llu rays traced on %i GPU%s.\n", (unsigned long long)rays, gpus, PLURAL(gpus));
-
-	for (int g = 0; g < gpus; ++g) {
-		if (workers[g].ctx && workers[g].fb) crh_framebuffer_free(workers[g].ctx, workers[g].fb);
-		if (workers[g].ctx) crh_context_destroy(workers[g].ctx);
-	}
-	pthread_mutex_destroy(&sync.mu);
-	pthread_cond_destroy(&sync.cv);
-	crh_flatten_free(&scene);
 	return output;
 }
 
@@ -595,11 +694,13 @@ struct renderer *newRenderer(void) {
 	r->state.tileMutex = createMutex();
 	r->state.timer = calloc(1, sizeof(*r->state.timer));
 	if (!g_vertices) allocVertexBuffers();
+	poolPrefetch();
 	return r;
 }
 
 void destroyRenderer(struct renderer *r) {
 	if (!r) return;
+	poolDestroy();
 	destroyScene(r->scene);
 	destroyTexture(r->state.uiBuffer);
 	destroyTexture(r->state.renderBuffer);

@@ -474,6 +474,35 @@ def test_srgb8_matches_oracle(pkg, ctx, oracle, manifest, golden_blob):
         ctx.strips_to_srgb8(fb, w, h, 4, 2, 2, np.zeros((h, w, 3), np.uint8))
 
 
+def test_upload_lifecycle_host_arrays_released_behind_a_dispatch(pkg, manifest, golden_blob, golden_ref, monkeypatch):
+    """crh_scene_upload leaves the compiled host arrays to the context's janitor thread, which lets them go once a dispatch of some length has been
+    launched, at the next upload, or when the context ends (round 4: freeing them inside the upload cost the drop-in 20 ms per frame). Every order
+    of those events: upload - upload, upload - end, upload - dispatch - upload, and the released-at-the-first-dispatch case (CRH_JANITOR_MIN_PATHS=1,
+    read at the process's first dispatch) — the same frames throughout."""
+    api = pkg.api
+    monkeypatch.setenv("CRH_JANITOR_MIN_PATHS", "1")
+    m = manifest["glowmetal"]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    frames = []
+    for order in ("upload-end", "upload-upload-render", "upload-render-upload-render"):
+        c = api.Context(0)
+        c.upload(api.Scene(golden_blob("glowmetal")))
+        if order == "upload-end":
+            c.close()
+            continue
+        if order == "upload-render-upload-render":
+            fb0 = c.framebuffer(w, h)
+            c.render_region(fb0, w, h, s, b)
+            frames.append(c.download(fb0, w, h))
+        c.upload(api.Scene(golden_blob("glowmetal")))
+        fb = c.framebuffer(w, h)
+        c.render_region(fb, w, h, s, b)
+        frames.append(c.download(fb, w, h))
+        c.close()
+    assert len(frames) == 3 and all(np.array_equal(f, frames[0]) for f in frames[1:])
+    assert np.array_equal(frames[0].view(np.uint32), golden_ref("glowmetal").view(np.uint32))
+
+
 def test_error_paths(pkg, ctx, golden_blob):
     api, abi = pkg.api, pkg.abi
     fresh = api.Context(0)

@@ -140,15 +140,16 @@ static void warmUp(crh_ctx *ctx, float *fb, const crh_render_params *p, int devi
 
 /* ---- the process's render contexts ------------------------------------------------------------------------------------------------------------
  * A context ready to dispatch — stream, counters, code objects, 600 MB of per-wave buffers — takes 13-30 ms to make (round 4, CRH_TRACE_UPLOAD: 8 ms until it
- * exists, 5-21 ms until crh_context_prepare returns) and 5 ms to take down, and none of it depends on the scene. GPU 0's is therefore made by a thread that
- * newRenderer() starts — the program then spends hundreds of milliseconds parsing JSON and OBJ files — and a frame's contexts go back to this pool instead of being
- * destroyed inside renderFrame(); destroyRenderer() ends them. (The other GPUs' contexts are made by their dispatch threads beside the flattener, as before: how
- * many GPUs the scene file asks for is not known when the program starts.) CRH_DROPIN_NO_PREFETCH=1: every context is made inside renderFrame(). */
+ * exists, 5-21 ms until crh_context_prepare returns) and 5 ms to take down, and none of it depends on the scene. They are therefore made — one thread per
+ * device — from newRenderer() on, while the program spends hundreds of milliseconds parsing JSON and OBJ files, and a frame's contexts go back to this pool instead
+ * of being destroyed inside renderFrame(); destroyRenderer() ends them. A dispatch thread whose device has no context yet (the maker failed, more GPUs than
+ * MAX_GPUS makers) makes it beside the flattener, as before. CRH_DROPIN_NO_PREFETCH=1: every context is made inside renderFrame();
+ * CRH_DROPIN_PREFETCH_GPUS=n: makers for the first n devices only (a scene file that asks for fewer GPUs than the node has). */
 static struct {
 	pthread_mutex_t mu;
 	crh_ctx *ctx[MAX_GPUS];
-	pthread_t thread;
-	int threadLive;
+	pthread_t master, maker[MAX_GPUS];
+	int masterLive, makerLive[MAX_GPUS];
 } g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER};
 
 static crh_ctx *makeContext(int device) {
@@ -162,33 +163,53 @@ static crh_ctx *makeContext(int device) {
 	return c;
 }
 
-static void *prefetchThread(void *arg) {
-	(void)arg;
-	crh_ctx *c = makeContext(0);
+static void *makerThread(void *arg) {
+	const int device = (int)(intptr_t)arg;
+	crh_ctx *c = makeContext(device);
 	pthread_mutex_lock(&g_pool.mu);
-	g_pool.ctx[0] = c;
+	g_pool.ctx[device] = c;
 	pthread_mutex_unlock(&g_pool.mu);
+	return NULL;
+}
+
+/* counts the devices (the first HIP call of the process: not on the thread that is about to parse the scene) and starts one maker per device — a scene file that
+ * does not say otherwise renders on every GPU of the node (prefs.threadCount defaults to the core count, renderFrame() clamps it to the device count) */
+static void *masterThread(void *arg) {
+	(void)arg;
+	int n = crh_device_count();
+	if (n > MAX_GPUS) n = MAX_GPUS;
+	if (getenv("CRH_DROPIN_PREFETCH_GPUS") && atoi(getenv("CRH_DROPIN_PREFETCH_GPUS")) < n) n = atoi(getenv("CRH_DROPIN_PREFETCH_GPUS"));
+	for (int g = 0; g < n; ++g) {
+		pthread_mutex_lock(&g_pool.mu);
+		if (!g_pool.makerLive[g] && !g_pool.ctx[g] && pthread_create(&g_pool.maker[g], NULL, makerThread, (void *)(intptr_t)g) == 0) g_pool.makerLive[g] = 1;
+		pthread_mutex_unlock(&g_pool.mu);
+	}
 	return NULL;
 }
 
 static void poolPrefetch(void) {
 	if (getenv("CRH_DROPIN_NO_PREFETCH")) return;
 	pthread_mutex_lock(&g_pool.mu);
-	if (!g_pool.threadLive && !g_pool.ctx[0] && pthread_create(&g_pool.thread, NULL, prefetchThread, NULL) == 0) g_pool.threadLive = 1;
+	if (!g_pool.masterLive && pthread_create(&g_pool.master, NULL, masterThread, NULL) == 0) g_pool.masterLive = 1;
 	pthread_mutex_unlock(&g_pool.mu);
 }
 
-static void poolJoin(void) {
+static void poolJoin(int device) {
 	pthread_mutex_lock(&g_pool.mu);
-	const int live = g_pool.threadLive;
-	g_pool.threadLive = 0;
+	const int master = g_pool.masterLive;
+	g_pool.masterLive = 0;
 	pthread_mutex_unlock(&g_pool.mu);
-	if (live) pthread_join(g_pool.thread, NULL);
+	if (master) pthread_join(g_pool.master, NULL);          /* (it only counts and starts) */
+	pthread_mutex_lock(&g_pool.mu);
+	const int live = g_pool.makerLive[device];
+	g_pool.makerLive[device] = 0;
+	pthread_mutex_unlock(&g_pool.mu);
+	if (live) pthread_join(g_pool.maker[device], NULL);
 }
 
 /* a context for `device`, ready to dispatch: the pool's, or a new one (NULL: crh_last_error() of the calling thread says why) */
 static crh_ctx *poolAcquire(int device) {
-	if (device == 0) poolJoin();
+	poolJoin(device);
 	pthread_mutex_lock(&g_pool.mu);
 	crh_ctx *c = g_pool.ctx[device];
 	g_pool.ctx[device] = NULL;
@@ -206,8 +227,8 @@ static void poolRelease(int device, crh_ctx *c, int healthy) {
 }
 
 static void poolDestroy(void) {
-	poolJoin();
 	for (int g = 0; g < MAX_GPUS; ++g) {
+		poolJoin(g);
 		pthread_mutex_lock(&g_pool.mu);
 		crh_ctx *c = g_pool.ctx[g];
 		g_pool.ctx[g] = NULL;

@@ -326,13 +326,18 @@ __device__ inline Box binBox(const BinKeys &k) {
 
 /* ---- kernels: preparation -------------------------------------------------------------------------------------------- */
 /* bvh.c:264-269 + 289-297: per-triangle box and centre, identity order, root box keys */
-__global__ void k_prepare(const crh_poly *polys, const float *vertices, uint32_t count, float *boxes, float *centers, int32_t *prims, unsigned long long *rootKeys) {
+__global__ void k_prepare(const crh_poly *polys, const float *vertices, uint64_t vertexCount, uint32_t count, float *boxes, float *centers, int32_t *prims, unsigned long long *rootKeys) {
 	__shared__ unsigned long long s_keys[6];
 	if (threadIdx.x < 3) { s_keys[threadIdx.x] = CRH_KEY_LO_EMPTY; s_keys[3 + threadIdx.x] = CRH_KEY_HI_EMPTY; }
 	__syncthreads();
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < count) {
+	/* (a grid-stride loop over a few thousand workgroups: with one workgroup per 256 polygons, 39 063 of them folded their six keys into the same six words with
+	 * device-scope atomics; rootKeys[6] collects "a polygon names a vertex that does not exist" — the host used to check that in a loop of its own, 10 M polygons at a time) */
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
 		const crh_poly p = polys[i];
+		if (p.v[0] < 0 || p.v[1] < 0 || p.v[2] < 0 || (uint64_t)p.v[0] >= vertexCount || (uint64_t)p.v[1] >= vertexCount || (uint64_t)p.v[2] >= vertexCount) {
+			atomicMax(&rootKeys[6], 1ull);
+			continue;
+		}
 		const float *a = vertices + 3 * (size_t)p.v[0], *b = vertices + 3 * (size_t)p.v[1], *c = vertices + 3 * (size_t)p.v[2];
 		for (int k = 0; k < 3; ++k) {
 			const float lo = pickLo(a[k], pickLo(b[k], c[k])), hi = pickHi(a[k], pickHi(b[k], c[k]));
@@ -781,9 +786,6 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	if (stats) memset(stats, 0, sizeof(*stats));
 	if (poly_count < 1) { *node_count_out = 0; return CRH_OK; }                               /* bvh.c:250-256 */
 	if (poly_count >= 0x40000000u) return crh_internal_fail(CRH_ERR_UNSUPPORTED, "crh_bvh_build_triangles: more than 2^30 primitives");
-	for (uint32_t i = 0; i < poly_count; ++i)
-		for (int k = 0; k < 3; ++k)
-			if (polys[i].v[k] < 0 || (uint64_t)polys[i].v[k] >= vertex_count) return crh_internal_fail(CRH_ERR_INVALID, "crh_bvh_build_triangles: vertex index out of range");
 	BVH_TRY(hipSetDevice(crh_internal_device(ctx)));
 	hipStream_t st = (hipStream_t)crh_internal_stream(ctx);
 	const auto t0 = std::chrono::steady_clock::now();
@@ -792,19 +794,20 @@ extern "C" int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint
 	DevBuf<crh_poly> dPolys; DevBuf<float> dVerts, dBoxes, dCenters; DevBuf<int32_t> dPrims; DevBuf<unsigned long long> dRootKeys;
 	DevBuf<uint32_t> dListL, dListR; DevBuf<crh_bvh_node> dLocal, dNodes;
 	BVH_TRY(dPolys.alloc(N)); BVH_TRY(dVerts.alloc((size_t)vertex_count * 3)); BVH_TRY(dBoxes.alloc((size_t)N * 6)); BVH_TRY(dCenters.alloc((size_t)N * 3));
-	BVH_TRY(dPrims.alloc(N)); BVH_TRY(dRootKeys.alloc(6)); BVH_TRY(dListL.alloc(N)); BVH_TRY(dListR.alloc(N));
+	BVH_TRY(dPrims.alloc(N)); BVH_TRY(dRootKeys.alloc(7)); BVH_TRY(dListL.alloc(N)); BVH_TRY(dListR.alloc(N));
 	BVH_TRY(dNodes.alloc(2 * (size_t)N));
 	BVH_TRY(hipMemcpyAsync(dPolys.p, polys, (size_t)N * sizeof(crh_poly), hipMemcpyHostToDevice, st));
 	BVH_TRY(hipMemcpyAsync(dVerts.p, vertices, (size_t)vertex_count * 3 * sizeof(float), hipMemcpyHostToDevice, st));
-	const unsigned long long rootInit[6] = {CRH_KEY_LO_EMPTY, CRH_KEY_LO_EMPTY, CRH_KEY_LO_EMPTY, CRH_KEY_HI_EMPTY, CRH_KEY_HI_EMPTY, CRH_KEY_HI_EMPTY};
+	const unsigned long long rootInit[7] = {CRH_KEY_LO_EMPTY, CRH_KEY_LO_EMPTY, CRH_KEY_LO_EMPTY, CRH_KEY_HI_EMPTY, CRH_KEY_HI_EMPTY, CRH_KEY_HI_EMPTY, 0ull};      /* [6]: a vertex index out of range */
 	BVH_TRY(hipMemcpyAsync(dRootKeys.p, rootInit, sizeof(rootInit), hipMemcpyHostToDevice, st));
 	BVH_TRY(hipStreamSynchronize(st));
 	const auto t1 = std::chrono::steady_clock::now();
 
-	hipLaunchKernelGGL(k_prepare, dim3((N + 255) / 256), dim3(256), 0, st, dPolys.p, dVerts.p, N, dBoxes.p, dCenters.p, dPrims.p, dRootKeys.p);
-	unsigned long long rootKeys[6];
+	hipLaunchKernelGGL(k_prepare, dim3(std::min<uint32_t>((N + 255) / 256, 4096u)), dim3(256), 0, st, dPolys.p, dVerts.p, vertex_count, N, dBoxes.p, dCenters.p, dPrims.p, dRootKeys.p);
+	unsigned long long rootKeys[7];
 	BVH_TRY(hipMemcpyAsync(rootKeys, dRootKeys.p, sizeof(rootKeys), hipMemcpyDeviceToHost, st));
 	BVH_TRY(hipStreamSynchronize(st));
+	if (rootKeys[6]) return crh_internal_fail(CRH_ERR_INVALID, "crh_bvh_build_triangles: vertex index out of range");
 
 	std::vector<UpperNode> upper;
 	upper.reserve(1024);

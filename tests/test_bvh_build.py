@@ -113,6 +113,15 @@ def test_gpu_builder_degenerate_inputs(pkg, oracle):
     ref_nodes, ref_prims = oracle.bvh_build_triangles(polys.ctypes.data, verts.ctypes.data, count)
     nodes, prims, st = ctx.bvh_build_triangles(polys.ctypes.data, count, verts.ctypes.data, len(verts))
     assert_same_bvh(nodes, prims, ref_nodes, ref_prims, ("outlier line", st))
+    # a polygon that names a vertex the mesh does not have (checked where the boxes are made, on the device, since round 4): refused, and the context builds the next mesh
+    for bad in (len(verts), -1):
+        broken = polys.copy()
+        broken[1234, 1] = bad
+        with pytest.raises(pkg.api.CrhError) as e:
+            ctx.bvh_build_triangles(broken.ctypes.data, count, verts.ctypes.data, len(verts))
+        assert e.value.code == pkg.abi.ERR_INVALID and "vertex index out of range" in str(e.value)
+    nodes, prims, st = ctx.bvh_build_triangles(polys.ctypes.data, count, verts.ctypes.data, len(verts))
+    assert_same_bvh(nodes, prims, ref_nodes, ref_prims, ("after a refused mesh", st))
     ctx.close()
 
 

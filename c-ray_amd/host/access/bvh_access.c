@@ -9,6 +9,7 @@
 #ifdef CRH_GPU_BVH
 #define buildBottomLevelBvh crh_reference_buildBottomLevelBvh
 #endif
+#include <sys/mman.h>
 #include "accelerators/bvh.c"
 #include "describe.h"
 
@@ -21,6 +22,8 @@ _Static_assert(sizeof(struct bvhNode) == sizeof(crh_bvh_node), "crh_bvh_node mus
 #ifdef CRH_GPU_BVH
 #undef buildBottomLevelBvh
 #include <pthread.h>
+#include <stdio.h>
+#include "utils/timer.h"
 #include "datatypes/vertexbuffer.h"
 #include "utils/logging.h"
 _Static_assert(sizeof(struct poly) == sizeof(crh_poly), "crh_poly must mirror struct poly (40 B)");
@@ -68,12 +71,26 @@ static void bvhPoolRelease(int slot) {
 	pthread_mutex_unlock(&g_bvh_lock);
 }
 
+/* malloc for the arrays the builder fills: from 8 MB on, on a 2 MB boundary with transparent huge pages asked for (free()- and realloc()-compatible, which is what
+ * the reference's destroyBvh and bvh.c:283 do to them). A 10 M-triangle mesh is 240 MB of nodes written by a device-to-host copy into fresh memory: with 4 KB pages
+ * that is 58 000 page faults in a process that has the GPU open (round 4: the same finding as for the scene upload). */
+static void *bigMalloc(size_t bytes) {
+	if (bytes < ((size_t)8 << 20) || getenv("CRH_NO_HUGEPAGES")) return malloc(bytes);          /* (the variable: dev, for an A/B) */
+	void *p = NULL;
+	const size_t rounded = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+	if (posix_memalign(&p, (size_t)2 << 20, rounded) != 0) return malloc(bytes);
+	(void)madvise(p, rounded, MADV_HUGEPAGE);
+	return p;
+}
+
 struct bvh *buildBottomLevelBvh(struct poly *polys, unsigned count) {
 	struct bvh *bvh = malloc(sizeof(*bvh));
 	bvh->nodeCount = 0; bvh->nodes = NULL; bvh->primIndices = NULL;
 	if (count < 1) return bvh;                                  /* bvh.c:250-256 */
-	bvh->nodes = malloc(sizeof(struct bvhNode) * (2 * (size_t)count - 1));
-	bvh->primIndices = malloc(sizeof(int) * count);
+	struct timeval tTrace;
+	startTimer(&tTrace);
+	bvh->nodes = bigMalloc(sizeof(struct bvhNode) * (2 * (size_t)count - 1));
+	bvh->primIndices = bigMalloc(sizeof(int) * count);
 	/* Upload only the vertex range this mesh references (the loader gives every mesh a contiguous range of g_vertices,
 	 * wavefront.c:110-126), not the whole global buffer once per mesh: polygons are handed over with indices rebased to it. */
 	int vmin = polys[0].vertexIndex[0], vmax = vmin;
@@ -84,20 +101,28 @@ struct bvh *buildBottomLevelBvh(struct poly *polys, unsigned count) {
 			if (v > vmax) vmax = v;
 		}
 	if (vmin < 0 || vmax >= vertexCount) logr(error, "c-ray-hip: mesh references vertex %i outside g_vertices[0..%i)\n", vmin < 0 ? vmin : vmax, vertexCount);
-	crh_poly *local = malloc(sizeof(*local) * count);
+	crh_poly *local = bigMalloc(sizeof(*local) * count);
 	memcpy(local, polys, sizeof(*local) * count);
 	for (unsigned i = 0; i < count; ++i)
 		for (int k = 0; k < 3; ++k) local[i].v[k] -= vmin;
+	const long preparedUs = getUs(tTrace);
 	int rc = CRH_OK, slot = -1;
 	crh_ctx *ctx = bvhPoolAcquire(&slot, &rc);
+	const long acquiredUs = getUs(tTrace);
+	crh_bvh_build_stats stats;
+	memset(&stats, 0, sizeof(stats));
 	if (ctx) {
 		rc = crh_bvh_build_triangles(ctx, local, count, (const float *)(g_vertices + vmin), (uint64_t)(vmax - vmin + 1),
-		                             (crh_bvh_node *)bvh->nodes, bvh->primIndices, &bvh->nodeCount, NULL);
+		                             (crh_bvh_node *)bvh->nodes, bvh->primIndices, &bvh->nodeCount, &stats);
 		bvhPoolRelease(slot);
 	}
 	free(local);
 	if (rc != CRH_OK) logr(error, "c-ray-hip: GPU BVH build failed (%i): %s\n", rc, crh_last_error());   /* exits: no CPU path here */
+	const long builtUs = getUs(tTrace);
 	bvh->nodes = realloc(bvh->nodes, sizeof(struct bvhNode) * bvh->nodeCount);   /* bvh.c:283 */
+	if (getenv("CRH_TRACE_UPLOAD") && count > 10000)
+		fprintf(stderr, "buildBottomLevelBvh trace: %u triangles: index range + rebased copy %.1f ms, builder context after %.1f ms, GPU builder call %.1f ms (upload %.1f, build %.1f, download %.1f), shrink %.1f ms\n",
+				count, preparedUs / 1e3, (acquiredUs - preparedUs) / 1e3, (builtUs - acquiredUs) / 1e3, stats.upload_ms, stats.build_ms, stats.download_ms, (getUs(tTrace) - builtUs) / 1e3);
 	return bvh;
 }
 #endif

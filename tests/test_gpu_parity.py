@@ -647,6 +647,21 @@ def test_dropin_binary_renders_through_the_reference_program(pkg, ctx, manifest,
     # byte for byte the file the real reference writes (tools/gen_bmp_golden.py): its encoder, fed by an 8-bit frame that was converted on the device
     assert hashlib.md5(data).hexdigest() == m["bmp_md5"], "the BMP differs from c-ray-ref-strict's"
     os.remove(tmp_path / bmp[0])
+    # where renderFrame()'s time went (CRH_DUMP_STATS): frame_ms runs to the END of renderFrame() — set-up + render phase + teardown — with the contexts made from
+    # newRenderer() on (the default) and with every context made inside the frame (CRH_DROPIN_NO_PREFETCH); the same frame either way
+    for extra in ({}, {"CRH_DROPIN_NO_PREFETCH": "1"}):
+        stats = str(tmp_path / "stats.json")
+        proc = subprocess.run([exe], input=json.dumps(scene).encode(), cwd=overlay, env=dict(env, CRH_DUMP_STATS=stats, **extra), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, timeout=600)
+        assert proc.returncode == 0, proc.stdout.decode(errors="replace")[-2000:]
+        st = json.load(open(stats))
+        assert st["rays"] == m["rays"] and st["gpus"] == 1
+        assert st["teardown_ms"] >= 0 and st["setup_ms"] > 0 and st["render_phase_ms"] > 0
+        assert abs(st["frame_ms"] - (st["setup_ms"] + st["render_phase_ms"] + st["teardown_ms"])) < 0.01, st
+        assert st["setup_ms"] >= st["upload_ms"] and st["setup_ms"] >= st["flatten_ms"], st
+        assert np.array_equal(np.fromfile(dump, dtype=np.float32).reshape(h, w, 3), img)
+        for f in os.listdir(tmp_path):
+            if f.endswith(".bmp"): os.remove(tmp_path / f)
     # --iterative: the interactive mode of the same program (Halton sampler, passes 1 .. samples-1, progressive chunks)
     mi = manifest["cfg1_scene_iterative"]
     scene = refrun.rewrite_scene("scene.json", w, h, mi["samples"], mi["bounces"], out_dir=str(tmp_path))

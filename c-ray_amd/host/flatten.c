@@ -11,7 +11,9 @@
  */
 #include <sys/mman.h>
 #include <stdint.h>
+#include <pthread.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -105,6 +107,56 @@ static void big_free(const void *p) {
 	free((void *)p);
 }
 
+/* fn(ctx, begin, end) over [0, n) on up to CRH_FLATTEN_THREADS threads (the calling one included; default: that one alone, see below): the flattener's big loops
+ * are copies — 60 MB for hdr.json */
+#define FLAT_THREADS 8
+#define FLAT_THREADS_DEFAULT 1      /* measured (profiles/r04z4_flatten_threads.log): 8 threads flatten hdr.json in 5 ms instead of 8, and the upload that follows takes 11 OR 20 ms
+                                    * instead of 12 — the pages are first touched wherever the helper threads happen to run; CRH_FLATTEN_THREADS=n for a host that pins its threads */
+struct par_job { void (*fn)(void *, size_t, size_t); void *ctx; size_t b, e; };
+static void *par_run(void *arg) { struct par_job *j = arg; j->fn(j->ctx, j->b, j->e); return NULL; }
+static void parallel_ranges(size_t n, size_t grain, void (*fn)(void *, size_t, size_t), void *ctx) {
+	size_t parts = n / (grain ? grain : 1);
+	static int threads = 0;
+	if (!threads) { const char *e = getenv("CRH_FLATTEN_THREADS"); threads = e && atoi(e) > 0 ? (atoi(e) > FLAT_THREADS ? FLAT_THREADS : atoi(e)) : FLAT_THREADS_DEFAULT; }
+	if (parts > (size_t)threads) parts = (size_t)threads;
+	if (parts <= 1) { fn(ctx, 0, n); return; }
+	pthread_t th[FLAT_THREADS];
+	struct par_job job[FLAT_THREADS];
+	int live[FLAT_THREADS];
+	for (size_t p = 0; p < parts; ++p) {
+		job[p] = (struct par_job){fn, ctx, n * p / parts, n * (p + 1) / parts};
+		live[p] = p > 0 && pthread_create(&th[p], NULL, par_run, &job[p]) == 0;
+	}
+	par_run(&job[0]);
+	for (size_t p = 1; p < parts; ++p) { if (live[p]) pthread_join(th[p], NULL); else par_run(&job[p]); }
+}
+struct copy_job { char *dst; const char *src; };
+static void copy_range(void *ctx, size_t b, size_t e) { const struct copy_job *c = ctx; memcpy(c->dst + b, c->src + b, e - b); }
+static void big_memcpy(void *dst, const void *src, size_t bytes) {
+	struct copy_job c = {dst, src};
+	parallel_ranges(bytes, (size_t)1 << 20, copy_range, &c);
+}
+struct bits_job { crh_bvh_node *nodes; crh_poly *polys; };
+/* (an inner node's primCount is never written by the reference's builders — bvh.c:235 sets isLeaf only — and nothing reads it: whatever malloc left there is cleared too) */
+static void node_bits_range(void *ctx, size_t b, size_t e) { struct bits_job *j = ctx; for (size_t i = b; i < e; ++i) j->nodes[i].count_leaf &= ((j->nodes[i].count_leaf >> 30) & 1u) ? 0x7FFFFFFFu : 0u; }
+static void poly_bits_range(void *ctx, size_t b, size_t e) { struct bits_job *j = ctx; for (size_t i = b; i < e; ++i) j->polys[i].bits &= 0xFF07FFFFu; }
+/* the vertex buffers in two passes: which slots does a polygon name (one byte per slot; several polygons, and several threads, store the same 1), then the named slots
+ * copied in index order — instead of every polygon copying its nine slots to wherever they lie */
+struct vert_job { const crh_poly *polys; float *verts, *norms, *texs; uint8_t *usedV, *usedN, *usedT; };
+static void mark_range(void *ctx, size_t b, size_t e) {
+	const struct vert_job *j = ctx;
+	for (size_t p = b; p < e; ++p)
+		for (int k = 0; k < 3; ++k) {
+			int vi = j->polys[p].v[k], ni = j->polys[p].n[k], ti = j->polys[p].t[k];
+			if (vi >= 0 && vi < vertexCount) j->usedV[vi] = 1;
+			if (ni >= 0 && ni < normalCount) j->usedN[ni] = 1;
+			if (ti >= 0 && ti < textureCount) j->usedT[ti] = 1;
+		}
+}
+static void copy_verts_range(void *ctx, size_t b, size_t e) { const struct vert_job *j = ctx; for (size_t i = b; i < e; ++i) if (j->usedV[i]) memcpy(j->verts + 3 * i, &g_vertices[i], 12); }
+static void copy_norms_range(void *ctx, size_t b, size_t e) { const struct vert_job *j = ctx; for (size_t i = b; i < e; ++i) if (j->usedN[i]) memcpy(j->norms + 3 * i, &g_normals[i], 12); }
+static void copy_texs_range(void *ctx, size_t b, size_t e) { const struct vert_job *j = ctx; for (size_t i = b; i < e; ++i) if (j->usedT[i]) memcpy(j->texs + 2 * i, &g_textureCoords[i], 8); }
+
 static uint32_t add_texture(struct flat *f, const struct texture *t) {
 	if (!t) return CRH_NODE_NONE;
 	uint32_t idx;
@@ -124,7 +176,7 @@ static uint32_t add_texture(struct flat *f, const struct texture *t) {
 		f->texdata = grown;
 	}
 	memset(f->texdata + f->texbytes, 0, off - f->texbytes);
-	memcpy(f->texdata + off, t->data.byte_p, bytes);
+	big_memcpy(f->texdata + off, t->data.byte_p, bytes);
 	f->texbytes = off + bytes;
 	idx = (uint32_t)f->texture_count++;
 	f->textures[idx] = (crh_texture){
@@ -201,6 +253,10 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 	memset(out, 0, sizeof(*out));
 	out->struct_size = sizeof(*out);
 	out->abi_version = CRH_SCENE_VERSION;
+	struct timespec tr0;
+	clock_gettime(CLOCK_MONOTONIC, &tr0);
+	double trAt[5] = {0, 0, 0, 0, 0};
+#define TRACE_LAP(i) do { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); trAt[i] = (t_.tv_sec - tr0.tv_sec) * 1e3 + (t_.tv_nsec - tr0.tv_nsec) / 1e6; } while (0)
 
 	/* --- BVHs: every BLAS, then the TLAS, concatenated --- */
 	size_t totalNodes = crh_access_bvh_node_count(w->topLevel), totalPrims = (size_t)w->instanceCount, totalPolys = 0, totalMats = (size_t)w->sphereCount;
@@ -230,18 +286,23 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 		fm->texcoord_count = (uint32_t)mesh->textureCoordCount;
 		fm->ray_offset = mesh->rayOffset;
 		if (nc) {
-			memcpy(nodes + nodeAt, crh_access_bvh_nodes(mesh->bvh), nc * sizeof(*nodes));
-			memcpy(prims + primAt, crh_access_bvh_prims(mesh->bvh), (size_t)mesh->polyCount * sizeof(*prims));
+			big_memcpy(nodes + nodeAt, crh_access_bvh_nodes(mesh->bvh), nc * sizeof(*nodes));
+			big_memcpy(prims + primAt, crh_access_bvh_prims(mesh->bvh), (size_t)mesh->polyCount * sizeof(*prims));
 		}
-		if (mesh->polyCount) memcpy(polys + polyAt, mesh->polygons, (size_t)mesh->polyCount * sizeof(*polys));
+		if (mesh->polyCount) big_memcpy(polys + polyAt, mesh->polygons, (size_t)mesh->polyCount * sizeof(*polys));
 		for (int k = 0; k < mesh->materialCount; ++k) materials[matAt + k] = flat_material(&f, &mesh->materials[k]);
 		nodeAt += nc; primAt += (size_t)mesh->polyCount; polyAt += (size_t)mesh->polyCount; matAt += (size_t)mesh->materialCount;
 	}
+	TRACE_LAP(0);
 	/* bvhNode's padding bits (count_leaf bit 31) and poly's padding bits are indeterminate in the
 	 * reference; clear them so that blobs are reproducible. */
-	for (size_t i = 0; i < nodeAt; ++i) nodes[i].count_leaf &= 0x7FFFFFFFu;
-	for (size_t i = 0; i < polyAt; ++i) polys[i].bits &= 0xFF07FFFFu;
+	{
+		struct bits_job bj = {nodes, polys};
+		parallel_ranges(nodeAt, (size_t)1 << 16, node_bits_range, &bj);
+		parallel_ranges(polyAt, (size_t)1 << 16, poly_bits_range, &bj);
+	}
 
+	TRACE_LAP(1);
 	out->tlas_node_base = (uint32_t)nodeAt;
 	out->tlas_node_count = crh_access_bvh_node_count(w->topLevel);
 	out->tlas_prim_base = (uint32_t)primAt;
@@ -249,7 +310,7 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 	if (out->tlas_node_count) {
 		memcpy(nodes + nodeAt, crh_access_bvh_nodes(w->topLevel), out->tlas_node_count * sizeof(*nodes));
 		memcpy(prims + primAt, crh_access_bvh_prims(w->topLevel), (size_t)w->instanceCount * sizeof(*prims));
-		for (size_t i = nodeAt; i < nodeAt + out->tlas_node_count; ++i) nodes[i].count_leaf &= 0x7FFFFFFFu;
+		{ struct bits_job tj = {nodes, polys}; node_bits_range(&tj, nodeAt, nodeAt + out->tlas_node_count); }
 		nodeAt += out->tlas_node_count; primAt += (size_t)w->instanceCount;
 	}
 
@@ -281,20 +342,26 @@ int crh_flatten_world(const struct renderer *r, crh_scene_desc *out) {
 
 	out->background = add_node(&f, w->background, CRH_CLS_BSDF);
 
+	TRACE_LAP(2);
 	/* --- global vertex buffers; slots no polygon references are zeroed (the loader over-allocates:
 	 * wavefront.c:148 counts every line starting with 'v') so the blob is deterministic --- */
 	float *verts = big_zalloc((size_t)(vertexCount > 0 ? vertexCount : 1) * 3 * sizeof(float));
 	float *norms = big_zalloc((size_t)(normalCount > 0 ? normalCount : 1) * 3 * sizeof(float));
 	float *texs = big_zalloc((size_t)(textureCount > 0 ? textureCount : 1) * 2 * sizeof(float));
-	for (size_t p = 0; p < polyAt; ++p) {
-		for (int k = 0; k < 3; ++k) {
-			int vi = polys[p].v[k], ni = polys[p].n[k], ti = polys[p].t[k];
-			if (vi >= 0 && vi < vertexCount) memcpy(verts + 3 * (size_t)vi, &g_vertices[vi], 12);
-			if (ni >= 0 && ni < normalCount) memcpy(norms + 3 * (size_t)ni, &g_normals[ni], 12);
-			if (ti >= 0 && ti < textureCount) memcpy(texs + 2 * (size_t)ti, &g_textureCoords[ti], 8);
-		}
+	{
+		struct vert_job vj = {polys, verts, norms, texs, calloc((size_t)(vertexCount > 0 ? vertexCount : 1), 1), calloc((size_t)(normalCount > 0 ? normalCount : 1), 1),
+		                      calloc((size_t)(textureCount > 0 ? textureCount : 1), 1)};
+		parallel_ranges(polyAt, (size_t)1 << 15, mark_range, &vj);
+		parallel_ranges((size_t)(vertexCount > 0 ? vertexCount : 0), (size_t)1 << 15, copy_verts_range, &vj);
+		parallel_ranges((size_t)(normalCount > 0 ? normalCount : 0), (size_t)1 << 15, copy_norms_range, &vj);
+		parallel_ranges((size_t)(textureCount > 0 ? textureCount : 0), (size_t)1 << 15, copy_texs_range, &vj);
+		free(vj.usedV); free(vj.usedN); free(vj.usedT);
 	}
 
+	TRACE_LAP(3);
+	if (getenv("CRH_TRACE_UPLOAD"))
+		fprintf(stderr, "crh_flatten_world trace: BVH / polygon copies %.1f ms, padding bits %.1f ms, instances + node graphs + textures %.1f ms, vertex buffers %.1f ms\n",
+				trAt[0], trAt[1] - trAt[0], trAt[2] - trAt[1], trAt[3] - trAt[2]);
 	const struct camera *cam = w->camera;
 	crh_camera *fc = &out->camera;
 	fc->right[0] = cam->right.x; fc->right[1] = cam->right.y; fc->right[2] = cam->right.z;

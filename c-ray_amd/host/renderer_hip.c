@@ -146,11 +146,11 @@ static void warmUp(crh_ctx *ctx, float *fb, const crh_render_params *p, int devi
  * MAX_GPUS makers) makes it beside the flattener, as before. CRH_DROPIN_NO_PREFETCH=1: every context is made inside renderFrame();
  * CRH_DROPIN_PREFETCH_GPUS=n: makers for the first n devices only (a scene file that asks for fewer GPUs than the node has). */
 static struct {
-	pthread_mutex_t mu;
+	pthread_mutex_t mu, joinMu;          /* joinMu: one thread joins the master, the others wait until it has (a maker that is not started yet would be missed) */
 	crh_ctx *ctx[MAX_GPUS];
 	pthread_t master, maker[MAX_GPUS];
 	int masterLive, makerLive[MAX_GPUS];
-} g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER};
+} g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER, .joinMu = PTHREAD_MUTEX_INITIALIZER};
 
 static crh_ctx *makeContext(int device) {
 	crh_ctx *c = NULL;
@@ -195,11 +195,13 @@ static void poolPrefetch(void) {
 }
 
 static void poolJoin(int device) {
+	pthread_mutex_lock(&g_pool.joinMu);
 	pthread_mutex_lock(&g_pool.mu);
 	const int master = g_pool.masterLive;
 	g_pool.masterLive = 0;
 	pthread_mutex_unlock(&g_pool.mu);
 	if (master) pthread_join(g_pool.master, NULL);          /* (it only counts and starts) */
+	pthread_mutex_unlock(&g_pool.joinMu);
 	pthread_mutex_lock(&g_pool.mu);
 	const int live = g_pool.makerLive[device];
 	g_pool.makerLive[device] = 0;

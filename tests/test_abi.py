@@ -115,3 +115,18 @@ def test_blob_roundtrip(pkg, golden_blob, tmp_path):
     assert open(out, "rb").read() == open(golden_blob("fence"), "rb").read()
     with pytest.raises(pkg.api.CrhError):
         pkg.api.Scene(str(tmp_path / "missing.blob"))
+
+
+def test_podbuf_allocation_regimes(tmp_path):
+    """scene_compile.h's PodBuf — the layout compiler's big arrays — below and above the size from which its blocks sit on 2 MB boundaries, ask for transparent huge
+    pages and grow by copying (round 4: the compile was bound by page faults): contents survive every growth, alignment, exact first reservation
+    (tests/emu/podbuf_check.cpp). The CPU tier's fixtures never reach that size; hdr.json's texels do."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "podbuf_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(repo, "include"), "-I" + os.path.join(repo, "c-ray_amd", "csrc"),
+                           os.path.join(repo, "tests", "emu", "podbuf_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "podbuf_check ok" in r.stdout, r.stdout + r.stderr
+

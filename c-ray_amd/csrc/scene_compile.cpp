@@ -64,6 +64,8 @@ struct Compiler {
 	std::map<uint32_t, uint32_t> oprMemo;
 	std::vector<uint8_t> needUv;          /* per bsdf gnode: its graph reads the hit's uv */
 	std::function<void()> texelsReady;
+	double tRelayoutPar = 0, tRelayoutDepth = 0, tTriLoop = 0, tResize = 0;          /* CRH_TRACE_UPLOAD: where "BLAS + prepared triangles" goes */
+	static double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 	Compiler(const crh_scene_desc *scene, CompiledScene &o) : s(scene), out(o) {}
 
@@ -80,10 +82,13 @@ struct Compiler {
 		if (node_count == 0) return info;
 		CHECK((uint64_t)node_base + node_count <= s->node_count, CRH_ERR_INVALID, "%s: node range out of bounds", what);
 		CHECK((uint64_t)prim_base + prim_count <= s->prim_index_count, CRH_ERR_INVALID, "%s: prim range out of bounds", what);
+		const double tr0 = nowMs();
 		out.nodes.resize((size_t)(dev_base + 1 + node_count) * 2);
+		const double tr1 = nowMs();
+		tResize += tr1 - tr0;
 		out.nodes[(size_t)dev_base * 2] = f4{0, 0, 0, 0}; out.nodes[(size_t)dev_base * 2 + 1] = f4{0, 0, 0, 0};          /* the unused slot in front of the root */
 		/* validation + records: every node on its own (threads) ... */
-		parallelFor(node_count, 1u << 16, [&](size_t b0, size_t e0) {
+		parallelFor(node_count, 1u << 13, [&](size_t b0, size_t e0) {
 			for (uint32_t i = (uint32_t)b0; i < (uint32_t)e0; ++i) {
 				const crh_bvh_node &n = s->nodes[node_base + i];
 				const uint32_t count = CRH_NODE_PRIMCOUNT(n);
@@ -104,6 +109,8 @@ struct Compiler {
 				out.nodes[(size_t)(dev_base + 1 + i) * 2 + 1] = b;
 			}
 		});
+		const double tr2 = nowMs();
+		tRelayoutPar += tr2 - tr1;
 		/* ... the depth in index order (children come after their parent) */
 		std::vector<uint8_t> depth(node_count, 0);
 		for (uint32_t i = 0; i < node_count; ++i) {
@@ -115,6 +122,7 @@ struct Compiler {
 			depth[n.first + 1] = (uint8_t)std::max<uint32_t>(depth[n.first + 1], d);
 			info.depth = std::max(info.depth, d);
 		}
+		tRelayoutDepth += nowMs() - tr2;
 		if (node_count > 1) {
 			CHECK(!CRH_NODE_ISLEAF(s->nodes[node_base]), CRH_ERR_INVALID, "%s: multi-node BVH with a leaf root", what);
 			info.root = dev_base + 1 + s->nodes[node_base].first;
@@ -374,17 +382,29 @@ struct Compiler {
 			out.materials[m].pad[0] = needUv[b];
 		}
 
+		const double tBlas0 = nowMs();
 		/* BLAS per mesh, prepared triangles */
 		/* (every prim slot of a mesh with a BVH is written below; slots no mesh owns — none in scenes the flattener makes — are zeroed first) */
 		out.tris.resize((size_t)std::max<uint64_t>(s->prim_index_count, 1) * 3);
 		out.shade.resize((size_t)std::max<uint64_t>(s->prim_index_count, 1));
-		{
-			bool all = s->prim_index_count > 0;
-			uint64_t covered = 0;
-			for (uint64_t m = 0; m < s->mesh_count; ++m) if (s->meshes[m].node_count) covered += s->meshes[m].poly_count;
-			if (covered != s->prim_index_count) all = false;
-			if (!all) { memset((void *)out.tris.data(), 0, out.tris.size() * sizeof(f4)); memset((void *)out.shade.data(), 0, out.shade.size() * sizeof(DShadeTri)); }
+		{	/* ... only them: the top-level BVH's own prim slots are such slots in EVERY scene, and zeroing both arrays whole for their sake was a single-threaded
+			 * pass over 75 MB — 2.5 of hdr.json's 8.7 ms (round 4, CRH_TRACE_UPLOAD) */
+			std::vector<std::pair<uint64_t, uint64_t>> owned;
+			for (uint64_t m = 0; m < s->mesh_count; ++m)
+				if (s->meshes[m].node_count && s->meshes[m].poly_count) owned.push_back({s->meshes[m].prim_base, (uint64_t)s->meshes[m].prim_base + s->meshes[m].poly_count});
+			std::sort(owned.begin(), owned.end());
+			const uint64_t slots = std::max<uint64_t>(s->prim_index_count, 1);
+			auto zero = [&](uint64_t b, uint64_t e) {
+				e = std::min(e, slots);
+				if (b >= e) return;
+				memset((void *)(out.tris.data() + b * 3), 0, (size_t)(e - b) * 3 * sizeof(f4));
+				memset((void *)(out.shade.data() + b), 0, (size_t)(e - b) * sizeof(DShadeTri));
+			};
+			uint64_t at = 0;
+			for (const auto &r : owned) { zero(at, r.first); at = std::max(at, r.second); }
+			zero(at, slots);
 		}
+		const double tPrelude = nowMs();
 		std::vector<BvhInfo> meshBvh(s->mesh_count);
 		uint32_t maxBlasDepth = 0;
 		for (uint64_t m = 0; m < s->mesh_count; ++m) {
@@ -394,6 +414,7 @@ struct Compiler {
 			meshBvh[m] = relayoutBvh(mesh.node_base, mesh.node_count, mesh.prim_base, mesh.node_count ? mesh.poly_count : 0, "BLAS");
 			maxBlasDepth = std::max(maxBlasDepth, meshBvh[m].depth);
 			if (!mesh.node_count) continue;
+			const double tt0 = nowMs();
 			parallelFor(mesh.poly_count, 1u << 14, [&](size_t k0, size_t k1) {
 			for (uint32_t k = (uint32_t)k0; k < (uint32_t)k1; ++k) {
 				const int32_t pi = s->prim_indices[mesh.prim_base + k];
@@ -433,10 +454,11 @@ struct Compiler {
 				}
 			}
 			});
+			tTriLoop += nowMs() - tt0;
 		}
 
 		const double tBlas = lap();
-		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: textures %.1f ms, node graph %.1f ms, BLAS + prepared triangles %.1f ms\n", tTex, tGraph, tBlas);
+		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: textures %.1f ms, node graph %.1f ms, BLAS + prepared triangles %.1f ms (reservations %.1f, node records %.1f, depth pass %.1f, triangle loop %.1f, resizes %.1f)\n", tTex, tGraph, tBlas, tPrelude - tBlas0, tRelayoutPar, tRelayoutDepth, tTriLoop, tResize);
 		/* TLAS */
 		CHECK(s->tlas_prim_count == (s->tlas_node_count ? s->instance_count : 0), CRH_ERR_INVALID, "TLAS prim count does not match the instance count");
 		const BvhInfo tlas = relayoutBvh(s->tlas_node_base, s->tlas_node_count, s->tlas_prim_base, s->tlas_prim_count, "TLAS");

@@ -261,7 +261,9 @@ struct SchedWg { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrl
 /* bits of a context's error word (host-visible memory; a kernel ORs them in, crh_synchronize / crh_framebuffer_download report and clear them) */
 #define CRH_ERRFLAG_WG_WATCHDOG 1u
 #define CRH_ERRFLAG_ROUND_LIMIT 2u
-#define CRH_JANITOR_MIN_PATHS ((uint64_t)1 << 22)      /* a dispatch of at least this many paths (milliseconds of device time) hides the release of an upload's host arrays */
+#define CRH_JANITOR_MIN_PATHS ((uint64_t)1 << 26)      /* a dispatch of at least this many paths (>= 20 ms of device time; the release takes 15 ms for hdr.json's arrays, huge pages or not:
+                                                          * profiles/r04zz6_janitor_time.log) hides the release of an upload's host arrays; shorter dispatches — a 1 / 8 share of a frame — leave them to
+                                                          * the next upload or the context's end rather than have their synchronisation wait for it */
 
 /* Per-wave PATH TABLE in global memory: a path lives in one 128-B record (one cache line, one lane reads or writes it
  * with a few 16-B accesses) from its camera ray to its last bounce; what moves between the work stacks is its one-byte
@@ -984,7 +986,11 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	c->janitorWaiting.store(true);
 	c->janitor = std::thread([c, trash]() {
 		{ std::unique_lock<std::mutex> lk(c->janitorMu); c->janitorCv.wait(lk, [c]() { return c->janitorGo; }); }
+		const auto t0 = std::chrono::steady_clock::now();
 		delete trash;
+		if (getenv("CRH_TRACE_UPLOAD"))
+			fprintf(stderr, "crh_scene_upload trace: the compiled host arrays were released in %.1f ms (behind a dispatch, or at the next upload / the context's end)\n",
+					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 	});
 	return CRH_OK;
 }

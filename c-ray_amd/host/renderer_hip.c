@@ -608,8 +608,9 @@ struct texture *renderFrame(struct renderer *r) {
 		const int finished = sync.finished, launched = sync.launched;
 		pthread_mutex_unlock(&sync.mu);
 		/* every GPU has its copy of the scene and is busy with its first dispatch: the flattened arrays (70 MB for hdr.json) go back NOW, while this thread has nothing
-		 * to do — at the end of renderFrame() the same free() is milliseconds of the frame (a process that has the GPU open gives pages back slowly) */
-		if (launched == gpus && scene.struct_size) crh_flatten_free(&scene);
+		 * to do — at the end of renderFrame() the same free() is milliseconds of the frame (a process that has the GPU open gives pages back slowly, and what its threads
+		 * launch or wait for meanwhile waits too: only when a GPU's share is long enough to hide it — 2^26 paths, like the library's own release, cray_hip.hip) */
+		if (launched == gpus && scene.struct_size && (uint64_t)W * H * (uint64_t)r->prefs.sampleCount / (uint64_t)gpus >= ((uint64_t)1 << 26)) crh_flatten_free(&scene);
 		if (finished == gpus) break;
 		getKeyboardInput(r);
 		drawWindow(r, output);

@@ -172,12 +172,14 @@ static void *makerThread(void *arg) {
 	return NULL;
 }
 
-/* counts the devices (the first HIP call of the process: not on the thread that is about to parse the scene) and starts one maker per device — a scene file that
- * does not say otherwise renders on every GPU of the node (prefs.threadCount defaults to the core count, renderFrame() clamps it to the device count) */
+/* counts the devices (the first HIP call of the process: not on the thread that is about to parse the scene) and starts one maker per device the frame will use:
+ * renderFrame() renders on every visible GPU, CRAY_HIP_DEVICES=n on the first n */
 static void *masterThread(void *arg) {
 	(void)arg;
 	int n = crh_device_count();
 	if (n > MAX_GPUS) n = MAX_GPUS;
+	const char *cap = getenv("CRAY_HIP_DEVICES");          /* the same cap renderFrame() applies: no context on a GPU the frame will not use */
+	if (cap && atoi(cap) > 0 && atoi(cap) < n) n = atoi(cap);
 	if (getenv("CRH_DROPIN_PREFETCH_GPUS") && atoi(getenv("CRH_DROPIN_PREFETCH_GPUS")) < n) n = atoi(getenv("CRH_DROPIN_PREFETCH_GPUS"));
 	for (int g = 0; g < n; ++g) {
 		pthread_mutex_lock(&g_pool.mu);

@@ -508,6 +508,9 @@ struct crh_ctx {
 	bool hasPrograms = true;     /* the compiled scene contains node programs -> kernel variant with runProgram() */
 	bool hasVolumes = false;     /* walks draw from the path's sampler: crh_trace_rays (caller rays, no path) refuses such scenes */
 	DScene d;                              /* device pointers */
+	int walk = CRH_WALK_BINARY;            /* CRH_OPT_WALK: what the NEXT upload prepares and the render kernel walks */
+	bool haveWide = false;                 /* the resident scene has a wide copy of its BVHs (behind the triangles, in the nodes' allocation) */
+	uint32_t wideTlasRoot = 0;             /* ... whose top-level root is this reference (scenes with more than one top-level node) */
 	std::vector<void *> sceneAllocs;
 	unsigned long long *dCounters = nullptr;
 	uint32_t *dWork = nullptr;             /* ring of work counters, one per in-flight launch */
@@ -575,14 +578,37 @@ static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
 	return CRH_OK;
 }
 
+/* the dispatch walks the wide copy: the option is on, the resident scene has one, and neither rare features nor the Halton sampler are in play */
+static bool wideWalk(const crh_ctx *c) {
+	return c->walk == CRH_WALK_WIDE4 && c->haveWide && c->kernel == CRH_KERNEL_ROLL && !c->hasPrograms && c->sampler == CRH_SAMPLER_RANDOM;
+}
+
 /* Launch the instantiation the context's options select (counter level, rare features, sampler; the kernel form in builds that hold more than one). */
 static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_params *P, const BlockQueue &Q, float *dev_fb, int chunk) {
 #define CRH_LAUNCH_ROLL(LEVEL, PROG, SAMP) do { snprintf(c->lastKernel, sizeof(c->lastKernel), "k_pathtrace_roll<%d,4,%s,%d>", LEVEL, PROG ? "true" : "false", SAMP); \
 		hipLaunchKernelGGL((k_pathtrace_roll<LEVEL, 4, PROG, SAMP>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Q, dev_fb, \
 						   c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf, c->dErr); } while (0)
+#define CRH_LAUNCH_ROLL_WIDE(LEVEL) do { snprintf(c->lastKernel, sizeof(c->lastKernel), "k_pathtrace_roll<%d,4,false,0,wide4>", LEVEL); \
+		hipLaunchKernelGGL((k_pathtrace_roll<LEVEL, 4, false, 0, true>), dim3(grid), dim3(CRH_BLOCK), 0, c->stream, dw, *P, Q, dev_fb, \
+						   c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf, c->dErr); } while (0)
 	const bool halton = c->sampler == CRH_SAMPLER_HALTON;
 	(void)halton;
 	if (c->kernel == CRH_KERNEL_ROLL) {
+		/* CRH_OPT_WALK = CRH_WALK_WIDE4 (an option, round 5): scenes without rare features, the random sampler */
+		if (wideWalk(c)) {
+			DScene dw = c->d;
+			if (dw.tlas_node_count > 1u) dw.tlas_root = c->wideTlasRoot;
+#ifdef CRH_DEV_ONLY_BENCH_VARIANT
+#if defined(CRH_DEV_ONLY_LEVEL2)
+			CRH_LAUNCH_ROLL_WIDE(2);
+#else
+			CRH_LAUNCH_ROLL_WIDE(1);
+#endif
+#else
+			if (c->counterLevel >= 2) CRH_LAUNCH_ROLL_WIDE(2); else CRH_LAUNCH_ROLL_WIDE(1);
+#endif
+			return hipGetLastError();
+		}
 #ifdef CRH_DEV_ONLY_BENCH_VARIANT                 /* development builds (tools/build_variant.sh, tools/kernel_regs.py): one instantiation compiles in seconds */
 #if defined(CRH_DEV_ONLY_LEVEL2)              /* the counting instantiation (tools/emu_sched_stats.py) */
 		CRH_LAUNCH_ROLL(2, true, 0);
@@ -603,6 +629,7 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 		return hipGetLastError();
 	}
 #undef CRH_LAUNCH_ROLL
+#undef CRH_LAUNCH_ROLL_WIDE
 #ifdef CRH_WITH_ALT_KERNELS
 	const bool wg = c->kernel == CRH_KERNEL_WG;
 #define CRH_LAUNCH(LEVEL, WPS, PROG, SAMP) do { snprintf(c->lastKernel, sizeof(c->lastKernel), "k_pathtrace<%d,%d,%s,%d>", LEVEL, WPS, PROG ? "true" : "false", SAMP); \
@@ -646,7 +673,7 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 
 /* Load the code object of the selected instantiation now (HIP loads kernels lazily, ~40 ms on first launch) with a launch that finds
  * an empty work queue: crh_scene_upload calls it, so a renderer's first frame is not the one that pays for it. */
-static int variantKey(const crh_ctx *c) { return (c->hasPrograms ? 1 : 0) | (c->sampler << 1) | (c->counterLevel << 2) | (c->wavesPerSimd << 4) | (c->kernel << 8); }
+static int variantKey(const crh_ctx *c) { return (c->hasPrograms ? 1 : 0) | (c->sampler << 1) | (c->counterLevel << 2) | (c->wavesPerSimd << 4) | (c->kernel << 8) | (wideWalk(c) ? 1 << 12 : 0); }
 static int preloadKernel(crh_ctx *c, bool again = false) {
 	crh_render_params P;
 	memset(&P, 0, sizeof(P));
@@ -864,6 +891,9 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 		case CRH_OPT_RENDER_SLABS:
 			if (value != CRH_TRACE_SLABS_LITERAL && value != CRH_TRACE_SLABS_EXACT) return fail(CRH_ERR_INVALID, "render slabs must be CRH_TRACE_SLABS_LITERAL or CRH_TRACE_SLABS_EXACT");
 			c->sched.rayFlags = value == CRH_TRACE_SLABS_LITERAL ? (int)CRH_RAY_LITERAL : 0; return CRH_OK;
+		case CRH_OPT_WALK:
+			if (value != CRH_WALK_BINARY && value != CRH_WALK_WIDE4) return fail(CRH_ERR_INVALID, "walk must be CRH_WALK_BINARY or CRH_WALK_WIDE4");
+			c->walk = (int)value; return CRH_OK;
 		case CRH_OPT_ROUND_LIMIT:
 			if (value < 2 || value > 2000000000) return fail(CRH_ERR_INVALID, "round limit must be 2..2e9 scheduling rounds per wave");
 			c->sched.roundLimit = (int)value; return CRH_OK;
@@ -912,6 +942,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 		hipError_t status = hipSuccess;
 		~TexelJob() { if (thread.joinable()) thread.join(); if (dev) (void)hipFree(dev); }
 	} texelJob;
+	cs.want_wide = c->walk == CRH_WALK_WIDE4;
 	rc = compile_scene(scene, cs, err, [&]() {
 		texelJob.thread = std::thread([&]() {
 			texelJob.status = hipSetDevice(c->device);
@@ -930,14 +961,18 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	{	/* BVH nodes and prepared triangles share ONE allocation — nodes, then (256-byte aligned) triangles, then one record of padding: a fused walk step
 		 * (pathtrace_roll.h) addresses a lane's child pair OR its next two triangles as (S.nodes, a kernel argument in SGPRs) + one 32-bit byte offset, and reads
 		 * the two triangles as six consecutive quarters (the second one unused when the leaf range holds one: at the array's end that is the padding) */
-		const size_t nodeBytes = (cs.nodes.size() * sizeof(f4) + 255u) & ~(size_t)255u, triBytes = cs.tris.size() * sizeof(f4);
-		if (nodeBytes + triBytes + 96u >= (1ull << 32)) { freeScene(c); return fail(CRH_ERR_UNSUPPORTED, "crh_scene_upload: BVH nodes + prepared triangles of 4 GB and more"); }
+		const size_t nodeBytes = sceneNodeBytes(cs), triBytes = cs.tris.size() * sizeof(f4);
+		/* (CRH_OPT_WALK = CRH_WALK_WIDE4: the wide nodes stand behind the padding, 128-byte aligned — scene_compile.h: sceneWideOffset, which their references were made for) */
+		const size_t wideOff = sceneWideOffset(cs), wideBytes = cs.wide.size() * sizeof(f4);
+		const size_t total = wideBytes ? wideOff + wideBytes : nodeBytes + triBytes + 96u;
+		if (total >= (1ull << 32)) { freeScene(c); return fail(CRH_ERR_UNSUPPORTED, "crh_scene_upload: BVH nodes + prepared triangles of 4 GB and more"); }
 		void *p = nullptr;
-		HIP_TRY(hipMalloc(&p, nodeBytes + triBytes + 96u));
+		HIP_TRY(hipMalloc(&p, total));
 		c->sceneAllocs.push_back(p);
-		HIP_TRY(hipMemset((char *)p + nodeBytes + triBytes, 0, 96u));
+		HIP_TRY(hipMemset((char *)p + nodeBytes + triBytes, 0, (wideBytes ? wideOff : total) - nodeBytes - triBytes));
 		if (cs.nodes.size()) HIP_TRY(hipMemcpy(p, cs.nodes.data(), cs.nodes.size() * sizeof(f4), hipMemcpyHostToDevice));
 		if (triBytes) HIP_TRY(hipMemcpy((char *)p + nodeBytes, cs.tris.data(), triBytes, hipMemcpyHostToDevice));
+		if (wideBytes) HIP_TRY(hipMemcpy((char *)p + wideOff, cs.wide.data(), wideBytes, hipMemcpyHostToDevice));
 		d.nodes = (const f4 *)p;
 		d.tris = (const f4 *)((const char *)p + nodeBytes);
 	}
@@ -965,6 +1000,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	d.background = cs.background;
 	{ const crh_camera *cam = nullptr; rc = upload(c, &cs.camera, 1, &cam); if (rc) { freeScene(c); return rc; } d.camera = cam; }
 	c->d = d;
+	c->haveWide = !cs.wide.empty(); c->wideTlasRoot = cs.wide_tlas_root;
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
 	c->hasVolumes = cs.has_volumes;
 	c->haveScene = true;

@@ -36,7 +36,8 @@
 #define CRH_ROLL_ITEM_MASK 0x3FFFFFFFu
 
 
-template <int LEVEL, int WPS, bool PROG, int SAMP>
+/* WIDE (round 5, CRH_OPT_WALK = CRH_WALK_WIDE4): the walk steps through the 4-ary copy of the BVHs (pt_device.h: stepWideLoaded; Sarg.tlas_root is the wide root) */
+template <int LEVEL, int WPS, bool PROG, int SAMP, bool WIDE = false>
 __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(const DScene Sarg, const crh_render_params P, const BlockQueue Q, float *fb,
 																 unsigned long long *counters,
 																 float *stage, int chunk, unsigned long long *waveStats, const Sched K, float *queues, uint32_t *ovfAll, unsigned int *errFlag) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	stk.parkp = (lds_u32 *)&s_park[threadIdx.x];
 	CRH_STAGE_SHADE_TABLES();
 	CRH_STAGE_INSTANCE_TABLES();
-	CountersT<LEVEL, PROG> cnt;
+	CountersT<LEVEL, PROG, WIDE> cnt;
 	memset(&cnt, 0, sizeof(cnt));
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * CRH_BLOCK + threadIdx.x) >> 6;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				int rqRun = raysQ, hqRun = hitsQ, mqRun = missQn;          /* the stack levels as this run's in-place retire / refill steps leave them */
 				f4 q0 = f4{0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;          /* (defined once per run: a lane reads only what it loaded in the same iteration, but an
 				                                                                                            * undefined value that meets a loaded one at every join costs the register allocator 70 spills) */
+				f4 q6 = q0, q7 = q0;          /* (WIDE: a wide node is eight quarters) */
 				do {
 					const bool isN = w.phase == PH_NODE;
 					const int nTw = (int)__popcll(__ballot(w.phase == PH_TRI));
@@ -302,11 +304,14 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					/* one 32-bit byte offset from S.nodes for either kind of record (crh_scene_upload puts the triangles behind the nodes in the same allocation), six
 					 * quarters in the same registers: a child pair is the first four, two triangles (48 bytes each, consecutive) all six */
 					if (isN || isT) {
-						const uint32_t off = isN ? (uint32_t)(w.node << 5) : trisOff + w.pA * 48u;
+						const uint32_t off = isN ? (uint32_t)(w.node << (WIDE ? 4 : 5)) : trisOff + w.pA * 48u;
 						const char *rec = (const char *)S.nodes + off;
 						q0 = *(const f4 *)rec; q1 = *(const f4 *)(rec + 16); q2 = *(const f4 *)(rec + 32); q3 = *(const f4 *)(rec + 48);
-						if (isT) { q4 = *(const f4 *)(rec + 64); q5 = *(const f4 *)(rec + 80); }
+						if (WIDE || isT) { q4 = *(const f4 *)(rec + 64); q5 = *(const f4 *)(rec + 80); }
+						if (WIDE && isN) { q6 = *(const f4 *)(rec + 96); q7 = *(const f4 *)(rec + 112); }
 					}
+					if constexpr (WIDE) { if (isN) stepWideLoaded<true>(S, w, stk, cnt, port, q0, q1, q2, q3, q4, q5, q6, q7); }
+					else
 					if (isN) stepNodeLoaded<true>(S, w, stk, cnt, port, q0, q1, q2, q3);
 					if (isT) stepTriLoaded(S, w, stk, cnt, port, q0, q1, q2, q3, q4, q5);
 					if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 			}
 			case ST_CTRL:
 				if (ph == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
-				if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port); }
+				if (__ballot(ph == PH_NODE_SLOW)) { if (ph == PH_NODE_SLOW) stepNodeAny<false>(S, w, stk, cnt, port); }
 				break;
 			case ST_SWAP: {
 				int rq = raysQ, hq = hitsQ, mq = missQn;

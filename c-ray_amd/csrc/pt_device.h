@@ -130,7 +130,8 @@ struct DScene {
 	const DOp *prog;
 	const DTexture *textures;
 	const f4 *texels;
-	uint32_t tlas_root;         /* device index of the TLAS root's child pair (or of the root leaf if tlas_node_count == 1) */
+	uint32_t tlas_root;         /* device index of the TLAS root's child pair (or of the root leaf if tlas_node_count == 1); for a WIDE walk (round 5, CRH_OPT_WALK) the launch passes
+	                             * the ref of the top-level BVH's wide root here instead (tlas_node_count > 1) */
 	uint32_t tlas_node_count;
 	uint32_t tlas_prim_base;
 	uint32_t background;        /* gnode index of the background bsdf */
@@ -148,10 +149,13 @@ struct DScene {
  * contain no call to runProgram() (a device function call in the persistent loop costs ~200 SGPR spills and
  * the callee's register budget) and no volume code (instance.c:62-92, 187-216: two extra walk states and a sampler draw inside
  * the traversal); the host picks that variant when the compiled scene has neither node programs nor volume instances. */
-template <int LEVEL, bool PROGRAMS> struct CountersT;
-template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
+/* Round 5: the type carries a second compile-time switch, `wide` = the walk steps through the derived 4-ary copy of the BVHs (CRH_OPT_WALK = CRH_WALK_WIDE4, an option;
+ * the binary walk is the contract). Instantiations without it are the code they were. */
+template <int LEVEL, bool PROGRAMS, bool WIDE = false> struct CountersT;
+template <bool PROGRAMS, bool WIDE> struct CountersT<2, PROGRAMS, WIDE> {
 	static constexpr int level = 2;
 	static constexpr bool programs = PROGRAMS;
+	static constexpr bool wide = WIDE;
 	uint32_t rays, node_tests, tri_tests, inst_visits, inst_hits, sphere_tests, tex_fetches, paths;
 	uint32_t t_setup, t_trav, t_shade;   /* debug: wall-clock ticks (100 MHz) this wave spent per phase */
 	uint32_t w_node, w_tri, w_ctrl, w_round, w_shade, w_setup;   /* debug: WAVE-level step counts by kind (lane 0 counts) */
@@ -162,16 +166,17 @@ template <bool PROGRAMS> struct CountersT<2, PROGRAMS> {
 	uint32_t u_wait_tri, u_wait_fin;                                              /* debug (rolling kernel): summed over node steps, the lanes that sat the step out waiting for a triangle step / for a retire + refill */
 #endif
 };
-template <bool PROGRAMS> struct CountersT<1, PROGRAMS> {
+template <bool PROGRAMS, bool WIDE> struct CountersT<1, PROGRAMS, WIDE> {
 	static constexpr int level = 1;
 	static constexpr bool programs = PROGRAMS;
+	static constexpr bool wide = WIDE;
 	uint32_t rays, paths;
 };
 typedef CountersT<2, true> Counters;
 typedef CountersT<1, true> LiteCounters;
-struct NoCounters { static constexpr int level = 0; static constexpr bool programs = true; };
-template <class T> struct cnt_traits { static constexpr int level = T::level; static constexpr bool programs = T::programs; };
-template <class T> struct cnt_traits<T &> { static constexpr int level = T::level; static constexpr bool programs = T::programs; };
+struct NoCounters { static constexpr int level = 0; static constexpr bool programs = true; static constexpr bool wide = false; };
+template <class T> struct cnt_traits { static constexpr int level = T::level; static constexpr bool programs = T::programs; static constexpr bool wide = T::wide; };
+template <class T> struct cnt_traits<T &> { static constexpr int level = T::level; static constexpr bool programs = T::programs; static constexpr bool wide = T::wide; };
 /* CRH_COUNT: detailed counters (level 2); CRH_COUNT1: rays / paths (level >= 1) */
 #define CRH_COUNT(c, field, n) do { if constexpr (crh::cnt_traits<decltype(c)>::level >= 2) (c).field += (n); } while (0)
 #if defined(__HIPCC__)
@@ -899,6 +904,13 @@ CRH_DEV bool intersectNode(const f4 n0, const f4 n1, const RayK &k, float maxDis
 #define CRH_DNODE_COUNT(n1) (asU32((n1).w) & 0x3FFFFFFFu)
 #define CRH_DNODE_ISLEAF(n1) ((int32_t)asU32((n1).w) < 0)
 
+/* The WIDE walk's child references (round 5, CRH_OPT_WALK = CRH_WALK_WIDE4; scene_compile.cpp: buildWide): bit 31 clear = a wide node, its offset from S.nodes in
+ * 16-byte units; bit 31 set = a leaf, count << 25 | first absolute prim slot; CRH_NONE = an unused slot. The same words are the wide walk's stack entries. */
+#define CRH_WREF_LEAF 0x80000000u
+#define CRH_WREF_COUNT_SHIFT 25u
+#define CRH_WREF_COUNT_MAX 63u
+#define CRH_WREF_FIRST_MASK 0x01FFFFFFu
+
 struct TravHit {
 	float t;           /* isect->distance */
 	float u, v;        /* barycentrics of the closest triangle (isect->uv before getTexMapMesh) */
@@ -999,7 +1011,7 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 			CRH_COUNT(cnt, node_tests, 1);
 			if (intersectNode(n0, n1, w.k, w.hit.t, tE)) { w.pA = CRH_DNODE_FIRST(n1); w.pAe = w.pA + CRH_DNODE_COUNT(n1); }
 		} else {
-			w.node = instRoot(inst);
+			w.node = cnt_traits<Cnt>::wide ? asU32(instRadius(inst)) : instRoot(inst);
 		}
 		if (w.pA != w.pAe) { w.phase = PH_TRI; return true; }
 		if (w.node != CRH_NONE) { w.phase = w.k.oct >> CRH_RAY_PHASE_SHIFT; return true; }
@@ -1021,7 +1033,15 @@ CRH_DEV bool volumeAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port 
 template <class Stack, class Cnt, class Port>
 CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
 	if (w.pA != w.pAe) { w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
-	if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
+	if constexpr (cnt_traits<Cnt>::wide) {      /* a wide walk's stack holds leaves too (stepWideLoaded): a popped leaf is the pending range */
+		if (w.node == CRH_NONE && w.sp > w.spBase) {
+			const uint32_t e = stk.pop(--w.sp);
+			if (e & CRH_WREF_LEAF) { w.pA = e & CRH_WREF_FIRST_MASK; w.pAe = w.pA + ((e >> CRH_WREF_COUNT_SHIFT) & CRH_WREF_COUNT_MAX); w.phase = w.inBlas ? PH_TRI : PH_CTRL; return; }
+			w.node = e;
+		}
+	} else {
+		if (w.node == CRH_NONE && w.sp > w.spBase) w.node = stk.pop(--w.sp);
+	}
 	if (w.node != CRH_NONE) { w.phase = w.k.oct >> CRH_RAY_PHASE_SHIFT; return; }
 	if (!w.inBlas) { w.phase = PH_SHADE; return; }                /* TLAS exhausted -> the walk is over */
 	if constexpr (cnt_traits<Cnt>::programs) {       /* volumes exist only in the rare-features instantiations (see CountersT) */
@@ -1040,7 +1060,15 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	w.node = stk.unpark(PK_NODE); w.pA = stk.unpark(PK_PA); w.pAe = stk.unpark(PK_PAE); w.pB = stk.unpark(PK_PB); w.pBe = stk.unpark(PK_PBE);
 	w.spBase = 0;
 	if (w.pA != w.pAe) { w.phase = PH_CTRL; return; }
-	if (w.node == CRH_NONE && w.sp > 0u) w.node = stk.pop(--w.sp);
+	if constexpr (cnt_traits<Cnt>::wide) {
+		if (w.node == CRH_NONE && w.sp > 0u) {
+			const uint32_t e = stk.pop(--w.sp);
+			if (e & CRH_WREF_LEAF) { w.pA = e & CRH_WREF_FIRST_MASK; w.pAe = w.pA + ((e >> CRH_WREF_COUNT_SHIFT) & CRH_WREF_COUNT_MAX); w.phase = PH_CTRL; return; }
+			w.node = e;
+		}
+	} else {
+		if (w.node == CRH_NONE && w.sp > 0u) w.node = stk.pop(--w.sp);
+	}
 	w.phase = (w.node != CRH_NONE) ? (w.k.oct >> CRH_RAY_PHASE_SHIFT) : PH_SHADE;
 }
 
@@ -1097,6 +1125,52 @@ CRH_DEV void stepNode(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 	const char *pair = (const char *)S.nodes + (uint32_t)(w.node << 5);
 	const f4 l0 = *(const f4 *)pair, l1 = *(const f4 *)(pair + 16), r0 = *(const f4 *)(pair + 32), r1 = *(const f4 *)(pair + 48);
 	stepNodeLoaded<FAST>(S, w, stk, cnt, port, l0, l1, r0, r1);
+}
+
+/* WIDE NODE (round 5, an option: DESIGN.md section 7): one step tests the FOUR boxes of a collapsed node — the reference's own boxes, bit for bit, of the binary nodes the
+ * collapse kept — against the same maxDist with the same slab arithmetic, orders the children that are hit by entry distance, continues with the nearest and leaves the
+ * others on the stack, farthest first. A leaf child is an entry like any other: it becomes the pending range when it is the nearest or when it is popped.
+ * What this changes against bvh.c:391-436: the ORDER in which leaves are reached (the reference tests a pair's leaves before it descends, and the nearer of two inner
+ * children first; here every child waits its turn by entry distance) and the boxes that are never tested (the binary nodes the collapse skipped: a child box is inside its
+ * parent's, and the slab test is monotone in the bounds, so a skipped box would have passed whenever one of its children does). The closest hit is the same whenever it
+ * is unique and the reference's own culling is consistent; of two triangles at exactly the same distance the FIRST one tested wins (poly.c:33: t < distance), so an
+ * exact tie may resolve differently — counted, not assumed: tools/wide_walk_study.py. */
+template <bool FAST = true, class Stack, class Cnt, class Port>
+CRH_DEV void stepWideLoaded(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port, const f4 a0, const f4 a1, const f4 b0, const f4 b1, const f4 c0, const f4 c1, const f4 d0, const f4 d1) {
+	float t0, t1, t2, t3;
+	CRH_COUNT(cnt, node_tests, 4);
+	const bool h0 = intersectNode<FAST>(a0, a1, w.k, w.hit.t, t0);
+	const bool h1 = intersectNode<FAST>(b0, b1, w.k, w.hit.t, t1);
+	const bool h2 = intersectNode<FAST>(c0, c1, w.k, w.hit.t, t2);
+	const bool h3 = intersectNode<FAST>(d0, d1, w.k, w.hit.t, t3);
+	const float inf = __builtin_inff();
+	float k0 = h0 ? t0 : inf, k1 = h1 ? t1 : inf, k2 = h2 ? t2 : inf, k3 = h3 ? t3 : inf;
+	uint32_t r0 = h0 ? asU32(a1.z) : CRH_NONE, r1 = h1 ? asU32(b1.z) : CRH_NONE, r2 = h2 ? asU32(c1.z) : CRH_NONE, r3 = h3 ? asU32(d1.z) : CRH_NONE;
+	/* five compare-exchanges: (0,1) (2,3) (0,2) (1,3) (1,2); ascending, misses (inf, CRH_NONE) last; a strict compare keeps slot order among equal distances */
+#define CRH_CSWAP(ka, ra, kb, rb) do { const bool sw_ = kb < ka; const float kt_ = sw_ ? kb : ka; kb = sw_ ? ka : kb; ka = kt_; const uint32_t rt_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rt_; } while (0)
+	CRH_CSWAP(k0, r0, k1, r1); CRH_CSWAP(k2, r2, k3, r3); CRH_CSWAP(k0, r0, k2, r2); CRH_CSWAP(k1, r1, k3, r3); CRH_CSWAP(k1, r1, k2, r2);
+#undef CRH_CSWAP
+	if (r3 != CRH_NONE) stk.push(w.sp++, r3);
+	if (r2 != CRH_NONE) stk.push(w.sp++, r2);
+	if (r1 != CRH_NONE) stk.push(w.sp++, r1);
+	w.node = CRH_NONE;
+	if (r0 != CRH_NONE) {
+		if (r0 & CRH_WREF_LEAF) { w.pA = r0 & CRH_WREF_FIRST_MASK; w.pAe = w.pA + ((r0 >> CRH_WREF_COUNT_SHIFT) & CRH_WREF_COUNT_MAX); }
+		else w.node = r0;
+	}
+	walkAdvance(S, w, stk, cnt, port);
+}
+template <bool FAST = true, class Stack, class Cnt, class Port>
+CRH_DEV void stepWide(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
+	const char *rec = (const char *)S.nodes + (uint32_t)(w.node << 4);
+	const f4 a0 = *(const f4 *)rec, a1 = *(const f4 *)(rec + 16), b0 = *(const f4 *)(rec + 32), b1 = *(const f4 *)(rec + 48);
+	const f4 c0 = *(const f4 *)(rec + 64), c1 = *(const f4 *)(rec + 80), d0 = *(const f4 *)(rec + 96), d1 = *(const f4 *)(rec + 112);
+	stepWideLoaded<FAST>(S, w, stk, cnt, port, a0, a1, b0, b1, c0, c1, d0, d1);
+}
+/* the node step of a walk whose form the counter type names */
+template <bool FAST, class Stack, class Cnt, class Port>
+CRH_DEV void stepNodeAny(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port) {
+	if constexpr (cnt_traits<Cnt>::wide) stepWide<FAST>(S, w, stk, cnt, port); else stepNode<FAST>(S, w, stk, cnt, port);
 }
 
 /* TRI: poly.c:17-53 on the prepared record (one triangle per step) */
@@ -1196,7 +1270,7 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
 			stk.park(PK_OCT, w.k.oct);
 			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
-			else { w.node = instRoot(inst); w.pA = w.pAe = 0; }
+			else { w.node = cnt_traits<Cnt>::wide ? asU32(instRadius(inst)) /* a mesh's wide root stands where a sphere's radius does */ : instRoot(inst); w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;
 			w.spBase = w.sp; w.inBlas = BLAS_SOLID; w.instFound = 0; w.curInst = idx; w.k = ko;
 			if (__builtin_expect(volume, 0)) {                                /* instance.c:188-196: the entry walk runs on a copy of the record */
@@ -1215,8 +1289,8 @@ CRH_DEV void traverse(const DScene &S, Stack &stk, const v3 rayO, const v3 rayD,
 	NullPort port;                    /* caller rays have no path: scenes with volumes are refused before this runs */
 	walkBegin(S, w, stk, rayO, rayD, cnt, port, rayFlags);
 	while (w.phase != PH_SHADE) {
-		if (w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
-		else if (w.phase == PH_NODE_SLOW) stepNode<false>(S, w, stk, cnt, port);
+		if (w.phase == PH_NODE) stepNodeAny<true>(S, w, stk, cnt, port);
+		else if (w.phase == PH_NODE_SLOW) stepNodeAny<false>(S, w, stk, cnt, port);
 		else if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
 		else stepCtrl(S, w, stk, cnt, port);
 	}
@@ -1434,8 +1508,8 @@ CRH_DEV void renderItems(const DScene &S, const crh_render_params &P, Stack &stk
 	for (;;) {
 		switch (w.phase) {
 			case PH_SETUP: stepSetup(S, P, J, laneStride, w, lp, stk, stage, cnt); break;
-			case PH_NODE: stepNode<true>(S, w, stk, cnt, port); break;
-			case PH_NODE_SLOW: stepNode<false>(S, w, stk, cnt, port); break;
+			case PH_NODE: stepNodeAny<true>(S, w, stk, cnt, port); break;
+			case PH_NODE_SLOW: stepNodeAny<false>(S, w, stk, cnt, port); break;
 			case PH_TRI: stepTri(S, w, stk, cnt, port); break;
 			case PH_CTRL: stepCtrl(S, w, stk, cnt, port); break;
 			case PH_SHADE: stepShade(S, P, w, lp, stk, stage, cnt); break;

@@ -73,6 +73,78 @@ struct Compiler {
 	/* root = device index of the root's child pair (node_count > 1) or of the root leaf itself (node_count == 1) */
 	struct BvhInfo { uint32_t dev_base; uint32_t depth; uint32_t root; };
 
+	/* ---- CRH_OPT_WALK = CRH_WALK_WIDE4: the 4-ary copy of one BVH (scene_compile.h: CompiledScene::wide) ---- */
+	/* rootPair = device index of the binary root's left child (BvhInfo::root of a BVH with more than one node). Returns the wide root's index in out.wide (in nodes of
+	 * 8 x f4); refs are written as such indices with CRH_WIDE_LOCAL set and made absolute by finishWide() once the arrays' sizes are final. Sibling wide nodes are
+	 * allocated side by side, then the first sibling's children, ... (depth first). */
+	static constexpr uint32_t CRH_WIDE_LOCAL = 0x40000000u;
+	uint32_t wideDepthMax = 0;
+	static float halfArea(const f4 &a, const f4 &b) {
+		const float dx = a.y - a.x, dy = a.w - a.z, dz = b.y - b.x;
+		return dx * dy + dy * dz + dz * dx;
+	}
+	uint32_t buildWide(uint32_t rootPair, const char *what) {
+		struct Job { uint32_t pair; uint32_t slot; uint32_t depth; };
+		std::vector<Job> todo;
+		const uint32_t rootSlot = (uint32_t)(out.wide.size() / 8);
+		out.wide.resize(out.wide.size() + 8);
+		todo.push_back(Job{rootPair, rootSlot, 1});
+		uint32_t depthMax = 0;
+		while (!todo.empty()) {
+			const Job j = todo.back(); todo.pop_back();
+			depthMax = std::max(depthMax, j.depth);
+			uint32_t kids[4] = {j.pair, j.pair + 1, 0, 0};
+			int n = 2;
+			auto isLeaf = [&](uint32_t c) { return CRH_DNODE_ISLEAF(out.nodes[(size_t)c * 2 + 1]); };
+			while (n < 4) {          /* the inner child with the largest surface makes room for its two children, in its place */
+				int best = -1; float bestA = -1.0f;
+				for (int i = 0; i < n; ++i) if (!isLeaf(kids[i])) { const float a = halfArea(out.nodes[(size_t)kids[i] * 2], out.nodes[(size_t)kids[i] * 2 + 1]); if (best < 0 || a > bestA) { best = i; bestA = a; } }
+				if (best < 0) break;
+				const uint32_t first = CRH_DNODE_FIRST(out.nodes[(size_t)kids[best] * 2 + 1]);
+				for (int i = n; i > best + 1; --i) kids[i] = kids[i - 1];
+				kids[best] = first; kids[best + 1] = first + 1;
+				++n;
+			}
+			int inner = 0;
+			for (int i = 0; i < n; ++i) if (!isLeaf(kids[i])) ++inner;
+			const uint32_t firstKid = (uint32_t)(out.wide.size() / 8);
+			if (inner) out.wide.resize(out.wide.size() + (size_t)inner * 8);
+			f4 *rec = out.wide.data() + (size_t)j.slot * 8;
+			int k = 0;
+			for (int i = 0; i < 4; ++i) {
+				const float inf = __builtin_inff();
+				if (i >= n) { rec[2 * i] = f4{inf, inf, inf, inf}; rec[2 * i + 1] = f4{inf, inf, asF32(CRH_NONE), 0.0f}; continue; }          /* min = max = +inf: no regular ray hits it */
+				const f4 a = out.nodes[(size_t)kids[i] * 2], b = out.nodes[(size_t)kids[i] * 2 + 1];
+				uint32_t ref;
+				if (isLeaf(kids[i])) {
+					const uint32_t first = CRH_DNODE_FIRST(b), count = CRH_DNODE_COUNT(b);
+					CHECK(count <= CRH_WREF_COUNT_MAX && first <= CRH_WREF_FIRST_MASK, CRH_ERR_UNSUPPORTED, "%s: a leaf of %u primitives at slot %u does not fit a wide reference", what, count, first);
+					ref = count ? (CRH_WREF_LEAF | (count << CRH_WREF_COUNT_SHIFT) | first) : CRH_NONE;          /* (an empty leaf — bvh.c:220 can make one — is an unused slot) */
+				} else {
+					ref = CRH_WIDE_LOCAL | (firstKid + (uint32_t)k);
+					todo.push_back(Job{CRH_DNODE_FIRST(b), firstKid + (uint32_t)k, j.depth + 1});
+					++k;
+				}
+				rec[2 * i] = a; rec[2 * i + 1] = f4{b.x, b.y, asF32(ref), 0.0f};
+			}
+			/* (the jobs were pushed first child first: reverse them so that the first child's subtree is laid out next) */
+			std::reverse(todo.end() - k, todo.end());
+		}
+		wideDepthMax = std::max(wideDepthMax, depthMax);
+		return rootSlot;
+	}
+	uint32_t wideAbs(uint32_t localSlot) const { return (uint32_t)((sceneWideOffset(out) >> 4) + (size_t)localSlot * 8u); }
+	void finishWide() {
+		CHECK(sceneWideOffset(out) + out.wide.size() * sizeof(f4) < (1ull << 32), CRH_ERR_UNSUPPORTED, "BVH nodes + prepared triangles + wide nodes of 4 GB and more");
+		parallelFor(out.wide.size() / 2, 1u << 14, [&](size_t b0, size_t e0) {
+			for (size_t i = b0; i < e0; ++i) {
+				f4 &q = out.wide[2 * i + 1];
+				const uint32_t r = asU32(q.z);
+				if (r != CRH_NONE && !(r & CRH_WREF_LEAF) && (r & CRH_WIDE_LOCAL)) q.z = asF32(wideAbs(r & ~CRH_WIDE_LOCAL));
+			}
+		});
+	}
+
 	BvhInfo relayoutBvh(uint32_t node_base, uint32_t node_count, uint32_t prim_base, uint32_t prim_count, const char *what) {
 		BvhInfo info{0, 0, 0};
 		if (out.nodes.size() % 4) out.nodes.resize(out.nodes.size() + 2, f4{0, 0, 0, 0});   /* even device node index */
@@ -515,6 +587,29 @@ struct Compiler {
 		}
 		assignShadeClasses();
 		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: TLAS + instances + classes %.1f ms\n", lap());
+		if (out.nodes.empty()) out.nodes.resize(4, f4{0, 0, 0, 0});
+		if (out.want_wide) {
+			try {
+				std::vector<uint32_t> wideRoot(s->mesh_count, CRH_NONE);
+				uint32_t blasDepth = 0;
+				for (uint64_t m = 0; m < s->mesh_count; ++m) if (s->meshes[m].node_count > 1) { wideDepthMax = 0; wideRoot[m] = buildWide(meshBvh[m].root, "BLAS"); blasDepth = std::max(blasDepth, wideDepthMax); }
+				uint32_t tlasWide = CRH_NONE;
+				wideDepthMax = 0;
+				if (s->tlas_node_count > 1) tlasWide = buildWide(tlas.root, "TLAS");
+				out.wide_max_stack = 3u * (wideDepthMax + blasDepth) + 1u;
+				finishWide();
+				if (tlasWide != CRH_NONE) out.wide_tlas_root = wideAbs(tlasWide);
+				for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {
+					const crh_instance &in = s->instances[out.instances[k].orig];
+					if ((in.kind == CRH_INSTANCE_MESH || in.kind == CRH_INSTANCE_MESH_VOLUME) && wideRoot[in.object] != CRH_NONE) out.instances[k].radius = asF32(wideAbs(wideRoot[in.object]));
+				}
+				if (out.wide.empty()) out.wide.resize(8, f4{0, 0, 0, 0});
+			} catch (const Fail &f) {
+				out.wide.resize(0); out.wide_refused = f.msg;
+				for (uint32_t k = 0; k < s->tlas_prim_count; ++k) if (CRH_DINST_KIND(out.instances[k].kind) != CRH_DINST_SPHERE) out.instances[k].radius = 0.0f;
+			}
+			if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: wide BVH copy %.1f ms (%zu wide nodes%s%s)\n", lap(), out.wide.size() / 8, out.wide_refused.empty() ? "" : "; refused: ", out.wide_refused.c_str());
+		}
 		for (uint64_t i = 0; i < s->instance_count; ++i) {           /* instances outside the TLAS (none with the reference's builder) are still validated */
 			const crh_instance &in = s->instances[i];
 			CHECK(in.kind <= CRH_INSTANCE_MESH_VOLUME, CRH_ERR_UNSUPPORTED, "unknown instance kind %u", in.kind);

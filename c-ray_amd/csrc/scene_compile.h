@@ -94,9 +94,24 @@ struct CompiledScene {
 	uint32_t tlas_first = 0;    /* device index of TLAS node 1 (the TLAS nodes are contiguous: node i at tlas_first - 1 + i) */
 	uint32_t max_stack = 0;     /* worst-case traversal stack entries (TLAS depth + saved TLAS state + deepest BLAS) */
 	uint32_t max_add_depth = 0;
+	/* CRH_OPT_WALK = CRH_WALK_WIDE4 (round 5, an OPTION: the binary walk over `nodes` stays the contract): a derived 4-ary copy of every BVH with at least one inner
+	 * node, collapsed from the reference's binary tree (the inner child with the largest surface is replaced by its two children until four children stand; the boxes are
+	 * the binary nodes' own bits). A wide node = 4 x 32 B: {minx, maxx, miny, maxy} {minz, maxz, ref, 0}; ref = CRH_NONE for an unused slot (its box is never hit), the
+	 * child wide node's offset from the start of `nodes` in 16-byte units (bit 31 clear), or a leaf: CRH_WREF_LEAF | count << 25 | first absolute prim slot.
+	 * In the device allocation the array stands behind the triangles (sceneWideOffset). Empty when not asked for, or when the scene cannot be encoded (wide_refused). */
+	PodBuf<f4> wide;
+	uint32_t wide_tlas_root = 0;    /* ref of the top-level BVH's wide root (tlas_node_count > 1) */
+	uint32_t wide_max_stack = 0;    /* worst-case stack entries of the wide walk: three per level */
+	bool want_wide = false;         /* in: build `wide` */
+	std::string wide_refused;       /* why `wide` is empty although it was asked for */
 	bool has_volumes = false;   /* some instance is a sphere / mesh volume: walks draw from the path's sampler (no crh_trace_rays) */
 	crh_camera camera;
 };
+
+/* where the arrays stand in the ONE device allocation the walk addresses with 32-bit offsets from `nodes` (crh_scene_upload; tests/emu builds the same block):
+ * nodes, (256-byte aligned) prepared triangles, 96 bytes of padding, (128-byte aligned) the wide nodes */
+inline size_t sceneNodeBytes(const CompiledScene &c) { return (c.nodes.size() * sizeof(f4) + 255u) & ~(size_t)255u; }
+inline size_t sceneWideOffset(const CompiledScene &c) { return (sceneNodeBytes(c) + c.tris.size() * sizeof(f4) + 96u + 127u) & ~(size_t)127u; }
 
 /* Returns CRH_OK or a negative CRH_ERR_* with a message in `err`. */
 /* texelsReady (optional) is called — on the compiling thread — as soon as out.textures / out.texels are final, while the BVHs and triangles are still to be prepared: the

@@ -318,6 +318,14 @@ int crh_context_prepare(crh_ctx *ctx);
 #define CRH_OPT_RENDER_SLABS 18   /* the render kernels and rays with a zero / denormal direction component: CRH_TRACE_SLABS_EXACT (default: see CRH_OPT_TRACE_SLABS) or
                                    * CRH_TRACE_SLABS_LITERAL = the reference's NaN arithmetic followed literally (bvh.c:326-352) — the same node visits as the reference for
                                    * every ray of the frame, at the reference's price for such a ray: a walk of most of the scene with the rest of its wave waiting */
+#define CRH_OPT_WALK         19   /* round 5, an EXPERIMENT kept as an option (set before crh_scene_upload): CRH_WALK_BINARY (default, the contract) = the reference's walk over the
+                                   * reference's binary tree, node for node (bvh.c:354-441); CRH_WALK_WIDE4 = the render kernel steps through a derived 4-ary copy of every BVH
+                                   * (the same boxes, bit for bit; half the dependent round trips), which reaches leaves in another ORDER: the closest hit is the same
+                                   * except where two triangles are hit at exactly the same distance (poly.c:33 keeps the first one tested) or where the reference's own
+                                   * culling is inconsistent by a rounding error — counted, not assumed (one ray in 4e5 on statues.json). Node-test
+                                   * counts are the wide walk's own. Scenes with node programs / volumes, the Halton sampler and crh_trace_rays keep the binary walk */
+#define CRH_WALK_BINARY 0
+#define CRH_WALK_WIDE4  1
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);

@@ -29,16 +29,32 @@ struct ArrayStack {
 	void park(int i, uint32_t v) { pk[i] = v; }
 	uint32_t unpark(int i) { return pk[i]; }
 };
-DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c) {
+/* CRH_OPT_WALK = CRH_WALK_WIDE4 in the lane emulation (emu_set_walk(1)): nodes, triangles and the wide nodes in ONE block, laid out as crh_scene_upload lays them out
+ * (scene_compile.h: sceneWideOffset) — a wide reference is an offset from the start of the nodes */
+int g_wide;
+uint32_t g_stack_high;
+typedef CountersT<2, true, true> WideCounters;
+struct WideBlock {
+	std::vector<char> mem;
+	void build(const CompiledScene &c) {
+		mem.assign(sceneWideOffset(c) + c.wide.size() * sizeof(f4) + 256, 0);
+		memcpy(mem.data(), c.nodes.data(), c.nodes.size() * sizeof(f4));
+		memcpy(mem.data() + sceneNodeBytes(c), c.tris.data(), c.tris.size() * sizeof(f4));
+		memcpy(mem.data() + sceneWideOffset(c), c.wide.data(), c.wide.size() * sizeof(f4));
+	}
+};
+DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c, const WideBlock *wb = nullptr) {
 	DScene d;
 	memset(&d, 0, sizeof(d));
 	d.nodes = c.nodes.data(); d.tris = c.tris.data(); d.prims = s->prim_indices; d.shade = c.shade.data();
+	if (wb) { d.nodes = (const f4 *)wb->mem.data(); d.tris = (const f4 *)(wb->mem.data() + sceneNodeBytes(c)); }
 	d.instances = c.instances.data(); d.materials = c.materials.data();
 	d.bsdfs = c.bsdfs.data(); d.consts = c.consts.data(); d.images = c.images.data(); d.prog = c.prog.data();
 	d.textures = c.textures.data(); d.texels = c.texels.data();
 	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base; d.tlas_first = c.tlas_first;
 	d.material_count = (uint32_t)c.materials.size(); d.bsdf_count = (uint32_t)c.bsdfs.size(); d.const_count = (uint32_t)c.consts.size(); d.image_count = (uint32_t)c.images.size(); d.texture_count = (uint32_t)c.textures.size();
 	d.background = c.background; d.camera = &c.camera;
+	if (wb && c.tlas_node_count > 1) d.tlas_root = c.wide_tlas_root;
 	return d;
 }
 std::string g_err;
@@ -63,13 +79,20 @@ int emu_compile_check(const crh_scene_desc *scene, uint32_t *max_stack, uint32_t
 static int g_halton;
 void emu_set_sampler(int halton) { g_halton = halton ? 1 : 0; }     /* 0 Random (renderThread), 1 Halton (renderThreadInteractive) */
 
+void emu_set_walk(int wide) { g_wide = wide ? 1 : 0; }
+uint32_t emu_stack_high(int reset) { const uint32_t h = g_stack_high; if (reset) g_stack_high = 0; return h; }     /* deepest stack of the emu_trace_rays walks since the last reset */              /* 0 the binary walk (the contract), 1 CRH_WALK_WIDE4 */
+
 int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, float *fb, crh_counters *out, uint32_t *stack_high,
 					  int bw, int bh, int chunk) {
 	CompiledScene c;
+	c.want_wide = g_wide != 0;
 	int rc = compile_scene(scene, c, g_err);
 	if (rc != CRH_OK) return rc;
+	if (g_wide && c.wide.empty()) { g_err = "no wide copy: " + c.wide_refused; return CRH_ERR_UNSUPPORTED; }
 	if (bw <= 0 || bh <= 0 || bw * bh > 256 || chunk <= 0) { g_err = "bad block shape"; return CRH_ERR_INVALID; }
-	const DScene d = make_dscene(scene, c);
+	WideBlock wb;
+	if (g_wide) wb.build(c);
+	const DScene d = make_dscene(scene, c, g_wide ? &wb : nullptr);
 	crh_counters total;
 	memset(&total, 0, sizeof(total));
 	uint32_t high = 0;
@@ -79,6 +102,8 @@ int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, f
 	{
 		Counters cnt;
 		memset(&cnt, 0, sizeof(cnt));
+		WideCounters wcnt;
+		memset(&wcnt, 0, sizeof(wcnt));
 		crh_counters mine;
 		memset(&mine, 0, sizeof(mine));
 		uint32_t myHigh = 0;
@@ -93,12 +118,14 @@ int emu_render_region(const crh_scene_desc *scene, const crh_render_params *p, f
 				J.passBegin = c0; J.passCount = std::min(chunk, p->first_pass + p->pass_count - c0);
 				for (uint32_t lane = 0; lane < 64; ++lane) {
 					ArrayStack stk;
-					if (g_halton) renderItems<HaltonRng>(d, *p, stk, J, lane, 64u, stage.data(), cnt);
+					if (g_wide) { if (g_halton) renderItems<HaltonRng>(d, *p, stk, J, lane, 64u, stage.data(), wcnt); else renderItems<Rng>(d, *p, stk, J, lane, 64u, stage.data(), wcnt); }
+					else if (g_halton) renderItems<HaltonRng>(d, *p, stk, J, lane, 64u, stage.data(), cnt);
 					else renderItems<Rng>(d, *p, stk, J, lane, 64u, stage.data(), cnt);
 					if (stk.high > myHigh) myHigh = stk.high;
 				}
 				for (uint32_t pix = 0; pix < (uint32_t)(bw * bh); ++pix) foldBlockPixel(*p, J, pix, stage.data(), fb);
 			}
+			if (g_wide) { memcpy(&cnt, &wcnt, sizeof(cnt)); memset(&wcnt, 0, sizeof(wcnt)); }
 			mine.paths += cnt.paths; mine.rays += cnt.rays; mine.node_tests += cnt.node_tests; mine.tri_tests += cnt.tri_tests;
 			mine.inst_visits += cnt.inst_visits; mine.inst_hits += cnt.inst_hits; mine.sphere_tests += cnt.sphere_tests; mine.tex_fetches += cnt.tex_fetches;
 			memset(&cnt, 0, sizeof(cnt));
@@ -119,9 +146,13 @@ int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, c
 	for (uint64_t i = 0; scene && i < scene->instance_count; ++i)     /* like crh_trace_rays: caller rays have no sampler for a volume to draw from */
 		if (scene->instances[i].kind == CRH_INSTANCE_SPHERE_VOLUME || scene->instances[i].kind == CRH_INSTANCE_MESH_VOLUME) { g_err = "volumes"; return CRH_ERR_UNSUPPORTED; }
 	CompiledScene c;
+	c.want_wide = g_wide != 0;
 	int rc = compile_scene(scene, c, g_err);
 	if (rc != CRH_OK) return rc;
-	const DScene d = make_dscene(scene, c);
+	if (g_wide && c.wide.empty()) { g_err = "no wide copy: " + c.wide_refused; return CRH_ERR_UNSUPPORTED; }
+	WideBlock wb;
+	if (g_wide) wb.build(c);
+	const DScene d = make_dscene(scene, c, g_wide ? &wb : nullptr);
 	#pragma omp parallel for schedule(static)
 	for (int64_t i = 0; i < (int64_t)n; ++i) {
 		ArrayStack stk;
@@ -129,7 +160,12 @@ int emu_trace_rays(const crh_scene_desc *scene, const float *rays, uint64_t n, c
 		memset(&cnt, 0, sizeof(cnt));
 		const v3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, dd{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
 		TravHit h;
-		traverse(d, stk, o, dd, h, cnt);          /* the render kernels' walk: degenerate slabs tested exactly (crh_trace_rays' CRH_TRACE_SLABS_EXACT) */
+		if (g_wide) { WideCounters wc; memset(&wc, 0, sizeof(wc)); traverse(d, stk, o, dd, h, wc); memcpy(&cnt, &wc, sizeof(cnt)); }
+		else traverse(d, stk, o, dd, h, cnt);          /* the render kernels' walk: degenerate slabs tested exactly (crh_trace_rays' CRH_TRACE_SLABS_EXACT) */
+		if (stk.high > g_stack_high) {
+			#pragma omp critical
+			if (stk.high > g_stack_high) g_stack_high = stk.high;
+		}
 		crh_hit *oh = &hits[i];
 		memset(oh, 0, sizeof(*oh));
 		oh->inst = h.inst < 0 ? -1 : (int32_t)d.instances[h.inst].orig; oh->distance = h.t; oh->node_tests = cnt.node_tests; oh->tri_tests = cnt.tri_tests;

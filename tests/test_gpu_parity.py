@@ -129,6 +129,61 @@ def test_sampler_key_wraps_at_4k_2048spp(pkg, ctx, oracle):
     assert not img[mask].any()
 
 
+def test_cfg3_full_width_strip_seeded_for_1024_passes(pkg, ctx, oracle):
+    """configs[2] (venus.json, 1920x1080, 1024 spp, 32 bounces) at its REAL frame size and sampler seeds: a full-width 8-row strip, the first two of maxPasses = 1024
+    passes, against the oracle float for float (round 5: until then the driver-run suite held this config at 320x180 only; the seed of a (pixel, pass) depends on
+    the frame's width and on maxPasses, sampler.c:42)."""
+    blob = built_blob("cfg3_venus")
+    w, h, b = 1920, 1080, 32
+    region = (0, 500, w, 508)
+    ctx.upload(pkg.api.Scene(blob))
+    fb = ctx.framebuffer(w, h)
+    ctx.reset_counters()
+    ctx.render_region(fb, w, h, 1024, b, first_pass=0, pass_count=2, region=region)
+    img, cnt = ctx.download(fb, w, h), ctx.counters()
+    oscene = oracle.OracleScene(blob)
+    ref = np.zeros((h, w, 3), np.float32)
+    _, ocnt = oracle.render(oscene, w, h, 1024, b, region=region, first_pass=0, pass_count=2, fb=ref)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).sum())
+    assert cnt["rays"] == ocnt["rays"] and cnt["rays"] > 2 * w * 8
+    assert img[h - 508:h - 500].any()
+
+
+def test_cfg4_rank_share_strips_at_full_size(pkg, ctx, oracle):
+    """The multi-GPU share at configs[3]'s real size, pixel for pixel (round 5): rank 3 of 8's strips — 4-row strips, strip i to rank i mod 8 (render.py: owned_tiles, the C
+    host's share.h) — of statues.json at 3840x2160, handed to crh_render_tiles as that rank would hand them; two of them (8 full-width rows, the first two of 2048
+    passes) are held against the oracle float for float, and no pixel outside the rank's share is touched."""
+    render = pkg.render
+    blob = built_blob("cfg4_statues")
+    w, h, b = 3840, 2160, 30
+    mine = render.owned_tiles(w, h, 64, 64, 0, 3, 8)
+    assert len(mine) == (h // render.STRIP_ROWS) // 8 + (1 if 3 < (h // render.STRIP_ROWS) % 8 else 0) and all(t[0] == 0 and t[2] == w for t in mine)
+    picked = [mine[len(mine) // 2], mine[len(mine) // 2 + 1]]          # two strips of the share, 32 rows apart
+    ctx.upload(pkg.api.Scene(blob))
+    fb = ctx.framebuffer(w, h)
+    ctx.reset_counters()
+    ctx.render_tiles(fb, w, h, 2048, b, picked, first_pass=0, pass_count=2)
+    img, cnt = ctx.download(fb, w, h), ctx.counters()
+    oscene = oracle.OracleScene(blob)
+    ref = np.zeros((h, w, 3), np.float32)
+    rays = 0
+    for t in picked:
+        _, ocnt = oracle.render(oscene, w, h, 2048, b, region=t, first_pass=0, pass_count=2, fb=ref)
+        rays += ocnt["rays"]
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).sum())
+    assert cnt["rays"] == rays
+    rows = np.zeros(h, bool)
+    for (_, y0, _, y1) in picked:
+        rows[h - y1:h - y0] = True
+    assert img[rows].any() and not img[~rows].any()
+    # ... and the whole share is a disjoint cover with the other ranks' (host logic; the gloo tests assemble the frame)
+    seen = np.zeros(h, np.int32)
+    for r in range(8):
+        for (_, y0, _, y1) in render.owned_tiles(w, h, 64, 64, 0, r, 8):
+            seen[y0:y1] += 1
+    assert (seen == 1).all()
+
+
 def test_shade_class_batches_change_nothing(pkg, ctx, manifest, golden_blob, golden_ref):
     """CRH_OPT_SHADE_SORT: scenes with at least that many shade classes (instances whose hits run the same surface-shader code path) shade their hits in batches
     of few classes; which hits share a batch is pure scheduling. hdr.json at 320x180 (six classes) and the node zoo (dozens of graphs, the

@@ -97,6 +97,16 @@ def test_soup_10m(pkg, oracle, tmp_path):
     assert info["triangles"] == n and info["nodes"] > n // 2
     scene = pkg.api.Scene(out)
     oscene = oracle.OracleScene(out)
+    # the GPU-built tree IS the reference's (round 5: until then only tests/test_bvh_build.py's meshes of up to 1 M triangles held the builder to that; here the same blob
+    # went to the GPU and to the oracle, and a wrong-but-valid tree would have passed): the restated reference builder (oracle/bvh_oracle.c, pinned against the
+    # reference's own trees inside every fixture blob) on the same 10 M polygons — 13 s of one core — node for node, bit for bit, prim order included
+    from test_bvh_build import assert_same_bvh, mesh_views
+    d = scene.desc
+    gpu_nodes, gpu_prims, polys, count = mesh_views(d, 0)
+    assert count == n
+    ref_nodes, ref_prims = oracle.bvh_build_triangles(polys, C.cast(d.vertices, C.c_void_p).value, count)
+    assert_same_bvh(gpu_nodes, gpu_prims, ref_nodes, ref_prims, ("soup", n))
+    del ref_nodes, ref_prims
     ctx = pkg.api.Context(0)
     ctx.upload(scene)
     w, h = 2560, 1440

@@ -1,6 +1,7 @@
 #!/bin/bash
 # pmc_deep.sh TAG [render_once options ...] — ONE GPU call: the counters DESIGN.md section 7(c) listed as never collected, for the default
-# kernel on three workloads (cfg2 at 64 spp, statues at 4 spp, the 1 M soup at 8 spp). One rocprofv3 --pmc pass per counter group
+# kernel on four workloads (cfg2 at 64 spp, statues at 4 spp, the 1 M soup at 8 spp and — round 5 — the 10 M soup at 8 spp, the one scene larger than the Infinity
+# Cache: its blob is built on the box first). PMC_WORKLOADS="soup10m cfg2" / PMC_GROUPS="waits insts" restrict the passes. One rocprofv3 --pmc pass per counter group
 # (tools/render_once.py, no torch: ~4 s per pass); a group that does not fit the block's slots fails alone (its log says so).
 #   waits     where wave cycles go: parked on s_waitcnt, issue-stalled, issuing (SQ_WAIT_ANY + SQ_WAIT_INST_ANY + SQ_ACTIVE_INST_ANY = SQ_WAVE_CYCLES)
 #   insts     instruction mix (VALU / SALU / SMEM / VMEM read, write / LDS) + average VMEM instructions in flight
@@ -16,12 +17,17 @@ OPTS="$*"
 cd "$(dirname "$0")/.." || exit 1
 R=$(pwd); OUT=$R/gpurun_out/pmc_deep_$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp
+if [ ! -f "$R/scenes/_built/soup_10m.blob" ] && { [ -z "$PMC_WORKLOADS" ] || [[ " $PMC_WORKLOADS " == *" soup10m "* ]]; }; then
+	python "$R/tools/make_soup_blob.py" 10000000 "$R/scenes/_built/soup_10m.blob" > "$OUT/make_soup_10m.log" 2>&1 || echo "soup_10m.blob: build failed"
+fi
 cd /tmp || exit 1
 while read -r wl scene w h spp b; do
 	[ -z "$wl" ] && continue
+	[ -n "$PMC_WORKLOADS" ] && [[ " $PMC_WORKLOADS " != *" $wl "* ]] && continue
 	[ -f "$R/scenes/_built/$scene.blob" ] || continue
 	while read -r grp ctrs; do
 		[ -z "$grp" ] && continue
+		[ -n "$PMC_GROUPS" ] && [[ " $PMC_GROUPS " != *" $grp "* ]] && continue
 		d=$OUT/$wl; mkdir -p "$d"
 		# shellcheck disable=SC2086
 		timeout 60 rocprofv3 --pmc $ctrs -d "$d" -o "$grp" -- python "$R/tools/render_once.py" $scene $w $h $spp $b $OPTS > "$d/$grp.log" 2>&1
@@ -43,4 +49,5 @@ done <<'WORKLOADS'
 cfg2 cfg2_hdr 1280 720 64 8
 statues cfg4_statues 3840 2160 4 30
 soup1m soup_1m 2560 1440 8 8
+soup10m soup_10m 2560 1440 8 8
 WORKLOADS

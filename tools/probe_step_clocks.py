@@ -12,8 +12,12 @@ if os.environ.get("PROBE_KERNEL"):          # 0: the one-unit-at-a-time form, 2:
 only = sys.argv[1:]          # optional scene names
 # PROBE_SPP=256 PROBE_UNIT_ITEMS=2048,512: the passes per pixel and the work-unit sizes (one run each) instead of the defaults
 units = [int(v) for v in os.environ["PROBE_UNIT_ITEMS"].split(",")] if os.environ.get("PROBE_UNIT_ITEMS") else [None]
-for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("cfg3_venus", 1920, 1080, 16, 32), ("soup_1m", 2560, 1440, 16, 8)):
+if os.environ.get("PROBE_WALK"):            # 1: CRH_OPT_WALK = CRH_WALK_WIDE4 (round 5)
+    ctx.set_option(abi.OPT_WALK, int(os.environ["PROBE_WALK"]))
+for name, w, h, spp, b in (("cfg2_hdr", 1280, 720, 64, 8), ("cfg3_venus", 1920, 1080, 16, 32), ("cfg4_statues", 3840, 2160, 4, 30), ("soup_1m", 2560, 1440, 16, 8), ("soup_10m", 2560, 1440, 8, 8)):
   if only and name not in only:
+      continue
+  if not os.path.exists(os.path.join(BUILT, name + ".blob")):          # (soup_10m.blob is built on the GPU box: tools/make_soup_blob.py)
       continue
   if os.environ.get("PROBE_SPP"): spp = int(os.environ["PROBE_SPP"])
   scene = api.Scene(os.path.join(BUILT, name + ".blob"))

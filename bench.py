@@ -41,8 +41,11 @@ WORKLOADS["soup10m"] = {"scene": None, "blob": "soup_10m", "width": 2560, "heigh
                         "what": "synthetic 10 M-triangle soup {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[4] at its real size; the 1.04 GB scene is built on this box by "
                                 "tools/make_soup_blob.py: gen_soup's triangles as the reference's loader reads them + the GPU BVH builder, the reference's tree)"}
 WORKLOAD = WORKLOADS["cfg2"]
-# what `other_workloads` measures beside the headline (reduced spp: the rate does not depend on it once a dispatch holds enough paths)
-OTHER_WORKLOADS = (("cfg3", 32), ("cfg4", 4), ("soup", 16), ("soup10m", 8))
+# what `other_workloads` measures beside the headline: (workload, spp of the measured dispatch, spp of a second, short dispatch kept for continuity with rounds 1-4).
+# Round 5: configs[2] and both soups at BASELINE's own sample counts — a frame is ONE dispatch of 1.7-3.7 s —, configs[3] at 256 of its 2048 passes
+# (the full frame is 25 s of one GPU; its rate no longer moves from 128 passes on: DESIGN.md section 3). The seed of a (pixel, pass) depends on the sample count
+# (sampler.c:42) and so does the path mix: the reduced figures understate (statues: 2.07 Gray/s at 4 spp, 2.34 at 16).
+OTHER_WORKLOADS = (("cfg3", 1024, 32), ("cfg4", 256, 4), ("soup", 512, 16), ("soup10m", 512, 8))
 
 
 def workload_blob(key, built_dir):
@@ -168,37 +171,72 @@ def kernel_source_md5():
     return h.hexdigest()
 
 
+def calibration():
+    """profiles/calibration.json (tools/calib.sh + tools/calib_table.py, round 5): what rocprofv3's FETCH_SIZE / WRITE_SIZE report for kernels of KNOWN traffic in this
+    kernel's own access patterns, and what the VALU-pipe formula reads at KNOWN saturation. {} when absent."""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "calibration.json")))
+    except Exception:
+        return {}
+
+
+def calibrated_traffic(t):
+    """Measured L2<->fabric bytes per launch from a profiles/hbm_traffic*.json record: the raw FETCH_SIZE bytes times the factor measured on divergent 64-byte gathers
+    (the kernel's reads are child pairs, texels and record quarters: 64-byte requests, which FETCH_SIZE counts at face value — NOT the x2 of wide streaming reads,
+    which are 128-byte requests tallied at 64) plus WRITE_SIZE (128-byte record writes: exact). Returns (bytes, upper bound as if every read request were 128 bytes)."""
+    if not t or t.get("fetch_bytes_raw") is None:
+        return None, None
+    cal = calibration()
+    rf = (cal.get("k_gather64") or {}).get("read_factor") or 1.0
+    rf128 = (cal.get("k_gather128") or {}).get("read_factor") or 2.0
+    wf = (cal.get("k_write128") or {}).get("write_factor") or 1.0
+    return t["fetch_bytes_raw"] * rf + t["write_bytes"] * wf, t["fetch_bytes_raw"] * rf128 + t["write_bytes"] * wf
+
+
 def measured_profile(workload_key):
-    """(traffic bytes per launch, VALU roofline dict) from the committed rocprofv3 PMC summary — or (None, None) when that summary
+    """(traffic bytes per launch, its upper bound, VALU roofline dict) from the committed rocprofv3 PMC summary — or Nones when that summary
     was taken from different kernel sources or another workload (stale numbers are not quoted)."""
     path = os.path.join(REPO, "profiles", "hbm_traffic.json" if workload_key == "cfg2" else f"hbm_traffic_{workload_key}.json")
     try:
         t = json.load(open(path))
     except Exception:
-        return None, None
+        return None, None, None
     if t.get("source_md5") != kernel_source_md5() or t.get("workload", "cfg2") != workload_key:
-        return None, None
-    return t.get("hbm_bytes_per_launch"), t.get("valu")
+        return None, None, None
+    lo, hi = calibrated_traffic(t)
+    valu = t.get("valu")
+    sat = (calibration().get("k_mix") or {}).get("pipe_busy_at_saturation")
+    if valu and valu.get("pipe_busy") and sat:
+        valu = dict(valu, calibration={"formula_reads_at_known_saturation": {k: round((calibration().get(k) or {}).get("pipe_busy_at_saturation") or 0, 3) for k in ("k_fma", "k_add", "k_mix")},
+                                       "of_saturated_rate": round(valu["pipe_busy"] / sat, 3),
+                                       "note": "SQ_ACTIVE_INST_VALU counts one busy quad-cycle per vector instruction and SQ_WAVE_CYCLES quad-cycles per resident wave, so the formula reads "
+                                               "vector instructions per SIMD quad-cycle — 1.6-1.7 for a saturating loop of the node step's blend (fma / min / max / cmp / cndmask), not 1.0: "
+                                               "of_saturated_rate = pipe_busy / that reading is the share of the vector pipe's saturated issue rate the kernel uses (profiles/calibration.json)"})
+    return lo, hi, valu
 
 
-def fractions(alg_bytes, traffic_bytes, ms):
+def fractions(alg_bytes, traffic_bytes, ms, traffic_upper=None):
     """The two roofline fractions of one launch, by name, so that neither is mistaken for the other: frac_algorithmic = the bytes a cache-less machine
     would move (scene records touched) / time / HBM peak — it EXCEEDS 1 wherever L2 and the 256 MB Infinity Cache serve most records, and says so;
-    frac_measured_traffic = the measured L2<->fabric volume (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, MALL hits included) / time / HBM peak, null when
-    profiles/ holds no PMC measurement of this device code and workload."""
+    frac_measured_traffic = the measured L2<->fabric volume (rocprofv3 FETCH_SIZE and WRITE_SIZE with the factors calibrated on this kernel's access patterns:
+    calibrated_traffic(); MALL hits included) / time / HBM peak, null when profiles/ holds no PMC measurement of this device code and workload;
+    frac_measured_traffic_upper = the same if every read request had been a 128-byte one."""
     fa = alg_bytes / ms / 1e6 / HBM_PEAK_GBS
     out = {"frac_algorithmic": round(fa, 4), "frac_measured_traffic": round(traffic_bytes / ms / 1e6 / HBM_PEAK_GBS, 4) if traffic_bytes else None}
+    if traffic_upper:
+        out["frac_measured_traffic_upper"] = round(traffic_upper / ms / 1e6 / HBM_PEAK_GBS, 4)
     if fa > 1.0:
         out["frac_note"] = "algorithmic fraction above 1: the records were served by L2 / Infinity Cache, not by HBM (see frac_measured_traffic)"
     return out
 
 
 def measure_other_workloads(api, abi, built_dir):
-    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region: one counting dispatch + three timed ones each (the median counts), at a reduced sample
-    count (stated). Mray/s, algorithmic bytes and fraction of the HBM roofline per workload; `traffic` where profiles/ holds a PMC measurement of
-    that workload on this device code (per dispatch of the stated spp)."""
+    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region, at the sample counts of OTHER_WORKLOADS (BASELINE's own for configs[2] and the soups):
+    one counting dispatch and one timed dispatch of the full frame each (a dispatch of seconds needs no median), then three short dispatches at the reduced sample count
+    of rounds 1-4 (`reduced`). Mray/s, algorithmic bytes and fraction of the HBM roofline per workload; `traffic` where profiles/ holds a PMC measurement of
+    that workload on this device code (per dispatch of the spp it names, scaled to this dispatch's rays)."""
     out = {}
-    for key, spp in OTHER_WORKLOADS:
+    for key, spp, spp_reduced in OTHER_WORKLOADS:
         wl = WORKLOADS[key]
         t0 = time.perf_counter()
         try:
@@ -218,27 +256,36 @@ def measure_other_workloads(api, abi, built_dir):
             full = ctx.counters()
             ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
             ctx.reset_counters()
+            ctx.clear(fb, w, h)
+            ctx.render_region(fb, w, h, spp, b)
+            ctx.synchronize()
+            ms = ctx.kernel_time_ms()[0]
+            assert ctx.counters()["rays"] == full["rays"], "the timed dispatch traced other rays than the counting one"
             times = []
             for _ in range(3):
-                ctx.clear(fb, w, h)
-                ctx.render_region(fb, w, h, spp, b)
+                ctx.clear(fb, w, h); ctx.reset_counters()
+                ctx.render_region(fb, w, h, spp_reduced, b)
                 ctx.synchronize()
                 times.append(ctx.kernel_time_ms()[0])
-            ms = sorted(times)[1]                       # the median of three dispatches (HIP events around the kernel)
+            reduced_rays = ctx.counters()["rays"]
             alg = algorithmic_bytes(full, path_state=False)
-            traffic = None
+            traffic = upper = None
             try:
                 t = json.load(open(os.path.join(REPO, "profiles", f"hbm_traffic_{key}.json")))
-                if t.get("source_md5") == kernel_source_md5() and t.get("spp") == spp:
-                    traffic = t.get("hbm_bytes_per_launch")
+                if t.get("source_md5") == kernel_source_md5() and t.get("rays"):
+                    lo, hi = calibrated_traffic(t)
+                    traffic, upper = lo * full["rays"] / t["rays"], hi * full["rays"] / t["rays"]          # measured at t["spp"]; bytes per ray carried to this dispatch
             except Exception:
                 pass
-            out[key] = {"workload": wl["what"].format(W=w, H=h, SPP=f"{spp} of {wl['samples']}", B=b), "mrays": round(full["rays"] / ms / 1e3, 1), "kernel_ms": round(ms, 2),
+            out[key] = {"workload": wl["what"].format(W=w, H=h, SPP=spp if spp == wl["samples"] else f"{spp} of {wl['samples']}", B=b), "spp": spp, "baseline_spp": wl["samples"],
+                        "mrays": round(full["rays"] / ms / 1e3, 1), "kernel_ms": round(ms, 2),
                         "rays": full["rays"], "rays_per_path": round(full["rays"] / max(full["paths"], 1), 2),
                         "node_tests_per_ray": round(full["node_tests"] / max(full["rays"], 1), 1), "tri_tests_per_ray": round(full["tri_tests"] / max(full["rays"], 1), 1),
                         "bytes_per_ray": round(alg / max(full["rays"], 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1),
-                        **fractions(alg, traffic, ms),
-                        "traffic": traffic, "setup_s": round(time.perf_counter() - t0 - 4 * ms / 1e3, 2)}
+                        **fractions(alg, traffic, ms, upper),
+                        "traffic": traffic,
+                        "reduced": {"spp": spp_reduced, "mrays": round(reduced_rays / sorted(times)[1] / 1e3, 1), "kernel_ms": round(sorted(times)[1], 2), "note": "the sample count of rounds 1-4's lines (median of three dispatches)"},
+                        "setup_s": round(time.perf_counter() - t0 - (2 * ms + sum(times)) / 1e3, 2)}
             ctx.close()
             scene.close()
         except Exception as e:      # a missing blob / failed build must not take the headline line with it
@@ -246,21 +293,29 @@ def measure_other_workloads(api, abi, built_dir):
     return out
 
 
-SCALING_CFG4_SPP = 16
+# the scaling objects of the bench line: configs[3] at 128 of its 2048 passes (1.6 s at N = 1: a 1/8 share is 0.2 s, not a drain test) and configs[4] —
+# the 10 M-triangle soup, "sharded across 8 MI355X (RCCL framebuffer reduce)" — at 128 of its 512 (0.9 s at N = 1), through the same strips + gather as the headline
+SCALING_SPP = {"cfg4": 128, "soup10m": 128}
 
 
-def scaling_cfg4(api, render, torch, dist, built_dir, local_rank, rank, world, reps=3):
-    """BASELINE.json configs[3] — input/statues.json 3840x2160, the scene the 1/2/4/8-GPU curve is quoted on — at a stated reduced sample count, with the
-    SAME share + gather path as the headline (4-row strips per rank, the owned strips gathered on rank 0), emitted at every N (N = 1 included) so that
-    the points of the driver's scaling run divide. Outside the timed region. Returns {mrays, ms, gather_ms, rays, spp} on rank 0 (ms = max over ranks)."""
-    wl = WORKLOADS["cfg4"]
+def scaling_workload(key, api, render, torch, dist, built_dir, local_rank, rank, world, reps=2):
+    """A BASELINE config through the multi-GPU path — 4-row strips per rank, the owned strips gathered on rank 0 — at a stated sample count, emitted at every N (N = 1
+    included) so that the points of the driver's scaling run divide. Outside the timed region. The 10 M soup's blob is built by rank 0 (tools/make_soup_blob.py: the
+    GPU BVH builder) while the others wait; every rank then uploads its replica. Returns {mrays, ms, gather_ms, rays, spp} on rank 0 (ms = max over ranks)."""
+    wl = WORKLOADS[key]
     blob = os.path.join(built_dir, wl["blob"] + ".blob")
+    if wl.get("triangles") and not os.path.exists(blob):
+        if rank == 0:
+            blob = workload_blob(key, built_dir)
+        if world > 1:
+            dist.barrier()
+        blob = workload_blob(key, built_dir)
     have = torch.tensor([1.0 if os.path.exists(blob) else 0.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
     if world > 1:
         dist.all_reduce(have, op=dist.ReduceOp.MIN)
     if not float(have[0]):
         return {"skipped": f"{blob} not built"}
-    W, H, B, spp = wl["width"], wl["height"], wl["bounces"], SCALING_CFG4_SPP
+    W, H, B, spp = wl["width"], wl["height"], wl["bounces"], SCALING_SPP[key]
     scene = api.Scene(blob)
     fr = render.FrameRenderer(api, scene, W, H, device=local_rank, rank=rank, world=world, tile=wl["tile"], order=wl["tile_order"])
     fr.ctx.set_option(api.abi.OPT_COUNTER_LEVEL, 1)
@@ -270,7 +325,7 @@ def scaling_cfg4(api, render, torch, dist, built_dir, local_rank, rank, world, r
             dist.barrier()
         torch.cuda.synchronize()
 
-    fr.render(spp, B); fr.reduce(dist); barrier()          # warm-up (code object, buffers, the collective's first use)
+    fr.render(min(spp, 8), B); fr.reduce(dist); barrier()          # warm-up (code object, buffers, the collective's first use)
     fr.ctx.reset_counters()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     best = None
@@ -410,10 +465,21 @@ def cpu_baseline(oracle_py, blob_path, w, h, bounces, budget_s=12.0, frames=None
             ref_img, st = refrun.render_reference(WORKLOAD["scene"], w, h, spp, bounces, flavour="default", threads=cores)
             frames["default"] = ref_img
             secs = st["render_ms"] / 1e3
-            return {"value": round(cnt["rays"] / secs / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "reference",
-                    "sample": f"oracle/_ref/c-ray-ref -j {cores}: {WORKLOAD['scene']} {w}x{h}, {spp} spp (of {WORKLOAD['samples']}), {bounces} bounces, "
-                              f"render phase {secs:.2f} s, {cnt['rays']} rays (counted by the bit-exact restatement)",
-                    "port_value": round(cnt["rays"] / port_s / 1e6, 3)}
+            out = {"value": round(cnt["rays"] / secs / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "reference",
+                   "sample": f"oracle/_ref/c-ray-ref -j {cores}: {WORKLOAD['scene']} {w}x{h}, {spp} spp (of {WORKLOAD['samples']}), {bounces} bounces, the scene file's own "
+                             f"{WORKLOAD['tile'][0]}x{WORKLOAD['tile'][1]} tiles, render phase {secs:.2f} s, {cnt['rays']} rays (counted by the bit-exact restatement)",
+                   "port_value": round(cnt["rays"] / port_s / 1e6, 3)}
+            # a FAIR column: the scene file's 64x64 tiles give a 1280x720 frame 240 tiles — with more threads than tiles every thread gets at most one and
+            # the frame lasts as long as its slowest tile (tile.c:66-117). The same sample with 16x16 tiles (args.c: the -t option's effect; here through the scene's
+            # renderer.tileWidth / tileHeight) keeps every core busy: the figure to divide by when a "x host CPU" ratio is wanted
+            try:
+                _img16, st16 = refrun.render_reference(WORKLOAD["scene"], w, h, spp, bounces, flavour="default", threads=cores, tile=(16, 16))
+                out["value_tiles16"] = round(cnt["rays"] / (st16["render_ms"] / 1e3) / 1e6, 3)
+                out["sample_tiles16"] = f"the same frame and sample with 16x16 tiles: render phase {st16['render_ms'] / 1e3:.2f} s"
+            except Exception as e:
+                out["value_tiles16"] = None
+                out["sample_tiles16"] = f"failed: {type(e).__name__}"
+            return out
         except Exception as e:  # fall back to the restatement, say so
             note = f" (reference binary failed: {type(e).__name__})"
     else:
@@ -523,14 +589,15 @@ def main():
         elapsed, gather_ms, kernel_ms_max = float(tmax[0]), float(tmax[3]), float(tmax[4])
     total_rays, total_paths = float(tt[1]), float(tt[2])
 
-    cfg4_scaling = None
+    scaling = {}
     if a.workload == "cfg2" and SPP == WORKLOAD["samples"] and not a.no_others:
-        try:
-            cfg4_scaling = scaling_cfg4(api, render, torch, dist, BUILT, local_rank, rank, world)
-        except Exception as e:          # must not take the headline line with it
-            cfg4_scaling = {"failed": f"{type(e).__name__}: {e}"[:300]}
-            if world > 1:
-                raise
+        for key in ("cfg4", "soup10m"):
+            try:
+                scaling[key] = scaling_workload(key, api, render, torch, dist, BUILT, local_rank, rank, world)
+            except Exception as e:          # must not take the headline line with it
+                scaling[key] = {"failed": f"{type(e).__name__}: {e}"[:300]}
+                if world > 1:
+                    raise
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = total_rays / elapsed / 1e6
@@ -538,9 +605,10 @@ def main():
         alg = algorithmic_bytes(full)
         alg_no_state = algorithmic_bytes(full, path_state=False)
         achieved = alg / (avg_kernel_ms * 1e-3) / 1e9
-        traffic, valu = (None, None)
+        traffic, traffic_upper, valu = (None, None, None)
         if world == 1 and SPP == WORKLOAD["samples"]:
-            traffic, valu = measured_profile(a.workload)
+            traffic, traffic_upper, valu = measured_profile(a.workload)
+        sat = ((valu or {}).get("calibration") or {}).get("of_saturated_rate")
         frac_state = achieved / HBM_PEAK_GBS
         achieved_scene = alg_no_state / (avg_kernel_ms * 1e-3) / 1e9
         out = {
@@ -552,32 +620,39 @@ def main():
                        "parallelism": ("1 rank: the whole frame in one dispatch" if world == 1 else
                                        f"4-row strips interleaved over {world} ranks; rank 0 gathers the owned strips (1/{world} of the float framebuffer per rank, "
                                        "RCCL send / receive over xGMI; render.py: StripGather — bit-identical to the one-reduce form)"),
-                       "baseline_config": {"cfg2": "configs[1] (the 1-GPU headline; at N > 1 a STRONG-scaling run of the same 88 ms frame)", "cfg3": "configs[2]",
+                       "baseline_config": {"cfg2": "configs[1] (the 1-GPU headline; at N > 1 a STRONG-scaling run of the same 68 ms frame)", "cfg3": "configs[2]",
                                            "cfg4": "configs[3] (the scene BASELINE.json quotes the 1/2/4/8-GPU curve on: --workload cfg4)",
                                            "soup": "configs[4] at 1 M triangles", "soup10m": "configs[4]"}.get(a.workload)},
             "gather_ms": round(gather_ms, 3) if world > 1 else None, "kernel_ms_max_over_ranks": round(kernel_ms_max, 3),
             # `bound` is set from the evidence: the PMC run of THIS device code (profiles/, fingerprint-gated) shows the vector ALU issuing most of the time
             # -> "valu-issue"; without such a run the label is the metric's nominal one, "hbm", and the note says that nothing measured backs it
-            "roofline": {"bound": "valu-issue" if (valu or {}).get("pipe_busy", 0) >= 0.7 else "hbm",
-                         "bound_evidence": ("profiles/hbm_traffic.json `valu` (rocprofv3 PMC of this device code): VALU pipe busy %.0f %%, lane utilisation %.0f %%"
-                                            % (100 * valu["pipe_busy"], 100 * valu.get("lane_utilisation", 0))) if valu and valu.get("pipe_busy") else
+            # `bound` is set from the evidence, CALIBRATED since round 5: the vector pipe's formula is held against its reading at known saturation (profiles/calibration.json)
+            "roofline": {"bound": ("valu-issue" if sat >= 0.7 else "memory-latency + valu-issue") if sat else ("valu-issue" if (valu or {}).get("pipe_busy", 0) >= 0.7 else "hbm"),
+                         "bound_evidence": (("profiles/hbm_traffic.json `valu` (rocprofv3 PMC of this device code): the vector pipe issues at %.0f %% of its saturated rate (formula reading %.2f "
+                                             "against %.2f for a saturating loop of the node step's instruction blend), lane utilisation %.0f %%; the waves are parked on memory waits half of their "
+                                             "cycles at 4 waves per SIMD (profiles/*_pmc_deep.txt): neither HBM bandwidth nor the issue rate alone binds — a wave waits for the slowest of its "
+                                             "lanes' cache misses, and too few of a SIMD's four waves are runnable to fill the pipe")
+                                            % (100 * sat, valu["pipe_busy"], valu["pipe_busy"] / sat, 100 * valu.get("lane_utilisation", 0))) if sat else
+                                           ("profiles/hbm_traffic.json `valu` (rocprofv3 PMC of this device code): VALU pipe formula %.2f (uncalibrated), lane utilisation %.0f %%"
+                                            % (valu["pipe_busy"], 100 * valu.get("lane_utilisation", 0))) if valu and valu.get("pipe_busy") else
                                            "no PMC run of this device code in profiles/ (fingerprint mismatch): nominal label",
                          "achieved": round(achieved_scene, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_scene / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         **fractions(alg_no_state, traffic if world == 1 else None, avg_kernel_ms),
+                         **fractions(alg_no_state, traffic if world == 1 else None, avg_kernel_ms, traffic_upper if world == 1 else None),
                          "kernel": kernel_name, "avg_launch_ms": round(avg_kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_no_state),
                          "bytes_per_ray": round(alg_no_state / max(full["rays"], 1), 1),
                          "frac_with_path_state": round(frac_state, 5),
                          "what_it_is": "`achieved` / `frac` (= frac_algorithmic) are the ALGORITHMIC rate, not an HBM measurement: scene records touched (node / triangle / "
                                        "instance / shading / texel), B_state = 0 (SURVEY 8(d): persistent megakernel), divided by the launch time. Most of those bytes are "
-                                       "served by L2 and the 256 MB Infinity Cache; `traffic` is the measured L2<->fabric volume per launch (FETCH_SIZE x2 + WRITE_SIZE, MALL "
-                                       "hits included), frac_measured_traffic the same over time and HBM peak; both are null whenever profiles/hbm_traffic.json was not "
-                                       "measured on this device code (fingerprint of the k_pathtrace* machine code) / this workload. frac_with_path_state adds 152 B/ray for "
-                                       "the per-wave path table. The kernel is bound by vector-instruction issue (`valu`), not by HBM",
+                                       "served by L2 and the 256 MB Infinity Cache; `traffic` is the measured L2<->fabric volume per launch (FETCH_SIZE and WRITE_SIZE with the factors "
+                                       "calibrated on divergent 64-byte gathers and 128-byte record writes — profiles/calibration.json; until round 4 the read side was doubled, which "
+                                       "holds for 128-byte requests only: frac_measured_traffic_upper —, MALL hits included), frac_measured_traffic the same over time and HBM peak; both are "
+                                       "null whenever profiles/hbm_traffic.json was not measured on this device code (fingerprint of the k_pathtrace* machine code) / this workload. "
+                                       "frac_with_path_state adds 152 B/ray for the per-wave path table. What binds the kernel: `bound_evidence`",
                          "valu": valu},
         }
-        if cfg4_scaling is not None:
-            out["scaling_cfg4"] = cfg4_scaling
+        for key, obj in scaling.items():
+            out["scaling_" + key] = obj
         if world == 1 and not a.no_cpu:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import oracle_py

@@ -75,6 +75,21 @@ VALU_KERNEL(k_mix, asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a0) : "v"(b));
 	asm volatile("v_min_f32 %0, %0, %1" : "+v"(a3) : "v"(b)); asm volatile("v_max_f32 %0, %0, %1" : "+v"(a4) : "v"(b)); asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(a5) : "v"(b)); \
 	asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a6), "v"(b) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a7) : "v"(b) : "vcc");)
 
+/* does the vector ALU skip a half (or three quarters) of a wave whose lanes are all masked off? the same fma loop with exec = lanes 0-31 / lanes 0-15 only */
+#define VALU_MASKED(NAME, MASK) \
+__global__ __launch_bounds__(256) void NAME(float *out, float seed) { \
+	float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7; \
+	const float b = seed * 0.5f + 1.0f; \
+	if ((threadIdx.x & 63u) < MASK) { \
+		for (int i = 0; i < LOOPS; ++i) { \
+			_Pragma("unroll") for (int u = 0; u < 16; ++u) { ALL8("v_fma_f32 %0, %0, %1, %1") } \
+		} \
+	} \
+	if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[0] = a0; \
+}
+VALU_MASKED(k_fma_half, 32u)
+VALU_MASKED(k_fma_quarter, 16u)
+
 int main(int argc, char **argv) {
 	const std::string only = argc > 1 ? argv[1] : "";
 	hipDeviceProp_t prop;
@@ -101,6 +116,8 @@ int main(int argc, char **argv) {
 	timed("k_stream", [&]() { hipLaunchKernelGGL(k_stream, dim3(blocks * 4u), dim3(256), 0, 0, arr, bytes / 16u, out); }, (double)bytes, 0);
 	timed("k_write128", [&]() { hipLaunchKernelGGL(k_write128, dim3(blocks * 8u), dim3(256), 0, 0, arr, (uint32_t)(bytes / 128u - 1u), 1.0f); }, lanes * 8.0 * RECORDS * 128.0, 0);
 	timed("k_fma", [&]() { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }, 0, waves * LOOPS * 16.0 * 8.0);
+	timed("k_fma_half", [&]() { hipLaunchKernelGGL(k_fma_half, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }, 0, waves * LOOPS * 16.0 * 8.0);
+	timed("k_fma_quarter", [&]() { hipLaunchKernelGGL(k_fma_quarter, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }, 0, waves * LOOPS * 16.0 * 8.0);
 	timed("k_add", [&]() { hipLaunchKernelGGL(k_add, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }, 0, waves * LOOPS * 16.0 * 8.0);
 	timed("k_mix", [&]() { hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }, 0, waves * LOOPS * 16.0 * 8.0);
 	return 0;

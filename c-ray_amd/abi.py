@@ -5,7 +5,7 @@ Field order and sizes must match the header exactly (tests/test_abi.py checks th
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 NODE_NONE = 0xFFFFFFFF
@@ -127,6 +127,7 @@ EXPORTED_SYMBOLS = [
     "crh_framebuffer_download", "crh_framebuffer_to_srgb8", "crh_render_region", "crh_render_tiles",
     "crh_synchronize", "crh_frames_reduce", "crh_frames_gather", "crh_frames_prepare", "crh_context_prepare", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
     "crh_blob_save", "crh_blob_load", "crh_blob_free", "crh_bvh_build_triangles", "crh_debug_eval_math", "crh_debug_plan_units", "crh_last_kernel_name", "crh_framebuffer_strips_to_srgb8",
+    "crh_scene_compile", "crh_scene_upload_compiled", "crh_compiled_scene_free", "crh_debug_upload_counts",
 ]
 MATH_FUNCTIONS = ("sinf", "cosf", "sincosf_sin", "sincosf_cos", "logf", "log10f", "atanf", "acosf", "asinf", "tanf", "powf", "atan2f")   # enum crh_math_function
 

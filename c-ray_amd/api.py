@@ -56,6 +56,10 @@ def library():
         "crh_debug_wave_stats": (C.c_int, [ctx, C.c_void_p, C.c_uint32]),
         "crh_debug_phase_ticks": (C.c_int, [ctx, C.c_void_p]),
         "crh_scene_upload": (C.c_int, [ctx, C.POINTER(abi.SceneDesc)]),
+        "crh_scene_compile": (C.c_int, [C.POINTER(abi.SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
+        "crh_scene_upload_compiled": (C.c_int, [ctx, C.c_void_p]),
+        "crh_compiled_scene_free": (None, [C.c_void_p]),
+        "crh_debug_upload_counts": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "crh_framebuffer_alloc": (C.c_int, [ctx, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
         "crh_framebuffer_free": (C.c_int, [ctx, C.c_void_p]),
         "crh_framebuffer_clear": (C.c_int, [ctx, C.c_void_p, C.c_int, C.c_int]),
@@ -98,6 +102,33 @@ def _check(rc, where):
 
 def device_count():
     return library().crh_device_count()
+
+
+class CompiledScene:
+    """crh_scene_compile: the device layout of a scene, derived once on the host; any number of contexts upload it (Context.upload_compiled)."""
+
+    def __init__(self, scene, walk=0):
+        desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)
+        self.h = C.c_void_p()
+        _check(library().crh_scene_compile(desc, walk, C.byref(self.h)), "crh_scene_compile")
+
+    def close(self):
+        if self.h:
+            library().crh_compiled_scene_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def upload_counts():
+    """(layout compiles, uploads) of this process so far (crh_debug_upload_counts)."""
+    a, b = C.c_int(0), C.c_int(0)
+    library().crh_debug_upload_counts(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def plan_units(width, height, samples, tiles, cu_count=256, first_pass=0, pass_count=None):
@@ -196,6 +227,10 @@ class Context:
     def upload(self, scene):
         desc = scene.ptr if hasattr(scene, "ptr") else C.pointer(scene)
         _check(self.L.crh_scene_upload(self.h, desc), "crh_scene_upload")
+
+    def upload_compiled(self, compiled):
+        """crh_scene_upload_compiled: the copies only, from a CompiledScene (one layout compile for several contexts)."""
+        _check(self.L.crh_scene_upload_compiled(self.h, compiled.h), "crh_scene_upload_compiled")
 
     def framebuffer(self, width, height):
         p = C.c_void_p()

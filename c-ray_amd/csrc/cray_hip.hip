@@ -244,10 +244,12 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 }
 
 #define CRH_NCOUNTERS 32
-/* the counter block of a context: CRH_NCOUNTERS global 64-bit counters, then CRH_NCOUNTERS 32-bit words per wave (the rolling kernel's wave-level numbers of the counting
+/* the counter block of a context: CRH_NCOUNTERS global 64-bit counters, then CRH_NCOUNTERS 64-bit words per wave (the rolling kernel's wave-level numbers of the counting
  * instantiation: pathtrace_roll.h, CRH_WCTR) for the largest grid a context launches (8 workgroups per CU) */
 #define CRH_COUNTER_WAVES_MAX(cus) ((size_t)(cus) * 8u * 4u)
-#define CRH_COUNTER_BYTES(cus) (CRH_NCOUNTERS * sizeof(unsigned long long) + CRH_COUNTER_WAVES_MAX(cus) * CRH_NCOUNTERS * sizeof(uint32_t))
+/* (round 5, ADVICE r04: the per-wave words are 64-bit too — a wave's step clocks accumulate over every dispatch until crh_counters_reset, and a 32-bit word wraps after
+ * about two seconds of a busy wave at the shader clock; bench.py's other_workloads dispatches run for three) */
+#define CRH_COUNTER_BYTES(cus) (CRH_NCOUNTERS * sizeof(unsigned long long) + CRH_COUNTER_WAVES_MAX(cus) * CRH_NCOUNTERS * sizeof(unsigned long long))
 
 /* scheduler weights: score of a step kind = lanes waiting for it x weight (weight ~ 1 / cost of the step) */
 struct Sched { int wNode, wTri, wCtrl, swapMin, fillTo, runNum, triInRun, ctrlInRun, shadeMin;
@@ -925,34 +927,14 @@ int crh_context_prepare(crh_ctx *c) {
 	return rc;
 }
 
-int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
-	if (!c || !scene) return fail(CRH_ERR_INVALID, "crh_scene_upload: NULL argument");
-	int rc = setDevice(c);
-	if (rc) return rc;
-	std::unique_ptr<CompiledScene> compiled(new CompiledScene);
-	CompiledScene &cs = *compiled;
-	std::string err;
-	const auto tUp0 = std::chrono::steady_clock::now();
+static std::atomic<int> g_sceneCompiles{0}, g_sceneUploads{0};          /* layout compiles / uploads of this process (tests: crh_debug_upload_counts) */
+
+/* The copies of an upload, with the compiled layout in hand: `cs` is only read (several contexts may upload the same compiled scene at once — renderer_hip.c's
+ * multi-GPU frame compiles ONCE, round 5); takeTexels() hands over texels that are already on the device (crh_scene_upload copies them beside its compile) or null. */
+static int uploadCompiled(crh_ctx *c, const CompiledScene &cs, const int32_t *prims, size_t primCount, const std::function<int(void **)> &takeTexels, double *tCopiesMs,
+                          const std::chrono::steady_clock::time_point &tUp0) {
 	auto upMs = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tUp0).count(); };
-	/* the texels — nine tenths of a textured scene's bytes, and the first thing the compiler finishes — are copied by a helper thread WHILE the BVHs and triangles are
-	 * prepared (round 4: traced in the drop-in, the pageable copies' DMA was still under way 21 ms after hipMemcpy had returned, in front of the first dispatch) */
-	struct TexelJob {                   /* joined, and its memory released unless the scene took it, on every way out of this function */
-		std::thread thread;
-		void *dev = nullptr;
-		hipError_t status = hipSuccess;
-		~TexelJob() { if (thread.joinable()) thread.join(); if (dev) (void)hipFree(dev); }
-	} texelJob;
-	cs.want_wide = c->walk == CRH_WALK_WIDE4;
-	rc = compile_scene(scene, cs, err, [&]() {
-		texelJob.thread = std::thread([&]() {
-			texelJob.status = hipSetDevice(c->device);
-			const size_t bytes = std::max<size_t>(cs.texels.size(), 1) * sizeof(f4);
-			if (texelJob.status == hipSuccess) texelJob.status = hipMalloc(&texelJob.dev, bytes);
-			if (texelJob.status == hipSuccess) texelJob.status = hipMemcpy(texelJob.dev, cs.texels.data(), cs.texels.size() * sizeof(f4), hipMemcpyHostToDevice);
-		});
-	});
-	if (rc != CRH_OK) return fail(rc, "crh_scene_upload: " + err);
-	const double tCompile = upMs();
+	int rc = CRH_OK;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	freeScene(c);
 	DScene d;
@@ -977,7 +959,7 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 		d.tris = (const f4 *)((const char *)p + nodeBytes);
 	}
 	UP(shade, cs.shade.data(), cs.shade.size());
-	UP(prims, scene->prim_indices, (size_t)scene->prim_index_count);
+	UP(prims, prims, primCount);
 	UP(instances, cs.instances.data(), cs.instances.size());
 	UP(materials, cs.materials.data(), cs.materials.size());
 	UP(bsdfs, cs.bsdfs.data(), cs.bsdfs.size());
@@ -985,13 +967,13 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	UP(images, cs.images.data(), cs.images.size());
 	UP(prog, cs.prog.data(), cs.prog.size());
 	UP(textures, cs.textures.data(), cs.textures.size());
-	if (texelJob.thread.joinable()) {
-		texelJob.thread.join();
-		if (texelJob.status != hipSuccess) { freeScene(c); return fail(CRH_ERR_HIP, std::string("crh_scene_upload: texels: ") + hipGetErrorString(texelJob.status)); }
-		c->sceneAllocs.push_back(texelJob.dev);
-		d.texels = (const f4 *)texelJob.dev;
-		texelJob.dev = nullptr;
-	} else UP(texels, cs.texels.data(), cs.texels.size());
+	{
+		void *texDev = nullptr;
+		rc = takeTexels ? takeTexels(&texDev) : CRH_OK;
+		if (rc) { freeScene(c); return rc; }
+		if (texDev) { c->sceneAllocs.push_back(texDev); d.texels = (const f4 *)texDev; }
+		else UP(texels, cs.texels.data(), cs.texels.size());
+	}
 #undef UP
 	d.tlas_first = cs.tlas_first;
 	d.material_count = (uint32_t)cs.materials.size(); d.bsdf_count = (uint32_t)cs.bsdfs.size(); d.const_count = (uint32_t)cs.consts.size();
@@ -1008,11 +990,64 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	 * set-up. Measured in round 3 (CRH_TRACE_SYNC): without it the first dispatch's kernel starts 7-25 ms after its launch — behind work the runtime
 	 * still owes the pageable host-to-device copies above, which neither hipStreamSynchronize on the context's (non-blocking) stream nor
 	 * hipDeviceSynchronize waits for; with it, 1-5 us. (Until round 3 the watchdog flag's copy in crh_synchronize was this barrier by accident.) */
-	const double tCopies = upMs();
+	*tCopiesMs = upMs();
 	rc = preloadKernel(c, true);         /* ... and an (empty) launch of the kernel on the context's stream is waited for: see below */
 	if (rc != CRH_OK) return rc;
 	unsigned int flag = 0;
 	HIP_TRY(hipMemcpy(&flag, c->dWork + (CRH_WORK_SLOTS - 1), sizeof(flag), hipMemcpyDeviceToHost));
+	return CRH_OK;
+}
+
+/* (every C++ exception a compile or an upload can raise ends at the C boundary as an error code: ADVICE r04) */
+static int guarded(const char *what, const std::function<int()> &f) {
+	try { return f(); }
+	catch (const std::bad_alloc &) { return fail(CRH_ERR_NOMEM, std::string(what) + ": out of host memory"); }
+	catch (const std::exception &e) { return fail(CRH_ERR_HIP, std::string(what) + ": " + e.what()); }
+}
+
+int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
+	if (!c || !scene) return fail(CRH_ERR_INVALID, "crh_scene_upload: NULL argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	return guarded("crh_scene_upload", [&]() -> int {
+	std::unique_ptr<CompiledScene> compiled(new CompiledScene);
+	CompiledScene &cs = *compiled;
+	std::string err;
+	const auto tUp0 = std::chrono::steady_clock::now();
+	auto upMs = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tUp0).count(); };
+	/* the texels — nine tenths of a textured scene's bytes, and the first thing the compiler finishes — are copied by a helper thread WHILE the BVHs and triangles are
+	 * prepared (round 4: traced in the drop-in, the pageable copies' DMA was still under way 21 ms after hipMemcpy had returned, in front of the first dispatch) */
+	struct TexelJob {                   /* joined, and its memory released unless the scene took it, on every way out of this function */
+		std::thread thread;
+		void *dev = nullptr;
+		hipError_t status = hipSuccess;
+		~TexelJob() { if (thread.joinable()) thread.join(); if (dev) (void)hipFree(dev); }
+	} texelJob;
+	cs.want_wide = c->walk == CRH_WALK_WIDE4;
+	int rc = compile_scene(scene, cs, err, [&]() {
+		try {
+			texelJob.thread = std::thread([&]() {
+				texelJob.status = hipSetDevice(c->device);
+				const size_t bytes = std::max<size_t>(cs.texels.size(), 1) * sizeof(f4);
+				if (texelJob.status == hipSuccess) texelJob.status = hipMalloc(&texelJob.dev, bytes);
+				if (texelJob.status == hipSuccess) texelJob.status = hipMemcpy(texelJob.dev, cs.texels.data(), cs.texels.size() * sizeof(f4), hipMemcpyHostToDevice);
+			});
+		} catch (const std::exception &) { /* no helper thread: the texels are copied with the rest */ }
+	});
+	if (rc != CRH_OK) return fail(rc, "crh_scene_upload: " + err);
+	++g_sceneCompiles;
+	const double tCompile = upMs();
+	double tCopies = 0.0;
+	rc = uploadCompiled(c, cs, scene->prim_indices, (size_t)scene->prim_index_count, [&](void **dev) -> int {
+		if (!texelJob.thread.joinable()) return CRH_OK;
+		texelJob.thread.join();
+		if (texelJob.status != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_scene_upload: texels: ") + hipGetErrorString(texelJob.status));
+		*dev = texelJob.dev;
+		texelJob.dev = nullptr;
+		return CRH_OK;
+	}, &tCopies, tUp0);
+	if (rc != CRH_OK) return rc;
+	++g_sceneUploads;
 	if (getenv("CRH_TRACE_UPLOAD"))         /* dev: where crh_scene_upload's time goes */
 		fprintf(stderr, "crh_scene_upload trace: layout compile %.1f ms, allocations + copies %.1f ms (%.1f MB), code object + barrier %.1f ms\n", tCompile, tCopies - tCompile,
 				(double)(cs.nodes.size() * 16 + cs.tris.size() * 16 + cs.shade.size() * sizeof(DShadeTri) + cs.texels.size() * 16) / 1e6, upMs() - tCopies);
@@ -1029,7 +1064,59 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 	});
 	return CRH_OK;
+	});
 }
+
+/* ONE compile for the contexts of an in-process multi-GPU frame (round 5; the reference builds its scene once and every worker reads it:
+ * src/datatypes/scene.c:111-213): crh_scene_compile derives the device layout on the host — no context, no device —, crh_scene_upload_compiled copies it to a
+ * context's GPU (only reads the handle: the GPU threads of renderer_hip.c call it at the same time), crh_compiled_scene_free releases it. */
+struct crh_compiled_scene {
+	CompiledScene cs;
+	std::vector<int32_t> prims;          /* crh_scene_desc.prim_indices: the caller's arrays are not retained */
+};
+
+int crh_scene_compile(const crh_scene_desc *scene, int walk, crh_compiled_scene **out) {
+	if (!scene || !out) return fail(CRH_ERR_INVALID, "crh_scene_compile: NULL argument");
+	if (walk != CRH_WALK_BINARY && walk != CRH_WALK_WIDE4) return fail(CRH_ERR_INVALID, "crh_scene_compile: walk must be CRH_WALK_BINARY or CRH_WALK_WIDE4");
+	*out = nullptr;
+	return guarded("crh_scene_compile", [&]() -> int {
+		const auto t0 = std::chrono::steady_clock::now();
+		std::unique_ptr<crh_compiled_scene> h(new crh_compiled_scene);
+		h->cs.want_wide = walk == CRH_WALK_WIDE4;
+		std::string err;
+		const int rc = compile_scene(scene, h->cs, err);
+		if (rc != CRH_OK) return fail(rc, "crh_scene_compile: " + err);
+		h->prims.assign(scene->prim_indices, scene->prim_indices + scene->prim_index_count);
+		++g_sceneCompiles;
+		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "crh_scene_compile trace: layout compile %.1f ms (one compile for every context that uploads it)\n",
+		                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		*out = h.release();
+		return CRH_OK;
+	});
+}
+
+int crh_scene_upload_compiled(crh_ctx *c, const crh_compiled_scene *h) {
+	if (!c || !h) return fail(CRH_ERR_INVALID, "crh_scene_upload_compiled: NULL argument");
+	int rc = setDevice(c);
+	if (rc) return rc;
+	if ((c->walk == CRH_WALK_WIDE4) != h->cs.want_wide) return fail(CRH_ERR_INVALID, "crh_scene_upload_compiled: the scene was compiled for another CRH_OPT_WALK than the context's");
+	return guarded("crh_scene_upload_compiled", [&]() -> int {
+		const auto t0 = std::chrono::steady_clock::now();
+		double tCopies = 0.0;
+		releaseJanitor(c, true);
+		const int rc2 = uploadCompiled(c, h->cs, h->prims.data(), h->prims.size(), nullptr, &tCopies, t0);
+		if (rc2 != CRH_OK) return rc2;
+		++g_sceneUploads;
+		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "crh_scene_upload_compiled trace: device %d: allocations + copies %.1f ms, code object + barrier %.1f ms\n", c->device, tCopies,
+		                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - tCopies);
+		return CRH_OK;
+	});
+}
+
+void crh_compiled_scene_free(crh_compiled_scene *h) { delete h; }
+
+/* tests: scene compiles / compiled-scene uploads of this process so far */
+void crh_debug_upload_counts(int *compiles, int *uploads) { if (compiles) *compiles = g_sceneCompiles.load(); if (uploads) *uploads = g_sceneUploads.load(); }
 
 int crh_framebuffer_alloc(crh_ctx *c, int width, int height, float **dev_out) {
 	if (!c || !dev_out || width <= 0 || height <= 0) return fail(CRH_ERR_INVALID, "crh_framebuffer_alloc: bad argument");
@@ -1677,8 +1764,8 @@ int crh_debug_phase_ticks(crh_ctx *c, uint64_t *out3 /* CRH_NCOUNTERS - 8 = 24 v
 	for (int i = 0; i < CRH_NCOUNTERS - 8; ++i) out3[i] = h[i];
 	/* ... plus the per-wave words of the rolling kernel (the other kernel forms add to the global counters) */
 	const size_t waves = CRH_COUNTER_WAVES_MAX(c->cuCount);
-	std::vector<uint32_t> w(waves * CRH_NCOUNTERS);
-	HIP_TRY(hipMemcpy(w.data(), c->dCounters + CRH_NCOUNTERS, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	std::vector<unsigned long long> w(waves * CRH_NCOUNTERS);
+	HIP_TRY(hipMemcpy(w.data(), c->dCounters + CRH_NCOUNTERS, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	for (size_t v = 0; v < waves; ++v)
 		for (int i = 8; i < CRH_NCOUNTERS; ++i) out3[i - 8] += w[v * CRH_NCOUNTERS + i];
 	return CRH_OK;

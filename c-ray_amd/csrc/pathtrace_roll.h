@@ -97,8 +97,8 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	/* the counting kernel's wave-level numbers (steps, lanes served, clocks per step kind: indices 8.. of the counter block) go straight to this wave's own words behind
 	 * the global counters — one fire-and-forget atomic by lane 0 per event, no contention — instead of through two dozen registers per lane that are summed at the end:
 	 * those registers were 70 spilled VGPRs, and the counting kernel's step clocks were not the timed kernel's */
-	uint32_t *const waveCtr = (uint32_t *)(counters + CRH_NCOUNTERS) + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_NCOUNTERS;
-#define CRH_WCTR(k, v) atomicAdd(&waveCtr[k], (uint32_t)(v))
+	unsigned long long *const waveCtr = counters + CRH_NCOUNTERS + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_NCOUNTERS;          /* (64-bit words: a busy wave's clocks wrap 32 bits in two seconds) */
+#define CRH_WCTR(k, v) atomicAdd(&waveCtr[k], (unsigned long long)(uint32_t)(v))
 	__shared__ int s_rq[(CRH_BLOCK / 64) * RQ_WORDS];
 	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_ROLL_IDS_BYTES];
 	typedef volatile __attribute__((address_space(3))) int lds_int;

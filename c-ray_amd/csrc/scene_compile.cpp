@@ -45,9 +45,18 @@ template <class F> void parallelFor(size_t n, size_t grain, F fn) {
 		const size_t b = n * c / chunks, e = n * (c + 1) / chunks;
 		try { fn(b, e); }
 		catch (const Fail &f) { std::lock_guard<std::mutex> g(mu); if (!failed) { failed = true; first = f; } }
+		catch (const std::exception &x) { std::lock_guard<std::mutex> g(mu); if (!failed) { failed = true; first = Fail{CRH_ERR_NOMEM, std::string("scene compile: ") + x.what()}; } }
 	};
-	for (size_t c = 1; c < chunks; ++c) pool.emplace_back(run, c);
+	/* (round 5, ADVICE r04: a thread that cannot be started — std::system_error — must not leave joinable threads behind it, which would end the process in
+	 * std::terminate: the chunks that got no thread run here, and the ones that did are joined) */
+	pool.reserve(chunks);
+	size_t started = 1;
+	for (; started < chunks; ++started) {
+		try { pool.emplace_back(run, started); }
+		catch (const std::exception &) { break; }
+	}
 	run(0);
+	for (size_t c = started; c < chunks; ++c) run(c);
 	for (auto &t : pool) t.join();
 	if (failed) throw first;
 }
@@ -698,6 +707,9 @@ int compile_scene(const crh_scene_desc *scene, CompiledScene &out, std::string &
 		return f.code;
 	} catch (const std::bad_alloc &) {
 		err = "out of host memory";
+		return CRH_ERR_NOMEM;
+	} catch (const std::exception &x) {          /* (e.g. std::system_error from the texelsReady callback's helper thread: nothing C++ crosses the C boundary) */
+		err = std::string("scene compile: ") + x.what();
 		return CRH_ERR_NOMEM;
 	}
 	return CRH_OK;

@@ -87,11 +87,20 @@ struct flat {
 #define BIG_PAGE ((size_t)2 << 20)
 #define BIG_MAGIC 0x4352482d42494721ull
 struct big_hdr { uint64_t magic; void *map; size_t span; char pad[40]; };
+/* (round 5, ADVICE r04: EVERY block carries the header — the small ones in front of a calloc block, map = NULL — so that big_free reads its own header whatever the
+ * block's address; until then it told the two kinds apart by the pointer's 2 MB alignment, which another malloc can hand out too) */
+static void *small_zalloc(size_t bytes) {
+	char *raw = calloc((bytes ? bytes : 1) + sizeof(struct big_hdr), 1);
+	if (!raw) return NULL;
+	struct big_hdr *h = (struct big_hdr *)raw;
+	h->magic = BIG_MAGIC; h->map = NULL; h->span = 0;
+	return raw + sizeof(struct big_hdr);
+}
 static void *big_zalloc(size_t bytes) {
-	if (bytes < BIG_FROM) return calloc(bytes ? bytes : 1, 1);
+	if (bytes < BIG_FROM) return small_zalloc(bytes);
 	const size_t span = ((bytes + BIG_PAGE - 1) & ~(BIG_PAGE - 1)) + BIG_PAGE;
 	char *map = mmap(NULL, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-	if (map == MAP_FAILED) return calloc(bytes, 1);
+	if (map == MAP_FAILED) return small_zalloc(bytes);
 	char *data = (char *)(((uintptr_t)map + sizeof(struct big_hdr) + BIG_PAGE - 1) & ~(uintptr_t)(BIG_PAGE - 1));
 	(void)madvise(data, span - (size_t)(data - map), MADV_HUGEPAGE);
 	struct big_hdr *h = (struct big_hdr *)(data - sizeof(struct big_hdr));
@@ -100,11 +109,10 @@ static void *big_zalloc(size_t bytes) {
 }
 static void big_free(const void *p) {
 	if (!p) return;
-	if (((uintptr_t)p & (BIG_PAGE - 1)) == 0) {          /* (malloc never returns a 2 MB-aligned pointer for the sizes that stay below BIG_FROM: its own header sits in front) */
-		const struct big_hdr *h = (const struct big_hdr *)((const char *)p - sizeof(struct big_hdr));
-		if (h->magic == BIG_MAGIC) { munmap(h->map, h->span); return; }
-	}
-	free((void *)p);
+	struct big_hdr *h = (struct big_hdr *)((char *)p - sizeof(struct big_hdr));          /* (every block big_zalloc returns has one) */
+	if (h->magic != BIG_MAGIC) return;          /* not ours (or freed twice): leak rather than guess */
+	h->magic = 0;
+	if (h->map) munmap(h->map, h->span); else free(h);
 }
 
 /* fn(ctx, begin, end) over [0, n) on up to CRH_FLATTEN_THREADS threads (the calling one included; default: that one alone, see below): the flattener's big loops

@@ -68,7 +68,9 @@
 struct frameSync {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
-	int sceneReady;          /* 1: flattened, -1: the flattener failed */
+	int sceneReady;          /* 1: flattened (and, for several GPUs, compiled), -1: the flattener / the layout compile failed */
+	const crh_compiled_scene *compiled;          /* several GPUs: the device layout, derived ONCE by the main thread (round 5: every GPU thread used to derive it for itself); NULL: one GPU,
+	                                              * whose crh_scene_upload compiles with its texel copy beside it */
 	int finished;
 	int launched;            /* GPU threads whose first dispatch is on its device (or that ended before one): the flattened scene has been read for the last time */
 };
@@ -189,8 +191,17 @@ static void *masterThread(void *arg) {
 	return NULL;
 }
 
+static void poolJoin(int device);
+/* the process never exits with HIP calls in flight (logr(error) exit()s on a scene the parser rejects, while the makers may be inside hipMalloc or a code-object
+ * load — ROCm's teardown is known to crash then): exit() waits for the makers here; the contexts themselves are left to the process's end */
+static void poolAtExit(void) {
+	for (int g = 0; g < MAX_GPUS; ++g) poolJoin(g);
+}
+
 static void poolPrefetch(void) {
 	if (getenv("CRH_DROPIN_NO_PREFETCH")) return;
+	static int hooked;
+	if (!hooked) { hooked = 1; atexit(poolAtExit); }
 	pthread_mutex_lock(&g_pool.mu);
 	if (!g_pool.masterLive && pthread_create(&g_pool.master, NULL, masterThread, NULL) == 0) g_pool.masterLive = 1;
 	pthread_mutex_unlock(&g_pool.mu);
@@ -288,7 +299,7 @@ static void *gpuThread(void *arg) {
 	const int sceneOk = w->sync->sceneReady > 0;
 	pthread_mutex_unlock(&w->sync->mu);
 	startTimer(&phase);
-	if (ok && sceneOk && (crh_scene_upload(w->ctx, w->scene) != CRH_OK ||
+	if (ok && sceneOk && ((w->sync->compiled ? crh_scene_upload_compiled(w->ctx, w->sync->compiled) : crh_scene_upload(w->ctx, w->scene)) != CRH_OK ||
 		crh_synchronize(w->ctx) != CRH_OK)) {           /* the scene copies are asynchronous: they belong to the setup, not to the first dispatch */
 		snprintf(w->error, sizeof(w->error), "%s", crh_last_error());
 		ok = 0;
@@ -377,13 +388,18 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	float *fb[MAX_GPUS];
 	crh_tile *tiles[MAX_GPUS];
 	uint32_t ntiles[MAX_GPUS];
+	/* the process's pooled contexts (round 5, ADVICE r04: this mode used to create a second context per GPU beside the pool's); several GPUs: one layout compile */
+	crh_compiled_scene *compiled = NULL;
+	if (gpus > 1 && crh_scene_compile(scene, CRH_WALK_BINARY, &compiled) != CRH_OK) logr(error, "c-ray-hip: %s\n", crh_last_error());
 	for (int g = 0; g < gpus; ++g) {
-		if (crh_context_create(g, NULL, &ctx[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
-			crh_set_option(ctx[g], CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || crh_scene_upload(ctx[g], scene) != CRH_OK ||
+		ctx[g] = poolAcquire(g);
+		if (!ctx[g] || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
+			crh_set_option(ctx[g], CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || (compiled ? crh_scene_upload_compiled(ctx[g], compiled) : crh_scene_upload(ctx[g], scene)) != CRH_OK ||
 			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK)
 			logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());
 		ntiles[g] = gpuShare(r, g, gpus, &tiles[g]);
 	}
+	crh_compiled_scene_free(compiled);
 	const int passes = r->prefs.sampleCount - 1;             /* finishedPasses runs from 1 while < sampleCount (renderer.c:199, tile.c:52) */
 	crh_render_params p;
 	memset(&p, 0, sizeof(p));
@@ -444,7 +460,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 		crh_counters c;
 		if (crh_counters_get(ctx[g], &c) == CRH_OK) rays += c.rays;
 		crh_framebuffer_free(ctx[g], fb[g]);
-		crh_context_destroy(ctx[g]);
+		poolRelease(g, ctx[g], crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_RANDOM) == CRH_OK);          /* (back to the pool as it came: the frame renderer's sampler) */
 		free(tiles[g]);
 		r->state.threadStates[g].threadComplete = true;
 	}
@@ -577,7 +593,7 @@ struct texture *renderFrame(struct renderer *r) {
 	struct frameSync sync;
 	pthread_mutex_init(&sync.mu, NULL);
 	pthread_cond_init(&sync.cv, NULL);
-	sync.sceneReady = 0; sync.finished = 0; sync.launched = 0;
+	sync.sceneReady = 0; sync.finished = 0; sync.launched = 0; sync.compiled = NULL;
 	struct gpuWorker workers[MAX_GPUS];
 	memset(workers, 0, sizeof(workers));
 	for (int i = 0; i < r->state.tileCount; ++i) r->state.renderTiles[i].isRendering = true;      /* every GPU works on the whole frame (strips): all tiles are "being rendered" until the frame is done */
@@ -590,9 +606,18 @@ struct texture *renderFrame(struct renderer *r) {
 	}
 	/* main thread: flatten the scene while the GPU threads set themselves up */
 	startTimer(&phase);
-	const int frc = crh_flatten_world(r, &scene);
+	int frc = crh_flatten_world(r, &scene);
 	const long flattenUs = getUs(phase);
+	/* several GPUs: ONE layout compile, here, behind the flattener; the GPU threads only copy (the reference builds its scene once and every worker reads it:
+	 * src/datatypes/scene.c:111-213). One GPU: its crh_scene_upload compiles with the texels' copy beside it */
+	crh_compiled_scene *compiled = NULL;
+	if (frc == CRH_OK && gpus > 1 && !getenv("CRH_DROPIN_COMPILE_PER_GPU") && crh_scene_compile(&scene, CRH_WALK_BINARY, &compiled) != CRH_OK) {
+		logr(warning, "c-ray-hip: %s\n", crh_last_error());
+		frc = CRH_ERR_INVALID;
+	}
+	const long compileUs = getUs(phase) - flattenUs;
 	pthread_mutex_lock(&sync.mu);
+	sync.compiled = compiled;
 	sync.sceneReady = frc == CRH_OK ? 1 : -1;
 	pthread_cond_broadcast(&sync.cv);
 	pthread_mutex_unlock(&sync.mu);
@@ -612,7 +637,10 @@ struct texture *renderFrame(struct renderer *r) {
 		/* every GPU has its copy of the scene and is busy with its first dispatch: the flattened arrays (70 MB for hdr.json) go back NOW, while this thread has nothing
 		 * to do — at the end of renderFrame() the same free() is milliseconds of the frame (a process that has the GPU open gives pages back slowly, and what its threads
 		 * launch or wait for meanwhile waits too: only when a GPU's share is long enough to hide it — 2^26 paths, like the library's own release, cray_hip.hip) */
-		if (launched == gpus && scene.struct_size && (uint64_t)W * H * (uint64_t)r->prefs.sampleCount / (uint64_t)gpus >= ((uint64_t)1 << 26)) crh_flatten_free(&scene);
+		if (launched == gpus && scene.struct_size && (uint64_t)W * H * (uint64_t)r->prefs.sampleCount / (uint64_t)gpus >= ((uint64_t)1 << 26)) {
+			crh_flatten_free(&scene);
+			crh_compiled_scene_free(compiled); compiled = NULL;          /* (every GPU thread has announced its launch: the compiled layout has been read for the last time) */
+		}
 		if (finished == gpus) break;
 		getKeyboardInput(r);
 		drawWindow(r, output);
@@ -677,6 +705,7 @@ struct texture *renderFrame(struct renderer *r) {
 	pthread_mutex_destroy(&sync.mu);
 	pthread_cond_destroy(&sync.cv);
 	crh_flatten_free(&scene);
+	crh_compiled_scene_free(compiled);
 	const long frameUs = getUs(frame);          /* the whole of renderFrame(), teardown included: what the timer of c-ray.c:279-281 sees */
 	/* CRH_DUMP_STATS=<path>: where the frame went, for bench.py's `dropin` object. render_phase_ms is SURVEY.md 8(d)'s phase — the timer
 	 * of src/c-ray.c:279-281 around renderFrame() minus the set-up (flatten / context / upload: everything before the slowest GPU was ready
@@ -697,11 +726,11 @@ struct texture *renderFrame(struct renderer *r) {
 		}
 		FILE *f = fopen(statsPath, "w");
 		if (f) {
-			fprintf(f, "{\"gpus\": %d, \"width\": %d, \"height\": %d, \"samples\": %d, \"bounces\": %d, \"rays\": %llu, \"flatten_ms\": %.3f, "
+			fprintf(f, "{\"gpus\": %d, \"width\": %d, \"height\": %d, \"samples\": %d, \"bounces\": %d, \"rays\": %llu, \"flatten_ms\": %.3f, \"compile_once_ms\": %.3f, "
 					"\"context_ms\": %.3f, \"upload_ms\": %.3f, \"context_upload_ms\": %.3f, \"setup_ms\": %.3f, \"render_ms\": %.3f, \"kernel_ms\": %.3f, \"launch_host_ms\": %.3f, "
 					"\"dispatches\": %d, \"reduce_download_ms\": %.3f, \"gather_ms\": %.3f, \"resolve_srgb_ms\": %.3f, \"download_ms\": %.3f, \"rccl_setup_ms\": %.3f, "
 					"\"frame_ms\": %.3f, \"teardown_ms\": %.3f, \"render_phase_ms\": %.3f}\n",
-					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, contextUs / 1e3, uploadUs / 1e3,
+					gpus, W, H, r->prefs.sampleCount, r->prefs.bounces, (unsigned long long)rays, flattenUs / 1e3, compileUs / 1e3, contextUs / 1e3, uploadUs / 1e3,
 					(contextUs + uploadUs) / 1e3, readyUs / 1e3, renderUs / 1e3, kernelMs, launchUs / 1e3, dispatches, (gatherUs + downloadUs) / 1e3, gatherUs / 1e3,
 					resolveUs / 1e3, downloadUs / 1e3, warm.us / 1e3, frameUs / 1e3, (frameUs - workUs) / 1e3, (workUs - readyUs) / 1e3);
 			fclose(f);
@@ -720,7 +749,7 @@ struct renderer *newRenderer(void) {
 	r->state.tileMutex = createMutex();
 	r->state.timer = calloc(1, sizeof(*r->state.timer));
 	if (!g_vertices) allocVertexBuffers();
-	poolPrefetch();
+	if (!isSet("is_worker")) poolPrefetch();          /* (a cluster worker makes its own context when its first tile arrives: host/access/worker_access.c) */
 	return r;
 }
 

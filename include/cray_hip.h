@@ -31,8 +31,10 @@ extern "C" {
 #endif
 
 /* 2 (round 4): crh_debug_plan_units writes EIGHT ints per unit (six in version 1), crh_frames_gather / crh_frames_prepare / crh_context_prepare exist,
- * CRH_OPT_ROUND_LIMIT / CRH_OPT_RENDER_SLABS exist, CRH_KERNEL_WAVE / CRH_KERNEL_WG are refused by the product build. A host checks crh_abi_version() == CRH_ABI_VERSION. */
-#define CRH_ABI_VERSION 2
+ * CRH_OPT_ROUND_LIMIT / CRH_OPT_RENDER_SLABS exist, CRH_KERNEL_WAVE / CRH_KERNEL_WG are refused by the product build.
+ * 3 (round 5): crh_scene_compile / crh_scene_upload_compiled / crh_compiled_scene_free (one layout compile for the contexts of a multi-GPU frame) and CRH_OPT_WALK exist.
+ * A host checks crh_abi_version() == CRH_ABI_VERSION. */
+#define CRH_ABI_VERSION 3
 /* layout version of crh_scene_desc and of the scene blobs (crh_blob_save / crh_blob_load): the records have not changed since round 1 */
 #define CRH_SCENE_VERSION 1
 
@@ -348,8 +350,19 @@ int crh_bvh_build_triangles(crh_ctx *ctx, const crh_poly *polys, uint32_t poly_c
                             crh_bvh_node *nodes_out, int32_t *prim_indices_out, uint32_t *node_count_out, crh_bvh_build_stats *stats /* may be NULL */);
 
 /* Replaces "the CPU reads struct world directly": copies the flattened scene to HBM, derives the
- * device-side acceleration layout (leaf-ordered prepared triangles) and validates the node graph. */
+ * device-side acceleration layout (leaf-ordered prepared triangles) and validates the node graph.
+ * Lifetime contract: the library does NOT retain the description or any array it points to, and no copy out of them is still in flight when the call returns —
+ * the caller may release or overwrite them at once (renderer_hip.c frees the flattened scene while the first dispatch runs; tests/test_gpu_parity.py poisons them). */
 int crh_scene_upload(crh_ctx *ctx, const crh_scene_desc *scene);
+/* The same in two steps, for a process that renders one scene on several GPUs (round 5; the reference builds its scene once and every worker reads it:
+ * src/datatypes/scene.c:111-213): crh_scene_compile derives the device layout ONCE, on the host (no context, no device; `walk` = the CRH_OPT_WALK the contexts use),
+ * crh_scene_upload_compiled copies it to a context's GPU — it only reads the handle, so the contexts' threads may call it at the same time —, and
+ * crh_compiled_scene_free releases it (any time after the last upload has returned). The same lifetime contract: nothing of `scene` is retained. */
+typedef struct crh_compiled_scene crh_compiled_scene;
+int crh_scene_compile(const crh_scene_desc *scene, int walk, crh_compiled_scene **out);
+int crh_scene_upload_compiled(crh_ctx *ctx, const crh_compiled_scene *compiled);
+void crh_compiled_scene_free(crh_compiled_scene *compiled);
+void crh_debug_upload_counts(int *compiles, int *uploads);   /* debug / tests: layout compiles and uploads of this process so far */
 
 /* Device float-RGB framebuffer helpers (layout = state.renderBuffer: index (x + (H-1-y)*W)*3,
  * src/datatypes/image/texture.c:24-28). The framebuffer may also be any caller-owned device pointer. */

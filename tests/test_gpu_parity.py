@@ -558,6 +558,78 @@ def test_upload_lifecycle_host_arrays_released_behind_a_dispatch(pkg, manifest, 
     assert np.array_equal(frames[0].view(np.uint32), golden_ref("glowmetal").view(np.uint32))
 
 
+def test_upload_lifecycle_callers_arrays_poisoned_and_one_compile_for_two_contexts(pkg, manifest, golden_blob, golden_ref):
+    """The lifetime contract of include/cray_hip.h (round 5): crh_scene_upload retains nothing of the caller's description — every array it points to is
+    overwritten with 0xA5 right after the upload returns, and the frame is still the reference's (renderer_hip.c frees the flattened scene while the first dispatch runs).
+    The same for crh_scene_compile + crh_scene_upload_compiled: ONE layout compile, two contexts that copy it, the description poisoned and the handle freed before
+    either renders."""
+    import ctypes as C
+    api = pkg.api
+    m = manifest["cfg1_scene"]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    ref = golden_ref("cfg1_scene")
+
+    def poison(scene):
+        d = scene.desc
+        for ptr, count, size in ((d.nodes, d.node_count, 32), (d.prim_indices, d.prim_index_count, 4), (d.polys, d.poly_count, 40), (d.vertices, d.vertex_count, 12),
+                                 (d.normals, d.normal_count, 12), (d.texcoords, d.texcoord_count, 8), (d.texture_data, d.texture_bytes, 1)):
+            if int(count):
+                C.memset(C.cast(ptr, C.c_void_p), 0xA5, int(count) * size)
+
+    scene = api.Scene(golden_blob("cfg1_scene"))
+    c = api.Context(0)
+    c.upload(scene)
+    poison(scene)
+    fb = c.framebuffer(w, h)
+    c.render_region(fb, w, h, s, b)
+    assert np.array_equal(c.download(fb, w, h).view(np.uint32), ref.view(np.uint32))
+    c.close()
+
+    scene = api.Scene(golden_blob("cfg1_scene"))
+    compiles0, uploads0 = api.upload_counts()
+    compiled = api.CompiledScene(scene)
+    poison(scene)
+    ctxs = [api.Context(0), api.Context(0)]
+    for x in ctxs:
+        x.upload_compiled(compiled)
+    compiled.close()
+    assert api.upload_counts() == (compiles0 + 1, uploads0 + 2)
+    for x in ctxs:
+        fb = x.framebuffer(w, h)
+        x.render_region(fb, w, h, s, b)
+        assert np.array_equal(x.download(fb, w, h).view(np.uint32), ref.view(np.uint32))
+        assert x.counters()["rays"] == m["rays"]
+        x.close()
+    with pytest.raises(api.CrhError):          # a scene compiled for one walk does not go to a context set to the other
+        x = api.Context(0)
+        x.set_option(pkg.abi.OPT_WALK, pkg.abi.WALK_WIDE4)
+        try:
+            x.upload_compiled(api.CompiledScene(api.Scene(golden_blob("cfg1_scene"))))
+        finally:
+            x.close()
+
+
+def test_wide_walk_option_renders_the_fixtures(pkg, manifest, golden_blob, golden_ref):
+    """CRH_OPT_WALK = CRH_WALK_WIDE4 (round 5, an experiment kept as an option; the binary walk is the contract): the 4-ary walk renders these fixtures to the
+    reference's frames bit for bit — no ray of theirs meets a tie or a near tie (tools/wide_walk_study.py counts where others do) — with the same ray count, fewer
+    node steps (box tests / 4 against box tests / 2), and the launch names the wide instantiation."""
+    api, abi = pkg.api, pkg.abi
+    for name in ("cfg1_scene", "fence", "refraction"):
+        m = manifest[name]
+        w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+        c = api.Context(0)
+        c.set_option(abi.OPT_WALK, abi.WALK_WIDE4)
+        c.upload(api.Scene(golden_blob(name)))
+        fb = c.framebuffer(w, h)
+        c.reset_counters()
+        c.render_region(fb, w, h, s, b)
+        img, cnt = c.download(fb, w, h), c.counters()
+        assert "wide4" in c.last_kernel_name()
+        assert np.array_equal(img.view(np.uint32), golden_ref(name).view(np.uint32)), name
+        assert cnt["rays"] == m["rays"] and cnt["node_tests"] / 4 < 0.7 * m["node_tests"] / 2
+        c.close()
+
+
 def test_error_paths(pkg, ctx, golden_blob):
     api, abi = pkg.api, pkg.abi
     fresh = api.Context(0)

@@ -37,7 +37,7 @@ def emu_lib():
 GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of tests that must run and pass)
     "trace_rays": (["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6),
     "frames": (["test_gpu_parity.py"], "test_image_parity_vs_reference", 6),
-    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths or round_limit or upload_lifecycle", 11),
+    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths or round_limit or upload_lifecycle or wide_walk_option", 13),
     "rare_and_wg": (["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"], "test_gpu_node_zoo or test_gpu_volumes", 3),          # (test_gpu_volumes renders with both kernel forms;
     # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
@@ -275,11 +275,13 @@ def test_dropin_program_on_several_emulated_gpus(emu_lib, manifest, golden_ref, 
         scene = refrun.rewrite_scene("scene.json", w, h, m["samples"], m["bounces"], out_dir=str(tmp_path))
         for gpus in gpu_counts:
             dump = str(tmp_path / f"hip_{key}_{gpus}.f32")
-            env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES=str(gpus), HIPEMU_DEVICES=str(gpus), HIPEMU_CUS="2", HIPEMU_THREADS="4",
+            env = dict(os.environ, CRH_DUMP_F32=dump, CRAY_HIP_DEVICES=str(gpus), HIPEMU_DEVICES=str(gpus), HIPEMU_CUS="2", HIPEMU_THREADS="4", CRH_TRACE_UPLOAD="1",
                        LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
             proc = subprocess.run([exe, *mode], input=json.dumps(scene).encode(), cwd=overlay, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
             out = proc.stdout.decode(errors="replace")
             assert proc.returncode == 0 and f"on {gpus} GPUs" in out, out[-2000:]
+            # ONE layout compile for the frame's GPUs (round 5: every GPU thread used to compile the scene for itself), one copy per GPU
+            assert out.count("crh_scene_compile trace:") == 1 and out.count("crh_scene_upload_compiled trace:") == gpus and "crh_scene_upload trace: layout compile" not in out, out[-3000:]
             img = np.fromfile(dump, dtype=np.float32).reshape(h, w, 3)
             assert np.array_equal(img.view(np.uint32), golden_ref(key).view(np.uint32)), (key, gpus)
             bmp = [f for f in os.listdir(tmp_path) if f.endswith(".bmp")]

@@ -986,6 +986,9 @@ CRH_DEV bool sphereTest(const v3 o, const v3 d, float radius, float bound, float
 	return true;
 }
 
+/* one instance under a one-leaf top-level BVH (the triangle soups of BASELINE.json configs[4]): when its BLAS has been walked, the walk is over */
+CRH_DEV bool sceneIsOneInstance(const DScene &S) { return S.instance_count == 1u && S.tlas_node_count == 1u; }
+
 /* after a step that left no pending prims: continue with the next pair, pop one, leave the BLAS, or hand over (CTRL / SHADE) */
 /* A volume instance's BLAS walk ended (instance.c:196-214). Entry walk found the medium's near side -> start the exit walk from just
  * behind it (true: the lane keeps walking); exit walk found the far side -> sample the free flight; anything else -> no hit. */
@@ -1052,6 +1055,10 @@ CRH_DEV void walkAdvance(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &p
 	 * reads, far cheaper than a scheduling round at the occupancy such a step would get. */
 	if (w.instFound) { w.hit.inst = w.curInst; CRH_COUNT(cnt, inst_hits, 1); }
 	w.inBlas = 0; w.instFound = 0;
+	/* (round 5) a scene of ONE instance under a one-leaf top level — BASELINE's triangle soups — has nothing to return to: no resume pair, no further instance, an empty stack.
+	 * Nothing was parked (stepCtrl), and the walk is over; the restored state would have led here too (no pending range, no node, nothing to pop -> PH_SHADE). Until now a node or
+	 * triangle step ran the fifteen LDS reads below for the ONE lane that left its BLAS in every other iteration of a soup's wave. The test is on kernel arguments: a scalar branch */
+	if (sceneIsOneInstance(S)) { w.spBase = 0; w.phase = PH_SHADE; return; }
 	w.k.o = v3{asF32(stk.unpark(PK_OX)), asF32(stk.unpark(PK_OY)), asF32(stk.unpark(PK_OZ))};
 	w.k.d = v3{asF32(stk.unpark(PK_DX)), asF32(stk.unpark(PK_DY)), asF32(stk.unpark(PK_DZ))};
 	w.k.inv = v3{asF32(stk.unpark(PK_IX)), asF32(stk.unpark(PK_IY)), asF32(stk.unpark(PK_IZ))};
@@ -1264,11 +1271,13 @@ CRH_DEV void stepCtrl(const DScene &S, Walk &w, Stack &stk, Cnt &cnt, Port &port
 			rootA = CRH_DNODE_FIRST(n1); rootAe = rootA + CRH_DNODE_COUNT(n1);
 		}
 		if (enter) {
+			if (!sceneIsOneInstance(S)) {          /* (a one-instance scene's top-level walk has nothing left behind its only BLAS visit: walkAdvance does not come back for it) */
 			stk.park(PK_NODE, w.node); stk.park(PK_PA, w.pA); stk.park(PK_PAE, w.pAe); stk.park(PK_PB, w.pB); stk.park(PK_PBE, w.pBe);
 			stk.park(PK_OX, asU32(w.k.o.x)); stk.park(PK_OY, asU32(w.k.o.y)); stk.park(PK_OZ, asU32(w.k.o.z));
 			stk.park(PK_DX, asU32(w.k.d.x)); stk.park(PK_DY, asU32(w.k.d.y)); stk.park(PK_DZ, asU32(w.k.d.z));
 			stk.park(PK_IX, asU32(w.k.inv.x)); stk.park(PK_IY, asU32(w.k.inv.y)); stk.park(PK_IZ, asU32(w.k.inv.z));
 			stk.park(PK_OCT, w.k.oct);
+			}
 			if (kind == CRH_DINST_MESH_LEAF) { w.node = CRH_NONE; w.pA = rootA; w.pAe = rootAe; }
 			else { w.node = cnt_traits<Cnt>::wide ? asU32(instRadius(inst)) /* a mesh's wide root stands where a sphere's radius does */ : instRoot(inst); w.pA = w.pAe = 0; }
 			w.pB = w.pBe = 0;

@@ -54,6 +54,7 @@ DScene make_dscene(const crh_scene_desc *s, const CompiledScene &c, const WideBl
 	d.tlas_root = c.tlas_root; d.tlas_node_count = c.tlas_node_count; d.tlas_prim_base = c.tlas_prim_base; d.tlas_first = c.tlas_first;
 	d.material_count = (uint32_t)c.materials.size(); d.bsdf_count = (uint32_t)c.bsdfs.size(); d.const_count = (uint32_t)c.consts.size(); d.image_count = (uint32_t)c.images.size(); d.texture_count = (uint32_t)c.textures.size();
 	d.background = c.background; d.camera = &c.camera;
+	d.instance_count = (uint32_t)c.instances.size(); d.shade_classes = c.shade_classes;
 	if (wb && c.tlas_node_count > 1) d.tlas_root = c.wide_tlas_root;
 	return d;
 }

@@ -22,7 +22,7 @@ ins = []
 on = False
 for l in dis:
     if re.match(r"^[0-9a-f]+ <", l):
-        on = "k_pathtrace_rollILi1ELi4ELb0ELi0E" in l
+        on = "k_pathtrace_rollILi1ELi4ELb0ELi0ELb0EE" in l          # the bench instantiation (binary walk)
         continue
     if on:
         m = re.match(r"\s+(\S+).*//\s*([0-9A-F]+):", l)

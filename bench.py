@@ -207,7 +207,7 @@ def measured_profile(workload_key):
     valu = t.get("valu")
     sat = (calibration().get("k_mix") or {}).get("pipe_busy_at_saturation")
     if valu and valu.get("pipe_busy") and sat:
-        valu = dict(valu, calibration={"formula_reads_at_known_saturation": {k: round((calibration().get(k) or {}).get("pipe_busy_at_saturation") or 0, 3) for k in ("k_fma", "k_add", "k_mix")},
+        valu = dict(valu, bound="valu-issue" if valu["pipe_busy"] / sat >= 0.7 else "memory-latency + valu-issue", calibration={"formula_reads_at_known_saturation": {k: round((calibration().get(k) or {}).get("pipe_busy_at_saturation") or 0, 3) for k in ("k_fma", "k_add", "k_mix")},
                                        "of_saturated_rate": round(valu["pipe_busy"] / sat, 3),
                                        "note": "SQ_ACTIVE_INST_VALU counts one busy quad-cycle per vector instruction and SQ_WAVE_CYCLES quad-cycles per resident wave, so the formula reads "
                                                "vector instructions per SIMD quad-cycle — 1.6-1.7 for a saturating loop of the node step's blend (fma / min / max / cmp / cndmask), not 1.0: "

@@ -76,7 +76,7 @@ def main():
             need = ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU")
             if all(k in pmc for k in need):
                 g = lambda k: pmc[k]["per_dispatch"]
-                valu = {"bound": "valu-issue", "pipe_busy": round(g("SQ_ACTIVE_INST_VALU") / (g("SQ_WAVE_CYCLES") / 4.0), 4),
+                valu = {"bound": "see bench.py: measured_profile (the formula's reading is held against profiles/calibration.json there)", "pipe_busy": round(g("SQ_ACTIVE_INST_VALU") / (g("SQ_WAVE_CYCLES") / 4.0), 4),
                         "lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INSTS_VALU")), 4),
                         "valu_wave_instructions_per_launch": g("SQ_INSTS_VALU"),
                         "formulas": "pipe_busy = SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU)",

@@ -606,6 +606,7 @@ struct Compiler {
 				wideDepthMax = 0;
 				if (s->tlas_node_count > 1) tlasWide = buildWide(tlas.root, "TLAS");
 				out.wide_max_stack = 3u * (wideDepthMax + blasDepth) + 1u;
+				CHECK(out.wide_max_stack <= 134u, CRH_ERR_UNSUPPORTED, "the wide walk could need %u stack entries (device: 134)", out.wide_max_stack);
 				finishWide();
 				if (tlasWide != CRH_NONE) out.wide_tlas_root = wideAbs(tlasWide);
 				for (uint32_t k = 0; k < s->tlas_prim_count; ++k) {

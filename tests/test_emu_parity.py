@@ -49,6 +49,26 @@ def test_emulated_kernel_bit_exact_on_baseline_configs_reduced_frame(name, emu, 
     assert cnt["rays"] == m["rays"] and cnt["node_tests"] <= m["node_tests"] and cnt["node_tests"] >= 0.98 * m["node_tests"]
 
 
+@pytest.mark.parametrize("name", ["cfg1_scene", "fence", "refraction", "uvsphere"])
+def test_wide_walk_lane_code_renders_the_fixtures(name, emu, oracle, manifest, golden_blob, golden_ref):
+    """CRH_OPT_WALK = CRH_WALK_WIDE4 (round 5, an option; the binary walk is the contract): the scene compiler's 4-ary copy of the BVHs and pt_device.h's wide node step,
+    built for the host — these fixtures' frames are the reference's bit for bit (no ray of theirs meets a tie or a near tie: tools/wide_walk_study.py counts where others do),
+    with the same rays, at most 0.62 of the binary walk's node steps, and a stack that stays inside the wide walk's own bound."""
+    m = manifest[name]
+    scene = oracle.OracleScene(golden_blob(name))
+    emu.emu_set_walk.argtypes = [C.c_int]
+    emu.emu_set_walk(1)
+    try:
+        fb, cnt, high = emu_render(emu, oracle, scene, m["width"], m["height"], m["samples"], m["bounces"])
+    finally:
+        emu.emu_set_walk(0)
+    assert np.array_equal(fb.view(np.uint32), golden_ref(name).view(np.uint32)), f"{name}: {(fb != golden_ref(name)).sum()} floats differ"
+    assert cnt["rays"] == m["rays"]
+    if m["node_tests"] > 100 * m["rays"] // 10:          # (scenes with a BVH worth the name)
+        assert cnt["node_tests"] / 4 < 0.62 * m["node_tests"] / 2
+    assert high <= 134, "deeper than the device's stack (12 LDS entries + 122 in the overflow columns)"
+
+
 def test_emulated_kernel_interactive_mode_bit_exact(emu, oracle, manifest, golden_blob, golden_ref):
     """The Halton-sampler instantiation of the lane code (CRH_OPT_SAMPLER = CRH_SAMPLER_HALTON) against the reference's
     --iterative -j 1 frame: passes 1 .. samples-1, any chunking."""

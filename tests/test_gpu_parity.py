@@ -600,6 +600,18 @@ def test_upload_lifecycle_callers_arrays_poisoned_and_one_compile_for_two_contex
         assert np.array_equal(x.download(fb, w, h).view(np.uint32), ref.view(np.uint32))
         assert x.counters()["rays"] == m["rays"]
         x.close()
+    # error behaviour of the two-step upload: int codes and a message, like every entry point
+    import ctypes as C2
+    L = api.library()
+    h = C2.c_void_p()
+    assert L.crh_scene_compile(None, 0, C2.byref(h)) == pkg.abi.ERR_INVALID and not h.value
+    scene = api.Scene(golden_blob("cfg1_scene"))
+    assert L.crh_scene_compile(scene.ptr, 7, C2.byref(h)) == pkg.abi.ERR_INVALID and b"walk" in L.crh_last_error()
+    assert L.crh_scene_upload_compiled(None, None) == pkg.abi.ERR_INVALID
+    L.crh_compiled_scene_free(None)          # (a no-op, like free)
+    bad = pkg.abi.SceneDesc.from_buffer_copy(scene.desc)
+    bad.tlas_prim_count += 1
+    assert L.crh_scene_compile(C2.byref(bad), 0, C2.byref(h)) == pkg.abi.ERR_INVALID and not h.value and b"TLAS" in L.crh_last_error()
     with pytest.raises(api.CrhError):          # a scene compiled for one walk does not go to a context set to the other
         x = api.Context(0)
         x.set_option(pkg.abi.OPT_WALK, pkg.abi.WALK_WIDE4)

@@ -103,12 +103,14 @@ def _cfg4_worker(rank, world, port, w, h, out_path):
     dist.destroy_process_group()
 
 
-def test_scaling_cfg4_share_and_gather_at_full_frame_size(tmp_path):
-    """bench.py emits `scaling_cfg4` (statues.json 3840x2160, the scene BASELINE.json quotes the 1/2/4/8-GPU curve on) through the same strips + gather as the
-    headline: two gloo ranks assemble that frame size exactly — every pixel from exactly one owner."""
+@pytest.mark.parametrize("w,h,world", [(3840, 2160, 2), (2560, 1440, 3)])
+def test_scaling_cfg4_share_and_gather_at_full_frame_size(w, h, world, tmp_path):
+    """bench.py emits `scaling_cfg4` (statues.json 3840x2160, the scene BASELINE.json quotes the 1/2/4/8-GPU curve on) and — round 5 — `scaling_soup10m` (configs[4]'s
+    2560x1440 frame) through the same strips + gather as the headline: two (three: a world size that does not divide the 360 strips) gloo ranks assemble those frame
+    sizes exactly — every pixel from exactly one owner."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_cfg4_worker, args=(2, _free_port(), 3840, 2160, out), nprocs=2, join=True)
+    mp.spawn(_cfg4_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
     ok = np.load(out)
     assert ok[0] == 1.0 and ok[1] == 1.0
 

@@ -154,11 +154,19 @@ static struct {
 	int masterLive, makerLive[MAX_GPUS];
 } g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER, .joinMu = PTHREAD_MUTEX_INITIALIZER};
 
+/* CRAY_HIP_WALK=wide4: the frame renderer walks the 4-ary copy of the BVHs (CRH_OPT_WALK; venus.json +10 %, statues / soups +3 %, frames not bit-identical to the
+ * reference's where two hits nearly tie: an opt-in). Anything else: the reference's walk */
+static int frameWalk(void) {
+	const char *e = getenv("CRAY_HIP_WALK");
+	return e && !strcmp(e, "wide4") ? CRH_WALK_WIDE4 : CRH_WALK_BINARY;
+}
+
 static crh_ctx *makeContext(int device) {
 	crh_ctx *c = NULL;
 	/* counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
 	if (crh_context_create(device, NULL, &c) != CRH_OK) return NULL;
-	if (crh_set_option(c, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || (!getenv("CRH_DROPIN_NO_PREPARE") && crh_context_prepare(c) != CRH_OK)) {
+	if (crh_set_option(c, CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || crh_set_option(c, CRH_OPT_WALK, frameWalk()) != CRH_OK ||
+		(!getenv("CRH_DROPIN_NO_PREPARE") && crh_context_prepare(c) != CRH_OK)) {
 		crh_context_destroy(c);
 		return NULL;
 	}
@@ -390,7 +398,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	uint32_t ntiles[MAX_GPUS];
 	/* the process's pooled contexts (round 5, ADVICE r04: this mode used to create a second context per GPU beside the pool's); several GPUs: one layout compile */
 	crh_compiled_scene *compiled = NULL;
-	if (gpus > 1 && crh_scene_compile(scene, CRH_WALK_BINARY, &compiled) != CRH_OK) logr(error, "c-ray-hip: %s\n", crh_last_error());
+	if (gpus > 1 && crh_scene_compile(scene, frameWalk(), &compiled) != CRH_OK) logr(error, "c-ray-hip: %s\n", crh_last_error());          /* (the pooled contexts' CRH_OPT_WALK; the Halton sampler keeps the binary walk either way) */
 	for (int g = 0; g < gpus; ++g) {
 		ctx[g] = poolAcquire(g);
 		if (!ctx[g] || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
@@ -611,7 +619,7 @@ struct texture *renderFrame(struct renderer *r) {
 	/* several GPUs: ONE layout compile, here, behind the flattener; the GPU threads only copy (the reference builds its scene once and every worker reads it:
 	 * src/datatypes/scene.c:111-213). One GPU: its crh_scene_upload compiles with the texels' copy beside it */
 	crh_compiled_scene *compiled = NULL;
-	if (frc == CRH_OK && gpus > 1 && !getenv("CRH_DROPIN_COMPILE_PER_GPU") && crh_scene_compile(&scene, CRH_WALK_BINARY, &compiled) != CRH_OK) {
+	if (frc == CRH_OK && gpus > 1 && !getenv("CRH_DROPIN_COMPILE_PER_GPU") && crh_scene_compile(&scene, frameWalk(), &compiled) != CRH_OK) {
 		logr(warning, "c-ray-hip: %s\n", crh_last_error());
 		frc = CRH_ERR_INVALID;
 	}

@@ -128,6 +128,7 @@ EXPORTED_SYMBOLS = [
     "crh_synchronize", "crh_frames_reduce", "crh_frames_gather", "crh_frames_prepare", "crh_context_prepare", "crh_counters_get", "crh_counters_reset", "crh_kernel_time_ms", "crh_trace_rays",
     "crh_blob_save", "crh_blob_load", "crh_blob_free", "crh_bvh_build_triangles", "crh_debug_eval_math", "crh_debug_plan_units", "crh_last_kernel_name", "crh_framebuffer_strips_to_srgb8",
     "crh_scene_compile", "crh_scene_upload_compiled", "crh_compiled_scene_free", "crh_debug_upload_counts",
+    "crh_debug_ray_dump", "crh_debug_ray_dump_counts", "crh_debug_ray_dump_fetch", "crh_debug_walk_probe", "crh_debug_walk_probe_fetch", "crh_debug_walk_probe_compare",
 ]
 MATH_FUNCTIONS = ("sinf", "cosf", "sincosf_sin", "sincosf_cos", "logf", "log10f", "atanf", "acosf", "asinf", "tanf", "powf", "atan2f")   # enum crh_math_function
 

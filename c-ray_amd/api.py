@@ -84,6 +84,12 @@ def library():
         "crh_blob_save": (C.c_int, [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.BlobPrefs)]),
         "crh_blob_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(abi.SceneDesc)), C.POINTER(abi.BlobPrefs)]),
         "crh_blob_free": (None, [C.POINTER(abi.SceneDesc)]),
+        "crh_debug_ray_dump": (C.c_int, [ctx, C.c_uint32]),
+        "crh_debug_ray_dump_counts": (C.c_int, [ctx, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]),
+        "crh_debug_ray_dump_fetch": (C.c_int, [ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+        "crh_debug_walk_probe": (C.c_int, [ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+        "crh_debug_walk_probe_fetch": (C.c_int, [ctx, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+        "crh_debug_walk_probe_compare": (C.c_int, [ctx, C.POINTER(C.c_uint64)]),
         "crh_debug_plan_units": (C.c_int, [C.POINTER(abi.RenderParams), C.POINTER(abi.Tile), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     }
@@ -315,6 +321,39 @@ class Context:
             yp = y.ctypes.data
         _check(self.L.crh_debug_eval_math(self.h, abi.MATH_FUNCTIONS.index(function), x.ctypes.data, yp, x.size, out.ctypes.data), "crh_debug_eval_math")
         return out
+
+    # ---- round 6: the walk-only probe (debug / measurement; include/cray_hip.h) ----
+    def ray_dump(self, rays_per_wave):
+        _check(self.L.crh_debug_ray_dump(self.h, rays_per_wave), "crh_debug_ray_dump")
+
+    def ray_dump_counts(self, max_waves=8192):
+        total = C.c_uint64(0)
+        per = np.zeros(max_waves, dtype=np.uint32)
+        _check(self.L.crh_debug_ray_dump_counts(self.h, C.byref(total), per.ctypes.data, max_waves), "crh_debug_ray_dump_counts")
+        return int(total.value), per
+
+    def ray_dump_fetch(self, wave, first, n):
+        out = np.zeros((n, 6), dtype=np.float32)
+        _check(self.L.crh_debug_ray_dump_fetch(self.h, wave, first, n, out.ctypes.data), "crh_debug_ray_dump_fetch")
+        return out
+
+    def walk_probe(self, wps, stack_lds=12, inst_lds=True, fused=True, unit_rays=512, slot=0):
+        """-> (kernel ms, rays walked)"""
+        ms = C.c_float(0.0)
+        rays = C.c_uint64(0)
+        _check(self.L.crh_debug_walk_probe(self.h, wps, stack_lds, 1 if inst_lds else 0, 1 if fused else 0, unit_rays, slot, C.byref(ms), C.byref(rays)), "crh_debug_walk_probe")
+        return float(ms.value), int(rays.value)
+
+    def walk_probe_fetch(self, slot, wave, first, n):
+        hits = np.zeros((n, 4), dtype=np.float32)
+        inst = np.zeros(n, dtype=np.int32)
+        _check(self.L.crh_debug_walk_probe_fetch(self.h, slot, wave, first, n, hits.ctypes.data, inst.ctypes.data), "crh_debug_walk_probe_fetch")
+        return hits, inst
+
+    def walk_probe_compare(self):
+        d = C.c_uint64(0)
+        _check(self.L.crh_debug_walk_probe_compare(self.h, C.byref(d)), "crh_debug_walk_probe_compare")
+        return int(d.value)
 
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

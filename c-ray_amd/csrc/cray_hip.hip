@@ -350,6 +350,11 @@ __device__ __forceinline__ uint32_t laneRank(unsigned long long m) {
 #define CRH_WPS_OVERRIDE WPS
 #endif
 /* SAMP: 0 = Random sampler (renderThread), 1 = Halton (renderThreadInteractive) */
+/* the words of the wave-statistics buffer (CRH_OPT_WAVE_STATS): two per wave for up to CRH_WAVE_STATS_MAX waves, then the ray dump's descriptor — list address, rays per wave region, one
+ * count per wave (crh_debug_ray_dump; written by the counting instantiations of k_pathtrace_roll only) */
+#define CRH_WAVE_STATS_MAX 8192u
+#define CRH_DUMP_HDR (2u * CRH_WAVE_STATS_MAX)
+#define CRH_WAVE_STATS_WORDS (CRH_DUMP_HDR + 2u + CRH_WAVE_STATS_MAX)
 #include "pathtrace_roll.h"          /* k_pathtrace_roll: the hot kernel (CRH_KERNEL_ROLL) */
 #ifdef CRH_WITH_ALT_KERNELS
 #include "pathtrace_alt.h"           /* k_pathtrace (one unit at a time) and k_pathtrace_wg (workgroup-cooperative): emulation tier and A/B variant libraries only */
@@ -383,6 +388,8 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 		hits[i] = out;
 	}
 }
+
+#include "walk_probe.h"              /* k_walk_probe: the walk of k_pathtrace_roll on its own, on the path tracer's own rays (round 6: a measurement entry, crh_debug_walk_probe) */
 
 /* bounces <= 0: pathTrace() returns black (pathtrace.c:36); only the running mean moves (renderer.c:288-291) */
 __global__ void k_fold_black(const crh_render_params P, const crh_tile *tiles, uint32_t ntiles, float *fb, unsigned long long *counters) {
@@ -502,6 +509,15 @@ struct crh_ctx {
 	float *dDefer = nullptr;    /* samples of the split pixels of the dispatch in flight (k_fold_deferred folds them) */
 	size_t deferFloats = 0;
 	unsigned long long *dWaveStats = nullptr;   /* debug (CRH_OPT_WAVE_STATS) */
+	/* debug (crh_debug_ray_dump / crh_debug_walk_probe): the rays the counting kernel's waves started, one region of dumpCap rays per wave; the probe's two outputs, its
+	 * unit list / counter and its own stack-overflow columns (up to eight workgroups per CU) */
+	float *dDump = nullptr;
+	uint32_t dumpCap = 0;
+	f4 *dProbeHits[2] = {nullptr, nullptr};
+	int32_t *dProbeInst[2] = {nullptr, nullptr};
+	uint32_t *dProbeOvf = nullptr;
+	void *dProbeUnits = nullptr;
+	size_t probeUnitCap = 0;
 	uint32_t lastGrid = 0;
 	char lastKernel[64] = "";               /* the instantiation launchPathtrace launched last (crh_last_kernel_name) */
 	float *dStage = nullptr;
@@ -819,6 +835,11 @@ int crh_context_destroy(crh_ctx *c) {
 	releaseJanitor(c, true);
 	if (c->dSrgb) (void)hipFree(c->dSrgb);
 	if (c->dGather) (void)hipFree(c->dGather);
+	if (c->dWaveStats) (void)hipFree(c->dWaveStats);
+	if (c->dDump) (void)hipFree(c->dDump);
+	for (int i = 0; i < 2; ++i) { if (c->dProbeHits[i]) (void)hipFree(c->dProbeHits[i]); if (c->dProbeInst[i]) (void)hipFree(c->dProbeInst[i]); }
+	if (c->dProbeOvf) (void)hipFree(c->dProbeOvf);
+	if (c->dProbeUnits) (void)hipFree(c->dProbeUnits);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return CRH_OK;
@@ -834,7 +855,8 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			if (value < 1 || value > 8) return fail(CRH_ERR_INVALID, "blocks per CU must be 1..8");
 			c->blocksPerCU = (int)value; return CRH_OK;
 		case CRH_OPT_WAVE_STATS:
-			if (value && !c->dWaveStats) { if (hipMalloc((void **)&c->dWaveStats, 2 * 8192 * sizeof(unsigned long long)) != hipSuccess) return fail(CRH_ERR_HIP, "wave stats alloc"); }
+			if (value && !c->dWaveStats) { if (hipMalloc((void **)&c->dWaveStats, CRH_WAVE_STATS_WORDS * sizeof(unsigned long long)) != hipSuccess) return fail(CRH_ERR_HIP, "wave stats alloc");
+				if (hipMemset(c->dWaveStats, 0, CRH_WAVE_STATS_WORDS * sizeof(unsigned long long)) != hipSuccess) return fail(CRH_ERR_HIP, "wave stats clear"); }
 			if (!value && c->dWaveStats) { (void)hipFree(c->dWaveStats); c->dWaveStats = nullptr; }
 			return CRH_OK;
 		case CRH_OPT_WAVES_PER_SIMD:
@@ -1415,7 +1437,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	const int bw = plan.bw, bh = plan.bh, sbw = plan.sbw, sbh = plan.sbh, tbw = plan.tbw, tbh = plan.tbh, chunk = plan.chunk;
 	const uint32_t firstSmall = plan.firstSmall, firstTiny = plan.firstTiny, grid = plan.grid;
 	c->lastGrid = grid;
-	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > 8192) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
+	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > CRH_WAVE_STATS_MAX) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
 	{
 		size_t need = (size_t)grid * (wg ? 1 : CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
 		if (c->kernel == CRH_KERNEL_ROLL) need *= CRH_ROLL_SLOTS;      /* one sample slab per open job */
@@ -1844,6 +1866,179 @@ int crh_trace_rays(crh_ctx *c, const float *rays_host, uint64_t n, crh_hit *hits
 	if (dRays) (void)hipFree(dRays);
 	if (dHits) (void)hipFree(dHits);
 	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_trace_rays: ") + hipGetErrorString(e));
+	return CRH_OK;
+}
+
+/* ---- round 6: the walk-only probe (walk_probe.h). Debug entries: a measurement of the walk at occupancies the render kernel cannot reach, on the render
+ * kernel's own rays. Nothing of the product path calls them. ---- */
+
+/* The next dispatches of the counting kernel (CRH_OPT_COUNTER_LEVEL 2) record every ray a wave starts to walk, in the order it starts them, rays_per_wave of them per wave (0: off,
+ * the buffers are released). Turns CRH_OPT_WAVE_STATS on (the descriptor lives behind the wave statistics). */
+int crh_debug_ray_dump(crh_ctx *c, uint32_t rays_per_wave) {
+	if (!c) return fail(CRH_ERR_INVALID, "crh_debug_ray_dump: ctx is NULL");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	if (c->dDump) { (void)hipFree(c->dDump); c->dDump = nullptr; }
+	for (int i = 0; i < 2; ++i) {
+		if (c->dProbeHits[i]) { (void)hipFree(c->dProbeHits[i]); c->dProbeHits[i] = nullptr; }
+		if (c->dProbeInst[i]) { (void)hipFree(c->dProbeInst[i]); c->dProbeInst[i] = nullptr; }
+	}
+	c->dumpCap = 0;
+	if (!rays_per_wave) {
+		if (c->dWaveStats) HIP_TRY(hipMemset(c->dWaveStats + CRH_DUMP_HDR, 0, (2u + CRH_WAVE_STATS_MAX) * sizeof(unsigned long long)));
+		return CRH_OK;
+	}
+	rc = crh_set_option(c, CRH_OPT_WAVE_STATS, 1);
+	if (rc) return rc;
+	const size_t waves = (size_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
+	if (waves > CRH_WAVE_STATS_MAX) return fail(CRH_ERR_INVALID, "crh_debug_ray_dump: too many waves");
+	const size_t slots = waves * (size_t)rays_per_wave;
+	if (slots >= ((size_t)1 << 32)) return fail(CRH_ERR_INVALID, "crh_debug_ray_dump: more than 2^32 ray slots");
+	HIP_TRY(hipMalloc((void **)&c->dDump, slots * 6 * sizeof(float)));
+	for (int i = 0; i < 2; ++i) {
+		HIP_TRY(hipMalloc((void **)&c->dProbeHits[i], slots * sizeof(f4)));
+		HIP_TRY(hipMalloc((void **)&c->dProbeInst[i], slots * sizeof(int32_t)));
+		HIP_TRY(hipMemset(c->dProbeHits[i], 0, slots * sizeof(f4)));
+		HIP_TRY(hipMemset(c->dProbeInst[i], 0, slots * sizeof(int32_t)));
+	}
+	c->dumpCap = rays_per_wave;
+	std::vector<unsigned long long> hdr(2u + CRH_WAVE_STATS_MAX, 0ull);
+	hdr[0] = (unsigned long long)(uintptr_t)c->dDump; hdr[1] = rays_per_wave;
+	HIP_TRY(hipMemcpy(c->dWaveStats + CRH_DUMP_HDR, hdr.data(), hdr.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+	return CRH_OK;
+}
+
+/* rays in the list now (summed over the waves of the last counting dispatch that dumped); optionally every wave's count */
+int crh_debug_ray_dump_counts(crh_ctx *c, uint64_t *total, uint32_t *per_wave, uint32_t max_waves) {
+	if (!c || !c->dDump || !total) return fail(CRH_ERR_INVALID, "crh_debug_ray_dump_counts: no ray dump");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	std::vector<unsigned long long> cnt(CRH_WAVE_STATS_MAX);
+	HIP_TRY(hipMemcpy(cnt.data(), c->dWaveStats + CRH_DUMP_HDR + 2, cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	*total = 0;
+	for (size_t i = 0; i < cnt.size(); ++i) { *total += cnt[i]; if (per_wave && i < max_waves) per_wave[i] = (uint32_t)cnt[i]; }
+	return CRH_OK;
+}
+
+/* copy rays [first, first + n) of wave region `wave` (six floats each) to the host: lets a test hand the same rays to crh_trace_rays */
+int crh_debug_ray_dump_fetch(crh_ctx *c, uint32_t wave, uint32_t first, uint32_t n, float *rays6_host) {
+	if (!c || !c->dDump || !rays6_host) return fail(CRH_ERR_INVALID, "crh_debug_ray_dump_fetch: no ray dump");
+	if ((uint64_t)first + n > c->dumpCap) return fail(CRH_ERR_INVALID, "crh_debug_ray_dump_fetch: beyond the wave's region");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpy(rays6_host, c->dDump + ((size_t)wave * c->dumpCap + first) * 6, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+	return CRH_OK;
+}
+
+/* ... and the probe's hits for the same rays (out slot 0 / 1): t, u, v, slot bits per ray, and the instance (TLAS leaf order, -1: miss) */
+int crh_debug_walk_probe_fetch(crh_ctx *c, int slot, uint32_t wave, uint32_t first, uint32_t n, float *hits4_host, int32_t *inst_host) {
+	if (!c || !c->dDump || slot < 0 || slot > 1 || !hits4_host || !inst_host) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe_fetch: bad argument");
+	if ((uint64_t)first + n > c->dumpCap) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe_fetch: beyond the wave's region");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpy(hits4_host, c->dProbeHits[slot] + ((size_t)wave * c->dumpCap + first), (size_t)n * sizeof(f4), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(inst_host, c->dProbeInst[slot] + ((size_t)wave * c->dumpCap + first), (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+	return CRH_OK;
+}
+
+/* Walk the dumped rays with k_walk_probe<wps, stack_lds, inst_lds, fused> (wps 0: the one-ray-per-lane reference form) into output `slot`; unit_rays = rays per unit of its work queue.
+ * Supported (wps, stack_lds, inst_lds): see the table below. Reports the kernel's time (HIP events on the context's stream) and the rays walked. */
+int crh_debug_walk_probe(crh_ctx *c, int wps, int stack_lds, int inst_lds, int fused, uint32_t unit_rays, int slot, float *ms_out, uint64_t *rays_out) {
+	if (!c || !c->dDump || slot < 0 || slot > 1) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe: no ray dump (crh_debug_ray_dump, then a counting dispatch)");
+	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe: no scene uploaded");
+	if (c->hasVolumes) return fail(CRH_ERR_UNSUPPORTED, "crh_debug_walk_probe: the scene has volume instances (their walks draw from the path's sampler)");
+	if (unit_rays < 64) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe: at least 64 rays per unit");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	const size_t dumpWaves = (size_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64);
+	std::vector<unsigned long long> cnt(CRH_WAVE_STATS_MAX);
+	HIP_TRY(hipMemcpy(cnt.data(), c->dWaveStats + CRH_DUMP_HDR + 2, cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	/* the queue: piece k of every wave's region before piece k + 1 of any, so that the waves of the probe work at about the same depth of the path tracer's waves' histories */
+	std::vector<ProbeUnit> units;
+	uint64_t total = 0;
+	unsigned long long deepest = 0;
+	for (size_t w = 0; w < dumpWaves; ++w) { total += cnt[w]; deepest = std::max(deepest, cnt[w]); }
+	for (unsigned long long k = 0; k * unit_rays < deepest; ++k)
+		for (size_t w = 0; w < dumpWaves; ++w)
+			if (k * unit_rays < cnt[w]) units.push_back(ProbeUnit{(uint32_t)(w * c->dumpCap + k * unit_rays), (uint32_t)std::min<unsigned long long>(unit_rays, cnt[w] - k * unit_rays)});
+	if (rays_out) *rays_out = total;
+	if (units.empty()) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe: the ray list is empty");
+	if ((units.size() + 1) * sizeof(ProbeUnit) > c->probeUnitCap) {
+		if (c->dProbeUnits) (void)hipFree(c->dProbeUnits);
+		c->dProbeUnits = nullptr; c->probeUnitCap = 0;
+		HIP_TRY(hipMalloc(&c->dProbeUnits, (units.size() + 1) * sizeof(ProbeUnit)));
+		c->probeUnitCap = (units.size() + 1) * sizeof(ProbeUnit);
+	}
+	/* word 0 of the buffer is the queue's counter, the units follow */
+	HIP_TRY(hipMemset(c->dProbeUnits, 0, sizeof(ProbeUnit)));
+	HIP_TRY(hipMemcpy((ProbeUnit *)c->dProbeUnits + 1, units.data(), units.size() * sizeof(ProbeUnit), hipMemcpyHostToDevice));
+	const size_t ovfWords = (size_t)c->cuCount * 8u * (CRH_BLOCK / 64) * CRH_OVF_WORDS_PER_WAVE;
+	if (!c->dProbeOvf) HIP_TRY(hipMalloc((void **)&c->dProbeOvf, ovfWords * sizeof(uint32_t)));
+	crh_ctx::Timed ev;
+	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
+	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
+	hipError_t e = hipSuccess;
+	bool launched = false;
+	const uint32_t slots = (uint32_t)(dumpWaves * c->dumpCap);
+	if (wps == 0) {
+		HIP_TRY(hipEventRecord(ev.a, c->stream));
+		hipLaunchKernelGGL(k_walk_simple, dim3((uint32_t)c->cuCount * 8u), dim3(CRH_BLOCK), 0, c->stream, c->d, c->dDump, (uint64_t)slots, c->dWaveStats + CRH_DUMP_HDR + 2, c->dumpCap, c->dProbeHits[slot], c->dProbeInst[slot], (uint32_t)c->sched.rayFlags);
+		e = hipGetLastError();
+		HIP_TRY(hipEventRecord(ev.b, c->stream));
+		launched = true;
+	}
+#define CRH_PROBE_VARIANT(W, N, I, F) \
+	if (!launched && wps == W && stack_lds == N && (inst_lds != 0) == I && (fused != 0) == F) { \
+		hipFuncAttributes fa; \
+		HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_walk_probe<W, N, I, F>)); \
+		const size_t want = (163840u / W) & ~511u;          /* a CU's 160 KB hold exactly W workgroups of this size */ \
+		if (fa.sharedSizeBytes > want) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe: this variant's LDS does not fit its occupancy"); \
+		const size_t pad = want - fa.sharedSizeBytes; \
+		snprintf(c->lastKernel, sizeof(c->lastKernel), "k_walk_probe<%d,%d,%s,%s> vgpr %d lds %zu+%zu", W, N, I ? "true" : "false", F ? "fused" : "lean", fa.numRegs, (size_t)fa.sharedSizeBytes, pad); \
+		HIP_TRY(hipEventRecord(ev.a, c->stream)); \
+		hipLaunchKernelGGL((k_walk_probe<W, N, I, F>), dim3((uint32_t)c->cuCount * W), dim3(CRH_BLOCK), pad, c->stream, c->d, c->dDump, (const ProbeUnit *)c->dProbeUnits + 1, (uint32_t)units.size(), \
+		                   (uint32_t *)c->dProbeUnits, c->dProbeHits[slot], c->dProbeInst[slot], c->sched, c->dProbeOvf); \
+		e = hipGetLastError(); \
+		HIP_TRY(hipEventRecord(ev.b, c->stream)); \
+		launched = true; \
+	}
+	CRH_PROBE_VARIANT(4, 12, true, true)
+	CRH_PROBE_VARIANT(4, 12, true, false)
+	CRH_PROBE_VARIANT(4, 4, false, false)
+	CRH_PROBE_VARIANT(5, 12, true, true)
+	CRH_PROBE_VARIANT(5, 12, true, false)
+	CRH_PROBE_VARIANT(6, 7, true, true)
+	CRH_PROBE_VARIANT(6, 7, true, false)
+	CRH_PROBE_VARIANT(6, 4, false, false)
+	CRH_PROBE_VARIANT(7, 3, true, false)
+	CRH_PROBE_VARIANT(8, 4, false, false)
+#undef CRH_PROBE_VARIANT
+	if (!launched) { c->eventPool.push_back(ev); return fail(CRH_ERR_INVALID, "crh_debug_walk_probe: no such variant (wps, stack_lds, inst_lds)"); }
+	if (e != hipSuccess) { c->eventPool.push_back(ev); return fail(CRH_ERR_HIP, std::string("crh_debug_walk_probe: ") + hipGetErrorString(e)); }
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	float ms = 0.0f;
+	HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+	c->eventPool.push_back(ev);
+	if (ms_out) *ms_out = ms;
+	return CRH_OK;
+}
+
+/* hits (bit patterns of t, u, v, slot; instance) that differ between the probe's two outputs, over every slot of the list */
+int crh_debug_walk_probe_compare(crh_ctx *c, uint64_t *differ) {
+	if (!c || !c->dDump || !differ) return fail(CRH_ERR_INVALID, "crh_debug_walk_probe_compare: no ray dump");
+	int rc = crh_synchronize(c);
+	if (rc) return rc;
+	const uint64_t slots = (uint64_t)c->cuCount * c->blocksPerCU * (CRH_BLOCK / 64) * c->dumpCap;
+	unsigned long long *d = nullptr, h = 0;
+	HIP_TRY(hipMalloc((void **)&d, sizeof(h)));
+	HIP_TRY(hipMemset(d, 0, sizeof(h)));
+	hipLaunchKernelGGL(k_probe_compare, dim3((uint32_t)c->cuCount * 8u), dim3(256), 0, c->stream, c->dProbeHits[0], c->dProbeInst[0], c->dProbeHits[1], c->dProbeInst[1], slots, d);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("crh_debug_walk_probe_compare: ") + hipGetErrorString(e));
+	*differ = h;
 	return CRH_OK;
 }
 

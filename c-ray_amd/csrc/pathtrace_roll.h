@@ -98,6 +98,17 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 	 * the global counters — one fire-and-forget atomic by lane 0 per event, no contention — instead of through two dozen registers per lane that are summed at the end:
 	 * those registers were 70 spilled VGPRs, and the counting kernel's step clocks were not the timed kernel's */
 	unsigned long long *const waveCtr = counters + CRH_NCOUNTERS + (size_t)__builtin_amdgcn_readfirstlane(wave) * CRH_NCOUNTERS;          /* (64-bit words: a busy wave's clocks wrap 32 bits in two seconds) */
+	/* round 6, the counting instantiations only (crh_debug_ray_dump; walk_probe.h): every ray this wave starts to walk goes — in the order it starts them — into the wave's own
+	 * region of a global list, so that a walk-only kernel can be timed on the path tracer's own rays in the path tracer's own order. The descriptor sits behind the wave
+	 * statistics (CRH_OPT_WAVE_STATS): list address, rays per region, then one count per wave. */
+	float *dumpRays = nullptr;
+	uint32_t dumpCap = 0, dumpCount = 0;
+	if constexpr (LEVEL >= 2) {
+		if (waveStats) {
+			const unsigned long long base = waveStats[CRH_DUMP_HDR];
+			if (base) { dumpCap = (uint32_t)waveStats[CRH_DUMP_HDR + 1]; dumpRays = (float *)(__attribute__((address_space(1))) float *)(uintptr_t)base + (size_t)__builtin_amdgcn_readfirstlane(wave) * dumpCap * 6u; }
+		}
+	}
 #define CRH_WCTR(k, v) atomicAdd(&waveCtr[k], (unsigned long long)(uint32_t)(v))
 	__shared__ int s_rq[(CRH_BLOCK / 64) * RQ_WORDS];
 	__shared__ __attribute__((aligned(2))) uint8_t s_ids[(CRH_BLOCK / 64) * CRH_ROLL_IDS_BYTES];
@@ -208,7 +219,11 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 			const f4 *q = ptab + myPath * CRH_PATH_F4;
 			const f4 q0 = q[0], q1 = q[1];
 			{ TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4}; walkBegin(S, w, stk, v3{q0.x, q0.y, q0.z}, v3{q1.x, q1.y, q1.z}, cnt, port2, (uint32_t)K.rayFlags); }
+			if constexpr (LEVEL >= 2) {
+				if (dumpRays && dumpCount + er < dumpCap) { float *o = dumpRays + (size_t)(dumpCount + er) * 6u; o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q1.x; o[4] = q1.y; o[5] = q1.z; }
+			}
 		}
+		if constexpr (LEVEL >= 2) dumpCount += (uint32_t)take;
 		hq += (int)__popcll(hm); mq += (int)__popcll(mm); rq -= take;
 		if (lane == 0) { wq[RQ_HITS] = hq; wq[RQ_MISSES] = mq; wq[RQ_RAYS] = rq; }
 		__threadfence_block();
@@ -617,6 +632,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 #endif
 	}
 	const bool lead = (lane == 0);
+	if constexpr (LEVEL >= 2) { if (dumpRays && lead) waveStats[CRH_DUMP_HDR + 2 + wave] = min(dumpCount, dumpCap); }
 	uint32_t v;
 	v = waveSum(cnt.paths); if (lead && v) atomicAdd(&counters[0], (unsigned long long)v);
 	v = waveSum(cnt.rays); if (lead && v) atomicAdd(&counters[1], (unsigned long long)v);

@@ -333,6 +333,20 @@ int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);
 int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out24);   /* debug: 24 values — per-step-kind clocks (10 ns ticks), step counts and lanes served of the counter-level-2 kernel */
 
+/* Round 6, debug / measurement entries (nothing of the drop-in path calls them): the WALK of the path-tracing kernel on its own — getClosestIsect (src/renderer/pathtrace.c:26-30 ->
+ * src/accelerators/bvh.c:354-441, 443-496) with the render kernel's lane code and node run, without generation, shading or fold — at occupancies the render kernel cannot reach,
+ * on the render kernel's own rays. crh_debug_ray_dump(ctx, n): the following dispatches at CRH_OPT_COUNTER_LEVEL 2 record every ray a wave starts to walk, in the order it starts
+ * them, up to n per wave (n = 0: off, buffers released). crh_debug_walk_probe walks the recorded rays with k_walk_probe<wps, stack_lds, inst_lds, fused> (csrc/walk_probe.h: waves per
+ * SIMD, traversal-stack entries in LDS, instance records in LDS, the fused node run or the lean one; wps = 0: one ray per lane from start to end, the form the others are checked
+ * against) into output `slot` (0 / 1) and reports the kernel's time; crh_debug_walk_probe_compare counts the hits whose bits differ between the two outputs;
+ * the two fetch entries copy a stretch of one wave's rays (six floats each: origin, direction) / hits (t, u, v, BLAS prim slot bits; instance in top-level leaf order or -1). */
+int crh_debug_ray_dump(crh_ctx *ctx, uint32_t rays_per_wave);
+int crh_debug_ray_dump_counts(crh_ctx *ctx, uint64_t *total_out, uint32_t *per_wave_out, uint32_t max_waves);
+int crh_debug_ray_dump_fetch(crh_ctx *ctx, uint32_t wave, uint32_t first, uint32_t n, float *rays6_host);
+int crh_debug_walk_probe(crh_ctx *ctx, int wps, int stack_lds, int inst_lds, int fused, uint32_t unit_rays, int slot, float *ms_out, uint64_t *rays_out);
+int crh_debug_walk_probe_fetch(crh_ctx *ctx, int slot, uint32_t wave, uint32_t first, uint32_t n, float *hits4_host, int32_t *inst_host);
+int crh_debug_walk_probe_compare(crh_ctx *ctx, uint64_t *differ_out);
+
 /* SURVEY.md 8(f) row 1 — replaces buildBottomLevelBvh() (src/accelerators/bvh.c:299-301 -> buildBvhGeneric, bvh.c:245-287,
  * with getPolyBBoxAndCenter, bvh.c:289-297): the reference's binned-SAH builder on the GPU. The result is THE reference's
  * tree: nodes_out[0 .. *node_count_out) equal its struct bvhNode array (bounds bit for bit, child / first-prim indices,

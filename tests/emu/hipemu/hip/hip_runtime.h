@@ -252,6 +252,9 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
+/* (crh_debug_walk_probe sizes its LDS pad by the kernel's static LDS: nothing to pad here) */
+struct hipFuncAttributes { size_t sharedSizeBytes; int numRegs; };
+static inline hipError_t hipFuncGetAttributes(hipFuncAttributes *a, const void *) { a->sharedSizeBytes = 0; a->numRegs = 0; return hipSuccess; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
 	hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

@@ -1029,3 +1029,49 @@ def test_cluster_worker_renders_its_tiles_on_the_gpu(float_tiles, pkg, oracle, m
         assert (t["beginX"], t["beginY"], t["endX"], t["endY"]) == (x0, y0, x1, y1)
         want = golden_ref("cfg1_scene")[h - y1:h - y0, x0:x1] if float_tiles else expected8[h - y1:h - y0, x0:x1]
         assert np.array_equal(px.view(np.uint32) if float_tiles else px, want.view(np.uint32) if float_tiles else want), f"tile {num} {tiles[num]} differs from the reference's frame"
+
+
+PROBE_VARIANTS = [(4, 12, True, True), (4, 12, True, False), (5, 12, True, False), (6, 7, True, False), (6, 4, False, False), (8, 4, False, False)]
+
+
+@pytest.mark.parametrize("name", ["cfg1_scene", "fence"])
+def test_walk_probe_equals_the_plain_walk_on_the_path_tracers_own_rays(name, pkg, ctx, manifest, golden_blob):
+    """Round 6's measurement kernel (csrc/walk_probe.h: the render kernel's walk on its own, at 4 - 8 waves per SIMD) is held to the walk's bar: the counting kernel
+    records every ray its waves start (crh_debug_ray_dump; as many as the dispatch counts), k_walk_probe walks them in every variant the measurement uses, and every hit
+    — distance, barycentrics, BLAS prim slot, instance, bit patterns — equals the one-ray-per-lane walk's (k_trace_rays' loop); a stretch of them also goes through crh_trace_rays."""
+    m = manifest[name]
+    w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+    ctx.set_option(pkg.abi.OPT_COUNTER_LEVEL, 2)
+    ctx.upload(pkg.api.Scene(golden_blob(name)))
+    fb = ctx.framebuffer(w, h)
+    try:
+        cap = 1 << 11
+        while True:          # (a wave's region must hold every ray the wave starts: 4096 waves on the MI355X, a few dozen on the kernel emulation)
+            ctx.ray_dump(cap)
+            ctx.clear(fb, w, h)
+            ctx.reset_counters()
+            ctx.render_region(fb, w, h, s, b)
+            cnt = ctx.counters()
+            total, per = ctx.ray_dump_counts()
+            if per.max() < cap or cap >= 1 << 19:
+                break
+            cap *= 4
+        assert total == cnt["rays"] == m["rays"], (total, cnt["rays"], m["rays"])          # every ray of the frame was recorded (no wave overran its region)
+        ms, rays = ctx.walk_probe(0, slot=0)
+        assert rays == total
+        for wps, nlds, inst, fused in PROBE_VARIANTS:
+            ms, rays = ctx.walk_probe(wps, nlds, inst, fused, unit_rays=128, slot=1)
+            assert rays == total
+            assert ctx.walk_probe_compare() == 0, (wps, nlds, inst, fused, ctx.last_kernel_name())
+        wave = int(np.argmax(per))
+        n = int(min(per[wave], 4096))
+        r6 = ctx.ray_dump_fetch(wave, 0, n)
+        hits, inst = ctx.walk_probe_fetch(1, wave, 0, n)
+        ref = ctx.trace_rays(r6)
+        assert np.array_equal((inst >= 0), (ref["inst"] >= 0))
+        hit = inst >= 0
+        assert hit.sum() > 50
+        assert np.array_equal(hits[hit, 0].view(np.uint32), ref["distance"][hit].view(np.uint32))
+    finally:
+        ctx.ray_dump(0)
+        ctx.set_option(pkg.abi.OPT_WAVE_STATS, 0)

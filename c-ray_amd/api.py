@@ -341,7 +341,7 @@ class Context:
         """-> (kernel ms, rays walked)"""
         ms = C.c_float(0.0)
         rays = C.c_uint64(0)
-        _check(self.L.crh_debug_walk_probe(self.h, wps, stack_lds, 1 if inst_lds else 0, 1 if fused else 0, unit_rays, slot, C.byref(ms), C.byref(rays)), "crh_debug_walk_probe")
+        _check(self.L.crh_debug_walk_probe(self.h, wps, stack_lds, 1 if inst_lds else 0, int(fused), unit_rays, slot, C.byref(ms), C.byref(rays)), "crh_debug_walk_probe")
         return float(ms.value), int(rays.value)
 
     def walk_probe_fetch(self, slot, wave, first, n):

@@ -8,8 +8,8 @@
  * list, hits go out to a global list. The list is the path tracer's own: a counting dispatch of k_pathtrace_roll dumps every ray a wave starts to walk, wave by wave, in the
  * order it started them (crh_debug_ray_dump), so that a probe wave works through the rays ONE wave of the path tracer walked together — the coherence is the path tracer's.
  *
- * Template parameters: FUSED = the node run of pathtrace_roll.h as it is (node pairs and triangles requested together, six quarters carried through the run) or the lean
- * form (every step loads its own records); WPS = waves per SIMD the register allocator must leave room for (and, with the LDS pad of the launch, the workgroups a CU holds); NLDS = traversal-stack
+ * Template parameters: FORM = 1: the node run of pathtrace_roll.h as it is (node pairs and triangles requested together, six quarters carried through the run), 0: the lean
+ * run (every step loads its own records), 3: the lean run with one site per step kind; WPS = waves per SIMD the register allocator must leave room for (and, with the LDS pad of the launch, the workgroups a CU holds); NLDS = traversal-stack
  * entries in LDS (deeper ones in the per-wave overflow columns, as in the render kernel); INST = line 0 of the instance records staged in LDS (scenes of <= 64 instances).
  * WPS = 0 is the reference form for the check: one ray per lane, traverse() to the end (k_trace_rays' loop), same output format — the probe's hits must equal it bit for bit.
  */
@@ -47,7 +47,7 @@ struct WalkOnlyCounters { static constexpr int level = 0; static constexpr bool 
 /* a unit of the probe's work queue: `count` consecutive rays of the list from `first` on (one wave's rays of the dump, cut into pieces) */
 struct ProbeUnit { uint32_t first, count; };
 
-template <int WPS, int NLDS, bool INST, bool FUSED>
+template <int WPS, int NLDS, bool INST, int FORM>
 __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_walk_probe(const DScene Sarg, const float *raysArg, const ProbeUnit *unitsArg, uint32_t nUnits, uint32_t *unitCounter,
                                                                f4 *hitsArg, int32_t *hitInstArg, const Sched K, uint32_t *ovfAll) {
 	__shared__ uint32_t s_stack[(NLDS > 0 ? NLDS : 1) * CRH_BLOCK];
@@ -113,13 +113,37 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_walk_probe(const DScene Sarg
 		const int walkers = nN + nT + nC;
 		const bool more = !dry || cur != end;
 		if (walkers == 0 && nF == 0 && !more) break;
+		if constexpr (FORM == 3) {
+			/* the lean run with ONE site per step kind (the register allocator sees the largest step, not the sum of the copies that the round-level steps and the run's
+			 * in-place steps inline): the round picks a mode by the render kernel's rules — 0 a node run, 1 a triangle run, 2 one control step, 3 retire + refill — and one loop
+			 * body serves all four */
+			int mode = 0;
+			if (walkers == 0 || (nF + nE >= K.swapMin && (nF > 0 || more))) mode = 3;
+			else { int best = nN * K.wNode; if (nT * K.wTri > best) { best = nT * K.wTri; mode = 1; } if (nC * K.wCtrl > best) mode = 2; }
+			const int n0 = mode == 1 ? nT : nN;
+			bool again;
+			do {
+				if (mode == 0 && w.phase == PH_NODE) stepNode<true>(S, w, stk, cnt, port);
+				const int nTw = (int)__popcll(__ballot(w.phase == PH_TRI));
+				if (mode == 1 || (mode == 0 && nTw >= K.triInRun)) { if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port); }
+				const int nCw = (int)__popcll(__ballot(w.phase == PH_CTRL));
+				if (mode == 2 || (mode == 0 && nCw >= K.ctrlInRun)) {
+					if (w.phase == PH_CTRL) stepCtrl(S, w, stk, cnt, port);
+					if (mode == 2 && __ballot(w.phase == PH_NODE_SLOW)) { if (w.phase == PH_NODE_SLOW) stepNodeAny<false>(S, w, stk, cnt, port); }
+				}
+				const int nFi = (int)__popcll(__ballot(w.phase == PH_SHADE)), nEi = (int)__popcll(__ballot(w.phase == PH_IDLE));
+				if (mode == 3 || (mode == 0 && nFi + nEi >= K.swapInRun && (nFi > 0 || !dry || cur != end))) retireRefill();
+				again = mode == 0 ? (int)__popcll(__ballot(w.phase == PH_NODE)) * 8 >= n0 * K.runNum : mode == 1 ? (int)__popcll(__ballot(w.phase == PH_TRI)) * 8 >= n0 * K.runNum : false;
+			} while (again);
+			continue;
+		}
 		if (walkers == 0 || (nF + nE >= K.swapMin && (nF > 0 || more))) { retireRefill(); continue; }
 		int best = nN * K.wNode, pick = 0;
 		if (nT * K.wTri > best) { best = nT * K.wTri; pick = 1; }
 		if (nC * K.wCtrl > best) { best = nC * K.wCtrl; pick = 2; }
 		if (pick == 0) {
 			int now = nN;
-			if constexpr (!FUSED) {
+			if constexpr (FORM == 0) {
 				/* the LEAN run: the same steps and thresholds, but every step requests its own records and waits for them (the unfused loop of round 3) — no six quarters live
 				 * across the run, which is what lets the register allocator go below 100 registers without spilling */
 				do {

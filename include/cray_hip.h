@@ -343,7 +343,7 @@ int crh_debug_phase_ticks(crh_ctx *ctx, uint64_t *out24);   /* debug: 24 values 
 int crh_debug_ray_dump(crh_ctx *ctx, uint32_t rays_per_wave);
 int crh_debug_ray_dump_counts(crh_ctx *ctx, uint64_t *total_out, uint32_t *per_wave_out, uint32_t max_waves);
 int crh_debug_ray_dump_fetch(crh_ctx *ctx, uint32_t wave, uint32_t first, uint32_t n, float *rays6_host);
-int crh_debug_walk_probe(crh_ctx *ctx, int wps, int stack_lds, int inst_lds, int fused, uint32_t unit_rays, int slot, float *ms_out, uint64_t *rays_out);
+int crh_debug_walk_probe(crh_ctx *ctx, int wps, int stack_lds, int inst_lds, int form, uint32_t unit_rays, int slot, float *ms_out, uint64_t *rays_out);
 int crh_debug_walk_probe_fetch(crh_ctx *ctx, int slot, uint32_t wave, uint32_t first, uint32_t n, float *hits4_host, int32_t *inst_host);
 int crh_debug_walk_probe_compare(crh_ctx *ctx, uint64_t *differ_out);
 

@@ -1031,7 +1031,7 @@ def test_cluster_worker_renders_its_tiles_on_the_gpu(float_tiles, pkg, oracle, m
         assert np.array_equal(px.view(np.uint32) if float_tiles else px, want.view(np.uint32) if float_tiles else want), f"tile {num} {tiles[num]} differs from the reference's frame"
 
 
-PROBE_VARIANTS = [(4, 12, True, True), (4, 12, True, False), (5, 12, True, False), (6, 7, True, False), (6, 4, False, False), (8, 4, False, False)]
+PROBE_VARIANTS = [(4, 12, True, 1), (4, 12, True, 0), (4, 12, True, 3), (5, 12, True, 3), (6, 7, True, 3), (7, 3, True, 3), (8, 4, False, 3)]          # (waves per SIMD, LDS stack entries, instance records in LDS, form of the node run)
 
 
 @pytest.mark.parametrize("name", ["cfg1_scene", "fence"])

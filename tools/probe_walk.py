@@ -18,7 +18,7 @@ pkg = load_package(); api = pkg.api; abi = pkg.abi
 SCENES = {          # name -> (bench workload key, width, height, bounces, rays per path (to size the dispatch))
     "cfg4_statues": ("cfg4", 3840, 2160, 30, 3.45), "soup_10m": ("soup10m", 2560, 1440, 8, 3.52), "cfg2_hdr": ("cfg2", 1280, 720, 8, 2.47),
     "soup_1m": ("soup", 2560, 1440, 8, 3.36), "cfg3_venus": ("cfg3", 1920, 1080, 32, 6.12)}
-VARIANTS = [(4, 12, 1, 1), (4, 12, 1, 0), (4, 4, 0, 0), (5, 12, 1, 1), (5, 12, 1, 0), (6, 7, 1, 1), (6, 7, 1, 0), (6, 4, 0, 0), (7, 3, 1, 0), (8, 4, 0, 0)]
+VARIANTS = [(4, 12, 1, 1), (4, 12, 1, 0), (2, 12, 1, 3), (3, 12, 1, 3), (4, 12, 1, 3), (4, 7, 1, 3), (4, 3, 1, 3), (4, 4, 0, 3), (5, 12, 1, 3), (6, 7, 1, 3), (7, 3, 1, 3), (8, 4, 0, 3)]
 if os.environ.get("PROBE_VARIANTS"):
     VARIANTS = [tuple(int(x) for x in v.split(".")) for v in os.environ["PROBE_VARIANTS"].split(",")]
 want_rays = float(os.environ.get("PROBE_RAYS", "64e6"))
@@ -67,11 +67,11 @@ for name in names:
         try:
             msv = None
             for _ in range(2):
-                m, _r = ctx.walk_probe(wps, nlds, bool(inst), bool(fused), unit_rays=unit, slot=1)
+                m, _r = ctx.walk_probe(wps, nlds, bool(inst), int(fused), unit_rays=unit, slot=1)
                 msv = m if msv is None else min(msv, m)
             differ = ctx.walk_probe_compare()
         except api.CrhError as e:
-            print(f"  {wps} waves/SIMD stack {nlds} inst {inst} {'fused' if fused else 'lean'}: {e}", flush=True); continue
+            print(f"  {wps} waves/SIMD stack {nlds} inst {inst} form {fused}: {e}", flush=True); continue
         kn = ctx.last_kernel_name()
         rate = total / msv / 1e3
         res["variants"][f"{wps}.{nlds}.{inst}.{fused}"] = {"ms": round(msv, 2), "mrays": round(rate, 1), "vs_megakernel_walk": round(rate / (mk / share_swap), 3), "hits_that_differ": differ, "kernel": kn}

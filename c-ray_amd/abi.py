@@ -9,11 +9,11 @@ ABI_VERSION = 3
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 NODE_NONE = 0xFFFFFFFF
-OPT_COUNTER_LEVEL, OPT_BLOCKS_PER_CU, OPT_PASS_CHUNK, OPT_WAVES_PER_SIMD, OPT_WAVE_STATS, OPT_UNIT_ITEMS, OPT_SCHED_WEIGHTS, OPT_UNITS_PER_WAVE, OPT_SAMPLER, OPT_TAIL_PERCENT, OPT_SCHED_RUNS, OPT_KERNEL, OPT_SCHED_WG, OPT_TRACE_SLABS, OPT_SHADE_SORT, OPT_TAIL_SPLIT, OPT_ROUND_LIMIT, OPT_RENDER_SLABS, OPT_WALK = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19
+OPT_COUNTER_LEVEL, OPT_BLOCKS_PER_CU, OPT_PASS_CHUNK, OPT_WAVES_PER_SIMD, OPT_WAVE_STATS, OPT_UNIT_ITEMS, OPT_SCHED_WEIGHTS, OPT_UNITS_PER_WAVE, OPT_SAMPLER, OPT_TAIL_PERCENT, OPT_SCHED_RUNS, OPT_KERNEL, OPT_SCHED_WG, OPT_TRACE_SLABS, OPT_SHADE_SORT, OPT_TAIL_SPLIT, OPT_ROUND_LIMIT, OPT_RENDER_SLABS, OPT_WALK, OPT_STREAM_COHORTS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
 WALK_BINARY, WALK_WIDE4 = 0, 1
 TAIL_SPLIT_DEFAULT = 0        # CRH_TAIL_SPLIT_DEFAULT
 TRACE_SLABS_LITERAL, TRACE_SLABS_EXACT = 0, 1
-KERNEL_WAVE, KERNEL_WG, KERNEL_ROLL = 0, 1, 2
+KERNEL_WAVE, KERNEL_WG, KERNEL_ROLL, KERNEL_STREAM = 0, 1, 2, 3
 SAMPLER_RANDOM, SAMPLER_HALTON = 0, 1
 
 

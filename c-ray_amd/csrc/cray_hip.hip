@@ -389,6 +389,7 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_trace_rays(const DScene Sarg, con
 	}
 }
 
+#include "pathtrace_stream.h"        /* k_stream_walk / k_stream_shade / k_stream_fold: the streaming form (CRH_KERNEL_STREAM, round 6) */
 #include "walk_probe.h"              /* k_walk_probe: the walk of k_pathtrace_roll on its own, on the path tracer's own rays (round 6: a measurement entry, crh_debug_walk_probe) */
 
 /* bounces <= 0: pathTrace() returns black (pathtrace.c:36); only the running mean moves (renderer.c:288-291) */
@@ -518,6 +519,24 @@ struct crh_ctx {
 	uint32_t *dProbeOvf = nullptr;
 	void *dProbeUnits = nullptr;
 	size_t probeUnitCap = 0;
+	/* the streaming form (CRH_KERNEL_STREAM; pathtrace_stream.h): two path pools of streamSlots slots (eight 16-byte planes), the walk's hit records, the cohorts' fill
+	 * levels, the ring of sample slabs, the dispatch's state, the walk kernel's stack-overflow columns, and the host-visible word that says a dispatch is over */
+	int streamCohorts = 16384;               /* CRH_OPT_STREAM_COHORTS: cohorts of 1024 paths in a pool (the most; small dispatches take fewer) */
+	int streamGroup = 8;                     /* iterations enqueued between two looks at the completion word */
+	f4 *dStreamPlanes = nullptr;
+	f4 *dStreamHit = nullptr;
+	int32_t *dStreamHitInst = nullptr;
+	uint32_t *dStreamCount = nullptr;
+	size_t streamSlots = 0;
+	float *dStreamSlab = nullptr;
+	size_t streamSlabFloats = 0;
+	StreamCtl *dStreamCtl = nullptr;
+	uint32_t *dStreamOvf = nullptr;
+	size_t streamOvfWords = 0;
+	unsigned int *hStreamDone = nullptr, *dStreamDone = nullptr;
+	unsigned int streamSeq = 0;
+	uint64_t streamIterations = 0;           /* iterations the last streamed dispatch enqueued (crh_debug_stream_stats) */
+	hipEvent_t streamEv[2] = {nullptr, nullptr};
 	uint32_t lastGrid = 0;
 	char lastKernel[64] = "";               /* the instantiation launchPathtrace launched last (crh_last_kernel_name) */
 	float *dStage = nullptr;
@@ -596,9 +615,11 @@ static int upload(crh_ctx *c, const T *host, size_t count, const T **dev) {
 	return CRH_OK;
 }
 
+/* the rolling kernel renders the dispatch: it is the selected form, or the selected form is the streaming one (CRH_KERNEL_STREAM) and cannot serve it (streamServes) */
+static bool rollForm(const crh_ctx *c) { return c->kernel == CRH_KERNEL_ROLL || c->kernel == CRH_KERNEL_STREAM; }
 /* the dispatch walks the wide copy: the option is on, the resident scene has one, and neither rare features nor the Halton sampler are in play */
 static bool wideWalk(const crh_ctx *c) {
-	return c->walk == CRH_WALK_WIDE4 && c->haveWide && c->kernel == CRH_KERNEL_ROLL && !c->hasPrograms && c->sampler == CRH_SAMPLER_RANDOM;
+	return c->walk == CRH_WALK_WIDE4 && c->haveWide && rollForm(c) && !c->hasPrograms && c->sampler == CRH_SAMPLER_RANDOM;
 }
 
 /* Launch the instantiation the context's options select (counter level, rare features, sampler; the kernel form in builds that hold more than one). */
@@ -611,7 +632,7 @@ static hipError_t launchPathtrace(crh_ctx *c, uint32_t grid, const crh_render_pa
 						   c->dCounters, c->dStage, chunk, c->dWaveStats, c->sched, c->dQueues, c->dOvf, c->dErr); } while (0)
 	const bool halton = c->sampler == CRH_SAMPLER_HALTON;
 	(void)halton;
-	if (c->kernel == CRH_KERNEL_ROLL) {
+	if (rollForm(c)) {
 		/* CRH_OPT_WALK = CRH_WALK_WIDE4 (an option, round 5): scenes without rare features, the random sampler */
 		if (wideWalk(c)) {
 			DScene dw = c->d;
@@ -713,7 +734,7 @@ static int preloadKernel(crh_ctx *c, bool again = false) {
 		HIP_TRY(hipMalloc((void **)&c->dQueues, waves * CRH_WAVE_QUEUE_FLOATS * sizeof(float)));
 		c->queueFloats = waves * CRH_WAVE_QUEUE_FLOATS;
 	}
-	const size_t slabs = c->kernel == CRH_KERNEL_ROLL ? CRH_ROLL_SLOTS : 1u;        /* one sample slab per open job */
+	const size_t slabs = rollForm(c) ? CRH_ROLL_SLOTS : 1u;        /* one sample slab per open job */
 	if (waves * slabs * (size_t)c->unitItems * 3 > c->stageFloats) {
 		if (c->dStage) HIP_TRY(hipFree(c->dStage));
 		c->dStage = nullptr; c->stageFloats = 0;
@@ -797,6 +818,13 @@ int crh_context_create(int device, void *stream, crh_ctx **out) {
 	if (env && atoi(env) > 0) c->blocksPerCU = atoi(env) > 8 ? 8 : atoi(env);          /* (1..8, like CRH_OPT_BLOCKS_PER_CU: the counter block is sized for 8) */
 	env = getenv("CRH_SWAP_IN_RUN");              /* dev: A/B of the in-run retire / refill threshold */
 	if (env && atoi(env) >= 1 && atoi(env) <= 65) c->sched.swapInRun = atoi(env);
+	env = getenv("CRH_KERNEL");                     /* dev: a process's default kernel form (A/B runs of unmodified hosts): "stream" or "roll" */
+	if (env && !strcmp(env, "stream")) c->kernel = CRH_KERNEL_STREAM;
+	if (env && !strcmp(env, "roll")) c->kernel = CRH_KERNEL_ROLL;
+	env = getenv("CRH_STREAM_COHORTS");
+	if (env && atoi(env) >= 1 && atoi(env) <= 262144) c->streamCohorts = atoi(env);
+	env = getenv("CRH_STREAM_GROUP");
+	if (env && atoi(env) >= 1 && atoi(env) <= 1024) c->streamGroup = atoi(env);
 	env = getenv("CRH_TAIL_SPLIT");                 /* dev: the default of CRH_OPT_TAIL_SPLIT for this process (A/B runs of unmodified hosts) */
 	if (env && atoi(env) >= 0 && atoi(env) <= 64) c->tailSplit = atoi(env);
 	*out = c;
@@ -840,6 +868,15 @@ int crh_context_destroy(crh_ctx *c) {
 	for (int i = 0; i < 2; ++i) { if (c->dProbeHits[i]) (void)hipFree(c->dProbeHits[i]); if (c->dProbeInst[i]) (void)hipFree(c->dProbeInst[i]); }
 	if (c->dProbeOvf) (void)hipFree(c->dProbeOvf);
 	if (c->dProbeUnits) (void)hipFree(c->dProbeUnits);
+	if (c->dStreamPlanes) (void)hipFree(c->dStreamPlanes);
+	if (c->dStreamHit) (void)hipFree(c->dStreamHit);
+	if (c->dStreamHitInst) (void)hipFree(c->dStreamHitInst);
+	if (c->dStreamCount) (void)hipFree(c->dStreamCount);
+	if (c->dStreamSlab) (void)hipFree(c->dStreamSlab);
+	if (c->dStreamCtl) (void)hipFree(c->dStreamCtl);
+	if (c->dStreamOvf) (void)hipFree(c->dStreamOvf);
+	if (c->hStreamDone) (void)hipHostFree(c->hStreamDone);
+	for (int i = 0; i < 2; ++i) if (c->streamEv[i]) (void)hipEventDestroy(c->streamEv[i]);
 	if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return CRH_OK;
@@ -907,11 +944,14 @@ int crh_set_option(crh_ctx *c, int option, int64_t value) {
 			if (value < 0 || value > 8) return fail(CRH_ERR_INVALID, "shade sort: 0 (never) or the number of shade classes (1..8) from which a scene's hits are shaded in batches of few classes");
 			c->sched.sortFrom = (int)value; return CRH_OK;
 		case CRH_OPT_KERNEL:
-			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG && value != CRH_KERNEL_ROLL) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_ROLL, CRH_KERNEL_WAVE or CRH_KERNEL_WG");
+			if (value != CRH_KERNEL_WAVE && value != CRH_KERNEL_WG && value != CRH_KERNEL_ROLL && value != CRH_KERNEL_STREAM) return fail(CRH_ERR_INVALID, "kernel must be CRH_KERNEL_ROLL, CRH_KERNEL_STREAM, CRH_KERNEL_WAVE or CRH_KERNEL_WG");
 #ifndef CRH_WITH_ALT_KERNELS
-			if (value != CRH_KERNEL_ROLL) return fail(CRH_ERR_UNSUPPORTED, "this library holds k_pathtrace_roll only: CRH_KERNEL_WAVE / CRH_KERNEL_WG need a build with -DCRH_WITH_ALT_KERNELS (tests/emu, tools/build_variant.sh)");
+			if (value != CRH_KERNEL_ROLL && value != CRH_KERNEL_STREAM) return fail(CRH_ERR_UNSUPPORTED, "this library holds k_pathtrace_roll only: CRH_KERNEL_WAVE / CRH_KERNEL_WG need a build with -DCRH_WITH_ALT_KERNELS (tests/emu, tools/build_variant.sh)");
 #endif
 			c->kernel = (int)value; return CRH_OK;
+		case CRH_OPT_STREAM_COHORTS:
+			if (value < 1 || value > 262144) return fail(CRH_ERR_INVALID, "stream cohorts: 1..262144 cohorts of 1024 paths in a pool");
+			c->streamCohorts = (int)value; return CRH_OK;
 		case CRH_OPT_RENDER_SLABS:
 			if (value != CRH_TRACE_SLABS_LITERAL && value != CRH_TRACE_SLABS_EXACT) return fail(CRH_ERR_INVALID, "render slabs must be CRH_TRACE_SLABS_LITERAL or CRH_TRACE_SLABS_EXACT");
 			c->sched.rayFlags = value == CRH_TRACE_SLABS_LITERAL ? (int)CRH_RAY_LITERAL : 0; return CRH_OK;
@@ -1412,6 +1452,189 @@ int crh_debug_plan_units(const crh_render_params *P, const crh_tile *tiles, uint
 	return CRH_OK;
 }
 
+/* ---- the streaming form (CRH_KERNEL_STREAM; csrc/pathtrace_stream.h) ------------------------------------------------------------------------------------------------ */
+/* can this dispatch be streamed? (the forms it cannot serve are rendered by the rolling kernel: a sampler draw inside the walk (volumes), the Halton sampler of the
+ * interactive mode, the 4-ary walk; bounces <= 0 never reaches the path tracer) */
+static bool streamServes(const crh_ctx *c, const crh_render_params *P) {
+	return c->kernel == CRH_KERNEL_STREAM && !c->hasVolumes && c->sampler == CRH_SAMPLER_RANDOM && !(c->walk == CRH_WALK_WIDE4 && c->haveWide) && P->bounces > 0;
+}
+static int growDevice(crh_ctx *c, void **p, size_t *have, size_t need, size_t elemBytes) {
+	if (need <= *have) return CRH_OK;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (*p) HIP_TRY(hipFree(*p));
+	*p = nullptr; *have = 0;
+	HIP_TRY(hipMalloc(p, need * elemBytes));
+	*have = need;
+	return CRH_OK;
+}
+/* walk-kernel instantiations: waves per SIMD the register allocator leaves room for / traversal-stack entries in LDS. One-instance scenes (the triangle soups) walk ONE deep
+ * BVH and want the deeper LDS stack at five workgroups per CU; everything else the shallower one at six (profiles/r06c_probe_walk.log) */
+#define CRH_STREAM_WALK_A_WPS 6
+#define CRH_STREAM_WALK_A_NLDS 7
+#define CRH_STREAM_WALK_B_WPS 5
+#define CRH_STREAM_WALK_B_NLDS 12
+static int renderStream(crh_ctx *c, const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, float *dev_fb) {
+	/* the dispatch's pixels in list order */
+	std::vector<crh_tile> work;
+	std::vector<uint32_t> start;
+	uint64_t npix64 = 0;
+	for (uint32_t i = 0; i < tile_count; ++i) {
+		crh_tile t = tiles[i];
+		if (t.x0 < 0 || t.y0 < 0 || t.x1 > P->image_width || t.y1 > P->image_height) return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
+		if (t.x1 <= t.x0 || t.y1 <= t.y0) continue;
+		start.push_back((uint32_t)npix64);
+		work.push_back(t);
+		npix64 += (uint64_t)(t.x1 - t.x0) * (uint64_t)(t.y1 - t.y0);
+		if (npix64 >= CRH_SF_CHUNK_ITEMS_MAX) return fail(CRH_ERR_UNSUPPORTED, "crh_render_tiles: a streamed dispatch holds fewer than 2^28 pixels");
+	}
+	if (npix64 == 0 || P->pass_count == 0) return CRH_OK;
+	start.push_back((uint32_t)npix64);
+	const uint32_t npix = (uint32_t)npix64, ntiles = (uint32_t)work.size();
+	const uint64_t totalItems = npix64 * (uint64_t)P->pass_count;
+	const uint32_t cohorts = (uint32_t)std::min<uint64_t>((uint64_t)c->streamCohorts, (totalItems + CRH_SF_COHORT - 1) / CRH_SF_COHORT);
+	const size_t slots = (size_t)cohorts * CRH_SF_COHORT;
+	/* chunks: about one pool's worth of items each (all pixels x a few passes), fewer than 2^28 */
+	uint32_t C = (uint32_t)std::min<uint64_t>((uint64_t)P->pass_count, (slots + npix - 1) / npix);
+	if (C < 1u) C = 1u;
+	while (C > 1u && (uint64_t)npix * C >= CRH_SF_CHUNK_ITEMS_MAX) --C;
+	const uint32_t chunkCount = ((uint32_t)P->pass_count + C - 1u) / C, lastPasses = (uint32_t)P->pass_count - (chunkCount - 1u) * C;
+	const uint32_t chunkItems = npix * C;
+	const size_t slabFloats = (size_t)std::min<uint32_t>(CRH_SF_RING, chunkCount) * chunkItems * 3;
+
+	int rc;
+	{
+		size_t have = c->streamSlots;
+		if (slots > have) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (c->dStreamPlanes) HIP_TRY(hipFree(c->dStreamPlanes));
+			if (c->dStreamHit) HIP_TRY(hipFree(c->dStreamHit));
+			if (c->dStreamHitInst) HIP_TRY(hipFree(c->dStreamHitInst));
+			if (c->dStreamCount) HIP_TRY(hipFree(c->dStreamCount));
+			c->dStreamPlanes = nullptr; c->dStreamHit = nullptr; c->dStreamHitInst = nullptr; c->dStreamCount = nullptr; c->streamSlots = 0;
+			HIP_TRY(hipMalloc((void **)&c->dStreamPlanes, slots * 8 * sizeof(f4)));
+			HIP_TRY(hipMalloc((void **)&c->dStreamHit, slots * sizeof(f4)));
+			HIP_TRY(hipMalloc((void **)&c->dStreamHitInst, slots * sizeof(int32_t)));
+			HIP_TRY(hipMalloc((void **)&c->dStreamCount, (slots / CRH_SF_COHORT) * 2 * sizeof(uint32_t)));
+			c->streamSlots = slots;
+		}
+	}
+	rc = growDevice(c, (void **)&c->dStreamSlab, &c->streamSlabFloats, slabFloats, sizeof(float));
+	if (rc) return rc;
+	const bool deepStack = c->d.instance_count == 1u && c->d.tlas_node_count == 1u;
+	const uint32_t walkGrid = (uint32_t)c->cuCount * (uint32_t)(deepStack ? CRH_STREAM_WALK_B_WPS : CRH_STREAM_WALK_A_WPS);
+	rc = growDevice(c, (void **)&c->dStreamOvf, &c->streamOvfWords, (size_t)walkGrid * (CRH_BLOCK / 64) * CRH_OVF_WORDS_PER_WAVE, sizeof(uint32_t));
+	if (rc) return rc;
+	if (!c->dStreamCtl) HIP_TRY(hipMalloc((void **)&c->dStreamCtl, sizeof(StreamCtl)));
+	if (!c->hStreamDone) {
+		HIP_TRY(hipHostMalloc((void **)&c->hStreamDone, sizeof(unsigned int), hipHostMallocDefault));
+		*c->hStreamDone = 0u;
+		HIP_TRY(hipHostGetDevicePointer((void **)&c->dStreamDone, c->hStreamDone, 0));
+	}
+	for (int i = 0; i < 2; ++i) if (!c->streamEv[i]) HIP_TRY(hipEventCreateWithFlags(&c->streamEv[i], hipEventDisableTiming));
+
+	/* the tile list: pinned host slot, copied into the device slot by the dispatch's first kernel (no copy engine in front of a kernel: see crh_render_tiles) */
+	const uint32_t slot = c->workSlot % CRH_WORK_SLOTS;
+	crh_ctx::TileSlot &ts = c->tileSlots[slot];
+	const size_t tileBytes = ntiles * sizeof(crh_tile), startBytes = (ntiles + 1) * sizeof(uint32_t);
+	if (ts.inFlight) { HIP_TRY(hipEventSynchronize(ts.done)); ts.inFlight = false; }
+	if (tileBytes + startBytes > ts.cap) {
+		if (ts.dev) HIP_TRY(hipFree(ts.dev));
+		if (ts.host) HIP_TRY(hipHostFree(ts.host));
+		ts.dev = ts.host = nullptr; ts.cap = 0;
+		const size_t cap = std::max<size_t>(4096, 2 * (tileBytes + startBytes));
+		HIP_TRY(hipMalloc(&ts.dev, cap));
+		HIP_TRY(hipHostMalloc(&ts.host, cap, hipHostMallocDefault));
+		ts.cap = cap;
+	}
+	if (!ts.done) HIP_TRY(hipEventCreateWithFlags(&ts.done, hipEventDisableTiming));
+	memcpy(ts.host, work.data(), tileBytes);
+	memcpy((char *)ts.host + tileBytes, start.data(), startBytes);
+	void *hostView = nullptr;
+	HIP_TRY(hipHostGetDevicePointer(&hostView, ts.host, 0));
+	c->workSlot++;
+
+	StreamPlan Pl;
+	Pl.tiles = (const crh_tile *)ts.dev;
+	Pl.start = (const uint32_t *)((char *)ts.dev + tileBytes);
+	Pl.ntiles = ntiles; Pl.npix = npix; Pl.cohorts = cohorts;
+	Pl.passesPerChunk = C; Pl.lastPasses = lastPasses; Pl.chunkCount = chunkCount; Pl.chunkItems = chunkItems;
+	Pl.genTotal = totalItems;
+	Pl.slab = c->dStreamSlab; Pl.hit = c->dStreamHit; Pl.hitInst = c->dStreamHitInst;
+	Pl.done = c->dStreamDone; Pl.seq = ++c->streamSeq;
+	if (Pl.seq == 0u) Pl.seq = ++c->streamSeq;
+	StreamPool pool[2];
+	for (int b = 0; b < 2; ++b) {
+		f4 *base = c->dStreamPlanes + (size_t)b * 4 * c->streamSlots;
+		pool[b].p0 = base; pool[b].p1 = base + c->streamSlots; pool[b].p2 = base + 2 * c->streamSlots; pool[b].p3 = base + 3 * c->streamSlots;
+		pool[b].count = c->dStreamCount + (size_t)b * (c->streamSlots / CRH_SF_COHORT);
+	}
+
+	crh_ctx::Timed ev;
+	if (!c->eventPool.empty()) { ev = c->eventPool.back(); c->eventPool.pop_back(); }
+	else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
+	HIP_TRY(hipEventRecord(ev.a, c->stream));
+	hipLaunchKernelGGL(k_stream_init, dim3(std::min<uint32_t>(64u, (cohorts + 255u) / 256u)), dim3(256), 0, c->stream, Pl, pool[0].count, pool[1].count, c->dStreamCtl,
+	                   (const uint32_t *)hostView, (uint32_t *)ts.dev, (uint32_t)((tileBytes + startBytes) / 4));
+	hipError_t e = hipGetLastError();
+	const uint32_t shadeGrid = std::min<uint32_t>((uint32_t)c->cuCount * 4u, cohorts);
+	const uint32_t foldGrid = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)c->cuCount * 4u, (npix + CRH_BLOCK - 1u) / CRH_BLOCK));
+	snprintf(c->lastKernel, sizeof(c->lastKernel), "k_stream<%d,%s> walk<%d,%d>", c->counterLevel >= 2 ? 2 : 1, c->hasPrograms ? "true" : "false",
+	         deepStack ? CRH_STREAM_WALK_B_WPS : CRH_STREAM_WALK_A_WPS, deepStack ? CRH_STREAM_WALK_B_NLDS : CRH_STREAM_WALK_A_NLDS);
+	c->lastGrid = walkGrid;
+	auto iteration = [&](uint64_t it) {
+		const StreamPool &in = pool[it & 1u], &out = pool[(it + 1u) & 1u];
+#define CRH_STREAM_WALK(W, N, L) hipLaunchKernelGGL((k_stream_walk<W, N, true, L>), dim3(walkGrid), dim3(CRH_BLOCK), 0, c->stream, c->d, in, c->dStreamHit, c->dStreamHitInst, cohorts, \
+		                                             c->dStreamCtl, c->sched, c->dStreamOvf, c->dCounters)
+#define CRH_STREAM_SHADE(L, PROG) hipLaunchKernelGGL((k_stream_shade<L, PROG, 0>), dim3(shadeGrid), dim3(CRH_BLOCK), 0, c->stream, c->d, *P, Pl, in, out, c->dStreamCtl, c->dCounters)
+#ifdef CRH_DEV_ONLY_BENCH_VARIANT
+		if (deepStack) CRH_STREAM_WALK(CRH_STREAM_WALK_B_WPS, CRH_STREAM_WALK_B_NLDS, 1); else CRH_STREAM_WALK(CRH_STREAM_WALK_A_WPS, CRH_STREAM_WALK_A_NLDS, 1);
+		CRH_STREAM_SHADE(1, false);
+#else
+		if (c->counterLevel >= 2) { if (deepStack) CRH_STREAM_WALK(CRH_STREAM_WALK_B_WPS, CRH_STREAM_WALK_B_NLDS, 2); else CRH_STREAM_WALK(CRH_STREAM_WALK_A_WPS, CRH_STREAM_WALK_A_NLDS, 2); }
+		else { if (deepStack) CRH_STREAM_WALK(CRH_STREAM_WALK_B_WPS, CRH_STREAM_WALK_B_NLDS, 1); else CRH_STREAM_WALK(CRH_STREAM_WALK_A_WPS, CRH_STREAM_WALK_A_NLDS, 1); }
+		if (c->counterLevel >= 2) { if (c->hasPrograms) CRH_STREAM_SHADE(2, true); else CRH_STREAM_SHADE(2, false); }
+		else { if (c->hasPrograms) CRH_STREAM_SHADE(1, true); else CRH_STREAM_SHADE(1, false); }
+#endif
+#undef CRH_STREAM_WALK
+#undef CRH_STREAM_SHADE
+		hipLaunchKernelGGL(k_stream_fold, dim3(foldGrid), dim3(CRH_BLOCK), 0, c->stream, *P, Pl, c->dStreamCtl, dev_fb);
+	};
+	/* iterations in groups; behind every group an event. With group g + 1 enqueued the host waits for group g and looks at the completion word: the device always has a
+	 * group ahead of it, and the iterations enqueued beyond the dispatch's end find nothing to do (each kernel leaves at its first instruction) */
+	const uint64_t poolsOfWork = totalItems / slots + 2u;
+	const uint64_t iterLimit = poolsOfWork * ((uint64_t)P->bounces + 2u) * 2u + 64u;          /* (every path ends within bounces iterations of its generation) */
+	uint64_t it = 0;
+	int pending = -1;                 /* the event slot of the group the host has not waited for yet */
+	bool over = false;
+	while (e == hipSuccess && !over) {
+		const int g = pending == 0 ? 1 : 0;
+		for (int k = 0; k < c->streamGroup; ++k) iteration(it++);
+		e = hipGetLastError();
+		if (e != hipSuccess) break;
+		HIP_TRY(hipEventRecord(c->streamEv[g], c->stream));
+		if (pending >= 0) {
+			HIP_TRY(hipEventSynchronize(c->streamEv[pending]));
+			over = *(volatile unsigned int *)c->hStreamDone == Pl.seq;
+		}
+		pending = g;
+		if (!over && it > iterLimit) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (*(volatile unsigned int *)c->hStreamDone == Pl.seq) break;
+			c->eventPool.push_back(ev);
+			return fail(CRH_ERR_HIP, "k_stream: the dispatch did not finish within its iteration limit: incomplete frame");
+		}
+	}
+	c->streamIterations = it;
+	HIP_TRY(hipEventRecord(ev.b, c->stream));
+	HIP_TRY(hipEventRecord(ts.done, c->stream));
+	ts.inFlight = true;
+	c->pendingTimes.push_back(ev);
+	c->launches++;
+	if (c->janitorWaiting.load(std::memory_order_relaxed)) releaseJanitor(c, false);
+	if (e != hipSuccess) return fail(CRH_ERR_HIP, std::string("k_stream launch: ") + hipGetErrorString(e));
+	return CRH_OK;
+}
+
 int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *tiles, uint32_t tile_count, float *dev_fb) {
 	if (!c || !P || !dev_fb || (!tiles && tile_count)) return fail(CRH_ERR_INVALID, "crh_render_tiles: NULL argument");
 	if (!c->haveScene) return fail(CRH_ERR_INVALID, "crh_render_tiles: no scene uploaded");
@@ -1420,9 +1643,10 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	int rc = setDevice(c);
 	if (rc) return rc;
 	(void)resolveTimes(c, false);
+	if (streamServes(c, P)) return renderStream(c, P, tiles, tile_count, dev_fb);
 	const bool wg = c->kernel == CRH_KERNEL_WG;
 	const PlanKnobs knobs{c->unitItems, c->unitsPerWave, c->tailPercent, c->tail2Percent, c->passChunk, c->cuCount, c->blocksPerCU, wg,
-	                      c->kernel == CRH_KERNEL_ROLL && P->bounces > 0 ? c->tailSplit : 0};
+	                      rollForm(c) && P->bounces > 0 ? c->tailSplit : 0};
 	WorkPlan plan;
 	{
 		std::string perr;
@@ -1440,7 +1664,7 @@ int crh_render_tiles(crh_ctx *c, const crh_render_params *P, const crh_tile *til
 	if (c->dWaveStats && grid * (CRH_BLOCK / 64) > CRH_WAVE_STATS_MAX) return fail(CRH_ERR_INVALID, "wave stats: grid too large");
 	{
 		size_t need = (size_t)grid * (wg ? 1 : CRH_BLOCK / 64) * (size_t)(bw * bh) * (size_t)chunk * 3;
-		if (c->kernel == CRH_KERNEL_ROLL) need *= CRH_ROLL_SLOTS;      /* one sample slab per open job */
+		if (rollForm(c)) need *= CRH_ROLL_SLOTS;      /* one sample slab per open job */
 		if (need > c->stageFloats) {
 			HIP_TRY(hipStreamSynchronize(c->stream));
 			if (c->dStage) HIP_TRY(hipFree(c->dStage));

@@ -305,6 +305,10 @@ int crh_context_prepare(crh_ctx *ctx);
 #define CRH_KERNEL_WAVE 0
 #define CRH_KERNEL_WG   1
 #define CRH_KERNEL_ROLL 2
+#define CRH_KERNEL_STREAM 3       /* round 6: the same machine as three kernels that take turns — walk / shade + refill / fold — over two pools of paths in global memory, so that
+                                   * the BVH walk runs at six or seven waves per SIMD instead of the megakernel's four (csrc/pathtrace_stream.h); the same frame bit for bit.
+                                   * Dispatches it cannot serve (volumes, the Halton sampler, the 4-ary walk, bounces <= 0) are rendered by CRH_KERNEL_ROLL. crh_render_tiles
+                                   * returns when the dispatch's last iteration has been enqueued, i.e. shortly before it is finished (the host feeds the device iteration by iteration) */
 #define CRH_SAMPLER_RANDOM 0
 #define CRH_SAMPLER_HALTON 1
 #define CRH_OPT_TAIL_SPLIT   16   /* rolling kernel: the work queue ENDS with this many units per wave (0..64; 0 = none, the default) of about 64 paths — blocks of 64 / passes
@@ -328,6 +332,7 @@ int crh_context_prepare(crh_ctx *ctx);
                                    * counts are the wide walk's own. Scenes with node programs / volumes, the Halton sampler and crh_trace_rays keep the binary walk */
 #define CRH_WALK_BINARY 0
 #define CRH_WALK_WIDE4  1
+#define CRH_OPT_STREAM_COHORTS 20 /* CRH_KERNEL_STREAM: the most cohorts of 1024 paths a pool holds (default 16384: 16.8 M paths in flight, 2.5 GB of pools + up to 3.2 GB of sample slabs) */
 #define CRH_OPT_WAVE_STATS    5   /* debug: record per-wave busy time / units of each dispatch (crh_debug_wave_stats) */
 int crh_set_option(crh_ctx *ctx, int option, int64_t value);
 int crh_debug_wave_stats(crh_ctx *ctx, uint64_t *out_pairs, uint32_t max_waves);

@@ -206,6 +206,7 @@ static __forceinline__ int atomicMax(int *p, int v) { return hipemu_atomic_max(p
 static __forceinline__ unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
+static __forceinline__ unsigned long long atomicCAS(unsigned long long *p, unsigned long long cmp, unsigned long long v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
 static __forceinline__ int atomicCAS(int *p, int cmp, int v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
 static __forceinline__ unsigned atomicExch(unsigned *p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 static __forceinline__ int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }

@@ -26,6 +26,8 @@
 
 #define CRH_SF_COHORT 1024u            /* slots per cohort (= what one workgroup of k_stream_shade sorts in LDS: 16-bit indices) */
 #define CRH_SF_UNIT 128u               /* slots per unit of the walk kernel's work counter */
+#define CRH_SF_COUNTERS 16u            /* unit counters of the walk kernel (a power of two) ... */
+#define CRH_SF_CTR_STRIDE 32u          /* ... this many words apart */
 #define CRH_SF_RING 16u                /* slabs in the sample ring (item word: ring slot << 28 | index inside the chunk) */
 #define CRH_SF_SLOT_SHIFT 28u
 #define CRH_SF_IDX_MASK 0x0FFFFFFFu
@@ -56,9 +58,10 @@ struct StreamCtl {
 	unsigned long long genNext;        /* items handed out so far (chunk-major numbering) */
 	uint32_t foldNext;                 /* the chunk that folds next */
 	uint32_t foldDone;                 /* workgroups of the running k_stream_fold that are through */
-	uint32_t walkCtr, shadeCtr;        /* work counters of the two persistent kernels (k_stream_fold zeroes them) */
+	uint32_t shadeCtr;                 /* work counter of k_stream_shade (k_stream_fold zeroes it) */
 	uint32_t liveIn, liveOut;          /* paths in the pool the iteration reads / paths the shade kernel has put into the pool it writes */
 	uint32_t left[CRH_SF_RING];        /* samples still missing in the chunk that occupies the ring slot */
+	uint32_t walkCtr[CRH_SF_COUNTERS * CRH_SF_CTR_STRIDE];          /* work counters of k_stream_walk, 128 bytes apart (k_stream_fold zeroes them) */
 };
 
 /* pixel `q` of a w x h rectangle in 8 x 8 blocks (bands of eight rows, blocks left to right, rows inside a block): neighbours in the item order are neighbours in the frame */
@@ -116,7 +119,8 @@ __global__ void k_stream_init(const StreamPlan Pl, uint32_t *countA, uint32_t *c
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < Pl.cohorts; i += gridDim.x * blockDim.x) { countA[i] = 0u; countB[i] = 0u; }
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < listWords; i += gridDim.x * blockDim.x) listDev[i] = listHost[i];
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		ctl->genNext = 0ull; ctl->foldNext = 0u; ctl->foldDone = 0u; ctl->walkCtr = 0u; ctl->shadeCtr = 0u; ctl->liveIn = 0u; ctl->liveOut = 0u;
+		ctl->genNext = 0ull; ctl->foldNext = 0u; ctl->foldDone = 0u; ctl->shadeCtr = 0u;
+		for (uint32_t i = 0; i < CRH_SF_COUNTERS; ++i) ctl->walkCtr[i * CRH_SF_CTR_STRIDE] = 0u; ctl->liveIn = 0u; ctl->liveOut = 0u;
 		for (uint32_t s = 0; s < CRH_SF_RING; ++s)
 			ctl->left[s] = s < Pl.chunkCount ? Pl.npix * (s + 1u == Pl.chunkCount ? Pl.lastPasses : Pl.passesPerChunk) : 0u;
 	}
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_stream_walk(const DScene Sar
 	w.phase = PH_IDLE;
 	uint32_t mySlot = 0;
 	uint32_t cur = 0, end = 0;                   /* wave-uniform: the slots of the unit in hand whose rays have not started */
-	bool dry = false;                            /* wave-uniform: the counter has run past the last unit */
+	bool dry = false;                            /* wave-uniform: every counter has run past its last unit */
+	uint32_t part = __builtin_amdgcn_readfirstlane(wave) & (CRH_SF_COUNTERS - 1u), partsDry = 0;          /* wave-uniform: the counter in use, and how many have been seen dry */
 	const uint32_t unitsPerCohort = CRH_SF_COHORT / CRH_SF_UNIT, nUnits = cohorts * unitsPerCohort;
 	/* retire + refill (pathtrace_roll.h: retireRefill): lanes whose walk ended leave the hit in their slot's record; they and the idle lanes take the next rays of the unit in hand */
 	auto retireRefill = [&]() __attribute__((always_inline)) {
@@ -169,14 +174,20 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_stream_walk(const DScene Sar
 		const unsigned long long em = __ballot(idle);
 		const uint32_t er = laneRank(em);
 		for (int tries = 0; tries < 8 && cur == end && !dry; ++tries) {          /* (a unit beyond its cohort's live slots is empty: try the next one) */
-			uint32_t u = 0;
-			if (lane == 0) u = atomicAdd((uint32_t *)&ctl->walkCtr, 1u);
-			u = __builtin_amdgcn_readfirstlane(u);
+			/* the units are dealt over CRH_SF_COUNTERS counters (unit = k * CRH_SF_COUNTERS + counter: sixteen addresses, sixteen L2 channels — one counter served an
+			 * atomic every 15 ns, a floor of 2 ms per iteration whatever the pool held); a wave starts at its own counter and moves on when one runs out */
+			uint32_t k = 0;
+			if (lane == 0) k = atomicAdd((uint32_t *)&ctl->walkCtr[part * CRH_SF_CTR_STRIDE], 1u);
+			k = __builtin_amdgcn_readfirstlane(k);
+			const uint32_t u = k * CRH_SF_COUNTERS + part;
 			if (u < nUnits) {
 				const uint32_t t = u / unitsPerCohort, off = (u % unitsPerCohort) * CRH_SF_UNIT;
 				const uint32_t n = __builtin_amdgcn_readfirstlane(count[t]);
 				if (off < n) { cur = t * CRH_SF_COHORT + off; end = t * CRH_SF_COHORT + (n < off + CRH_SF_UNIT ? n : off + CRH_SF_UNIT); }
-			} else dry = true;
+			} else {
+				part = (part + 1u) & (CRH_SF_COUNTERS - 1u);
+				if (++partsDry == CRH_SF_COUNTERS) dry = true;
+			}
 		}
 		const uint32_t take = min(end - cur, (uint32_t)__popcll(em));
 		if (idle && er < take) {
@@ -386,15 +397,14 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_stream_shade(const DScene Sarg
 		/* the slots that stay free take the dispatch's next items (renderer.c:280-284): one compare-and-swap per cohort hands them out */
 		const uint32_t nOut = sw[SW_OUT];
 		if (threadIdx.x == 0) {
+			/* (a fetch-and-add, not a compare-and-swap: a thousand workgroups retrying against each other took 60 ms per iteration. The counter may run past the limit — the
+			 * items beyond it are nobody's: k_stream_fold, which moves the limit, takes the counter back to it first) */
 			const uint32_t want = CRH_SF_COHORT - nOut;
 			uint32_t n = 0;
 			unsigned long long g = __hip_atomic_load(&ctl->genNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			for (;;) {
+			if (want && g < genLimit) {
+				g = atomicAdd((unsigned long long *)&ctl->genNext, (unsigned long long)want);
 				n = g < genLimit ? (uint32_t)(genLimit - g < (unsigned long long)want ? genLimit - g : (unsigned long long)want) : 0u;
-				if (n == 0u) break;
-				const unsigned long long seen = atomicCAS((unsigned long long *)&ctl->genNext, g, g + n);
-				if (seen == g) break;
-				g = seen;
 			}
 			s_word[SW_NEW] = n;
 			if (n) { s_word[SW_G0_CHUNK] = (uint32_t)(g / Pl.chunkItems); s_word[SW_G0_IDX] = (uint32_t)(g % Pl.chunkItems); }
@@ -470,9 +480,14 @@ __global__ __launch_bounds__(CRH_BLOCK) void k_stream_fold(const crh_render_para
 				const uint32_t c = first + k + CRH_SF_RING;          /* the chunk that takes the freed slab */
 				ctl->left[(first + k) & (CRH_SF_RING - 1u)] = c < Pl.chunkCount ? Pl.npix * (c + 1u == Pl.chunkCount ? Pl.lastPasses : Pl.passesPerChunk) : 0u;
 			}
+			{          /* what the shade kernel really handed out: its limit was the ring's end as it stood, or the dispatch's */
+				const unsigned long long lim0 = (unsigned long long)(first + CRH_SF_RING) * (unsigned long long)Pl.chunkItems, lim = lim0 < Pl.genTotal ? lim0 : Pl.genTotal;
+				if (ctl->genNext > lim) ctl->genNext = lim;
+			}
 			ctl->foldNext = first + n;
 			ctl->foldDone = 0u;
-			ctl->walkCtr = 0u; ctl->shadeCtr = 0u;
+			ctl->shadeCtr = 0u;
+			for (uint32_t i = 0; i < CRH_SF_COUNTERS; ++i) ctl->walkCtr[i * CRH_SF_CTR_STRIDE] = 0u;
 			ctl->liveIn = ctl->liveOut; ctl->liveOut = 0u;
 			__threadfence();
 			if (first + n == Pl.chunkCount) *(volatile unsigned int *)Pl.done = Pl.seq;

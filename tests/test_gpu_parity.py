@@ -264,6 +264,71 @@ def test_dispatch_decompositions_are_bit_identical(pkg, ctx, manifest, golden_bl
     ctx.set_option(pkg.abi.OPT_COUNTER_LEVEL, 2)
 
 
+def test_streaming_form_is_bit_identical(pkg, ctx, manifest, golden_blob, golden_ref):
+    """CRH_KERNEL_STREAM (csrc/pathtrace_stream.h: walk / shade + refill / fold kernels over two path pools) renders the reference's frame bit for bit, with the rolling
+    kernel's counters, whatever the pool size (seven cohorts: chunks of one pass; one cohort and 24 passes of a small region: dozens of iterations and a ring of sample
+    slabs that turns over), for pass ranges and tile lists; dispatches it cannot serve (volumes: a sampler draw inside the walk) are rendered by the rolling kernel."""
+    abi = pkg.abi
+
+    def streamed(fb, w, h, s, b, **kw):
+        ctx.clear(fb, w, h); ctx.reset_counters()
+        ctx.render_region(fb, w, h, s, b, **kw)
+        assert ctx.last_kernel_name().startswith("k_stream"), ctx.last_kernel_name()
+        return ctx.download(fb, w, h), ctx.counters()
+    try:
+        # the fixture's frame, two pool sizes
+        m = manifest["cfg1_scene"]
+        w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+        img, cnt, fb = gpu_render(pkg, ctx, golden_blob("cfg1_scene"), w, h, s, b)
+        assert np.array_equal(img, golden_ref("cfg1_scene"))
+        region = (16, 24, 64, 56)          # 48 x 32 pixels, 24 passes: more chunks than the ring has slabs when the pool is one cohort
+        ctx.clear(fb, w, h); ctx.reset_counters()
+        ctx.render_region(fb, w, h, 24, b, region=region)
+        small, small_cnt = ctx.download(fb, w, h), ctx.counters()
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_STREAM)
+        for cohorts in (16384, 7):
+            ctx.set_option(abi.OPT_STREAM_COHORTS, cohorts)
+            got, got_cnt = streamed(fb, w, h, s, b)
+            assert np.array_equal(got, img) and got_cnt == cnt, cohorts
+        ctx.set_option(abi.OPT_STREAM_COHORTS, 1)
+        got, got_cnt = streamed(fb, w, h, 24, b, region=region)
+        assert np.array_equal(got, small) and got_cnt == small_cnt
+        # pass ranges and the reference's tile list dealt over three "ranks"; counter level 1 (the timed instantiations)
+        m = manifest["refraction"]
+        w, h, s, b = m["width"], m["height"], m["samples"], m["bounces"]
+        ref = golden_ref("refraction")
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+        img, cnt, fb = gpu_render(pkg, ctx, golden_blob("refraction"), w, h, s, b)
+        assert np.array_equal(img, ref)
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_STREAM)
+        ctx.set_option(abi.OPT_STREAM_COHORTS, 3)
+        ctx.clear(fb, w, h)
+        ctx.render_region(fb, w, h, s, b, first_pass=0, pass_count=1)
+        ctx.render_region(fb, w, h, s, b, first_pass=1)
+        assert np.array_equal(ctx.download(fb, w, h), ref)
+        ctx.set_option(abi.OPT_STREAM_COHORTS, 16384)
+        tiles = pkg.tiles.quantize_image(w, h, 32, 32, pkg.tiles.ORDER_FROM_MIDDLE)
+        ctx.clear(fb, w, h); ctx.reset_counters()
+        for r in range(3):
+            ctx.render_tiles(fb, w, h, s, b, pkg.tiles.tiles_for_rank(tiles, r, 3))
+        assert np.array_equal(ctx.download(fb, w, h), ref)
+        assert ctx.counters() == cnt
+        ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
+        got, got_cnt = streamed(fb, w, h, s, b)
+        assert np.array_equal(got, ref) and got_cnt["rays"] == cnt["rays"] and got_cnt["paths"] == cnt["paths"]
+        ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+        # a scene with volumes: the option stays set, the rolling kernel renders
+        m = manifest["volumes"]
+        img, _, _ = gpu_render(pkg, ctx, golden_blob("volumes"), m["width"], m["height"], m["samples"], m["bounces"])
+        assert ctx.last_kernel_name().startswith("k_pathtrace_roll"), ctx.last_kernel_name()
+        assert np.array_equal(img, golden_ref("volumes"))
+    finally:
+        ctx.set_option(abi.OPT_KERNEL, abi.KERNEL_ROLL)
+        ctx.set_option(abi.OPT_STREAM_COHORTS, 16384)
+        ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
+
+
 def test_rolling_and_one_unit_at_a_time_kernels_are_bit_identical(pkg, ctx, manifest, golden_blob):
     """CRH_OPT_KERNEL: the default form keeps up to four work units open per wave (k_pathtrace_roll), CRH_KERNEL_WAVE works one unit at a time (the default
     until round 3). Same per-path operations, so: the same frame and the same counters — for default and tiny units, one-pass chunks, ragged tiles split

@@ -37,7 +37,7 @@ def emu_lib():
 GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of tests that must run and pass)
     "trace_rays": (["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6),
     "frames": (["test_gpu_parity.py"], "test_image_parity_vs_reference", 6),
-    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths or round_limit or upload_lifecycle or wide_walk_option", 13),
+    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths or round_limit or upload_lifecycle or wide_walk_option or streaming_form", 14),
     "rare_and_wg": (["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"], "test_gpu_node_zoo or test_gpu_volumes", 3),          # (test_gpu_volumes renders with both kernel forms;
     # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),

@@ -296,36 +296,70 @@ def measure_other_workloads(api, abi, built_dir):
 # the scaling objects of the bench line: configs[3] at 128 of its 2048 passes (1.6 s at N = 1: a 1/8 share is 0.2 s, not a drain test) and configs[4] —
 # the 10 M-triangle soup, "sharded across 8 MI355X (RCCL framebuffer reduce)" — at 128 of its 512 (0.9 s at N = 1), through the same strips + gather as the headline
 SCALING_SPP = {"cfg4": 128, "soup10m": 128}
+# (say it in the line) the reduced sample counts do not move the N = 1 rate: round 5's driver line has 2 419 (128 spp, here) against 2 416 Mray/s (256 spp,
+# other_workloads) for configs[3] and 1 999 (128 spp) against 1 997 (512 spp, BASELINE's own count) for the 10 M soup
+SCALING_FULL_SPP_NOTE = {"cfg4": "; at N = 1 the rate at 128 spp equals the rate at 256 / 2048 spp (BENCH_r05: 2419 vs 2416 Mray/s; other_workloads.cfg4 of this line)",
+                         "soup10m": "; at N = 1 the rate at 128 spp equals the rate at BASELINE's 512 spp (BENCH_r05: 1999 vs 1997 Mray/s; other_workloads.soup10m of this line)"}
 
 
-def scaling_workload(key, api, render, torch, dist, built_dir, local_rank, rank, world, reps=2):
+def all_ranks_ok(ok, torch, dist, world, device):
+    """Every rank learns whether ALL ranks came through their last local phase (one tiny all-reduce; nothing at world == 1). A rank that failed locally must not walk away
+    from the collectives its peers are about to enter — and must not take the headline line with it (renderer.c:96-117: a worker that fails to start does not abort the frame)."""
+    if world == 1:
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(float(t[0]))
+
+
+def scaling_workload(key, api, render, torch, dist, built_dir, local_rank, rank, world, reps=2, device=None):
     """A BASELINE config through the multi-GPU path — 4-row strips per rank, the owned strips gathered on rank 0 — at a stated sample count, emitted at every N (N = 1
     included) so that the points of the driver's scaling run divide. Outside the timed region. The 10 M soup's blob is built by rank 0 (tools/make_soup_blob.py: the
-    GPU BVH builder) while the others wait; every rank then uploads its replica. Returns {mrays, ms, gather_ms, rays, spp} on rank 0 (ms = max over ranks)."""
+    GPU BVH builder) while the others wait; every rank then uploads its replica. Returns {mrays, ms, gather_ms, rays, spp} on rank 0 (ms = max over ranks).
+    Every local phase (scene build, upload, the first dispatch) ends with all_ranks_ok(): a failure on ANY rank makes EVERY rank return {"failed": ...} before the next
+    collective — nobody raises, nobody hangs, and the caller's headline line is printed regardless (tests/test_dist_gloo.py)."""
     wl = WORKLOADS[key]
+    device = device if device is not None else torch.device("cuda", local_rank)
+    err = None
     blob = os.path.join(built_dir, wl["blob"] + ".blob")
-    if wl.get("triangles") and not os.path.exists(blob):
-        if rank == 0:
+    try:
+        if wl.get("triangles") and not os.path.exists(blob) and rank == 0:
             blob = workload_blob(key, built_dir)
-        if world > 1:
-            dist.barrier()
+    except Exception as e:
+        err = f"scene build: {type(e).__name__}: {e}"
+    if not all_ranks_ok(err is None, torch, dist, world, device):          # (also the barrier the other ranks wait at while rank 0 builds)
+        return {"failed": (err or "scene build failed on another rank")[:300]}
+    if wl.get("triangles") and not os.path.exists(blob):
         blob = workload_blob(key, built_dir)
-    have = torch.tensor([1.0 if os.path.exists(blob) else 0.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
-    if world > 1:
-        dist.all_reduce(have, op=dist.ReduceOp.MIN)
-    if not float(have[0]):
+    if not all_ranks_ok(os.path.exists(blob), torch, dist, world, device):
         return {"skipped": f"{blob} not built"}
     W, H, B, spp = wl["width"], wl["height"], wl["bounces"], SCALING_SPP[key]
-    scene = api.Scene(blob)
-    fr = render.FrameRenderer(api, scene, W, H, device=local_rank, rank=rank, world=world, tile=wl["tile"], order=wl["tile_order"])
-    fr.ctx.set_option(api.abi.OPT_COUNTER_LEVEL, 1)
+    scene = fr = None
+    try:
+        scene = api.Scene(blob)
+        fr = render.FrameRenderer(api, scene, W, H, device=local_rank, rank=rank, world=world, tile=wl["tile"], order=wl["tile_order"])
+        fr.ctx.set_option(api.abi.OPT_COUNTER_LEVEL, 1)
+        fr.render(min(spp, 8), B)          # warm-up dispatch (code object, buffers); its gather follows once every rank has come this far
+    except Exception as e:
+        err = f"upload / first dispatch: {type(e).__name__}: {e}"
+
+    def close():
+        for obj in (fr, scene):
+            try:
+                if obj is not None:
+                    obj.close()
+            except Exception:
+                pass
+    if not all_ranks_ok(err is None, torch, dist, world, device):
+        close()
+        return {"failed": (err or "upload / first dispatch failed on another rank")[:300]}
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fr.render(min(spp, 8), B); fr.reduce(dist); barrier()          # warm-up (code object, buffers, the collective's first use)
+    fr.reduce(dist); barrier()          # (the collective's first use)
     fr.ctx.reset_counters()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     best = None
@@ -353,13 +387,13 @@ def scaling_workload(key, api, render, torch, dist, built_dir, local_rank, rank,
         wall_ms, render_ms, gather_ms, total_rays = float(tmax[0]), float(tmax[1]), float(tmax[2]), float(tt[3])
     else:
         wall_ms, render_ms, gather_ms, total_rays = (float(v) for v in tt)
-    fr.close()
-    scene.close()
+    close()
+    full_spp = SCALING_FULL_SPP_NOTE.get(key, "")
     return {"workload": wl["what"].format(W=W, H=H, SPP=f"{spp} of {wl['samples']}", B=B), "spp": spp, "n_gpus": world,
             "mrays": round(total_rays / wall_ms / 1e3, 1), "ms": round(wall_ms, 3), "render_ms": round(render_ms, 3), "gather_ms": round(gather_ms, 3),
             "rays": int(total_rays), "scaling": "strong (the frame is a fixed job)",
             "note": "best of %d frames, wall clock between barriers, max over ranks; render_ms / gather_ms = stream events around this rank's dispatch / the strip gather "
-                    "(at N > 1 a rank's gather_ms includes waiting for the slowest peer)" % reps}
+                    "(at N > 1 a rank's gather_ms includes waiting for the slowest peer)%s" % (reps, full_spp)}
 
 
 def parity_columns(img, ref):
@@ -589,15 +623,7 @@ def main():
         elapsed, gather_ms, kernel_ms_max = float(tmax[0]), float(tmax[3]), float(tmax[4])
     total_rays, total_paths = float(tt[1]), float(tt[2])
 
-    scaling = {}
-    if a.workload == "cfg2" and SPP == WORKLOAD["samples"] and not a.no_others:
-        for key in ("cfg4", "soup10m"):
-            try:
-                scaling[key] = scaling_workload(key, api, render, torch, dist, BUILT, local_rank, rank, world)
-            except Exception as e:          # must not take the headline line with it
-                scaling[key] = {"failed": f"{type(e).__name__}: {e}"[:300]}
-                if world > 1:
-                    raise
+    out = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = total_rays / elapsed / 1e6
@@ -651,6 +677,18 @@ def main():
                                        "frac_with_path_state adds 152 B/ray for the per-wave path table. What binds the kernel: `bound_evidence`",
                          "valu": valu},
         }
+        if world > 1:
+            # the headline FIRST: the scaling objects below are the first time RCCL's grouped send / receive meets the 1 GB soup on N real GPUs — whatever
+            # happens there, this line is out. The complete line follows when they have run
+            print(json.dumps({**out, "provisional": "headline only: the complete line (scaling_cfg4, scaling_soup10m) follows"}), flush=True)
+    scaling = {}
+    if a.workload == "cfg2" and SPP == WORKLOAD["samples"] and not a.no_others:
+        for key in ("cfg4", "soup10m"):
+            try:
+                scaling[key] = scaling_workload(key, api, render, torch, dist, BUILT, local_rank, rank, world)
+            except Exception as e:          # must not take the headline line with it (local failures come back as {"failed": ...} on every rank: scaling_workload)
+                scaling[key] = {"failed": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0:
         for key, obj in scaling.items():
             out["scaling_" + key] = obj
         if world == 1 and not a.no_cpu:

@@ -149,3 +149,54 @@ def test_c_host_partition_equals_the_python_hosts_and_covers_the_frame_once(widt
         for x0, y0, x1, y1 in mine:
             cover[y0:y1, x0:x1] += 1
     assert (cover == 1).all()
+
+
+def _failing_side_workload_worker(rank, world, port, built_dir, out_dir):
+    """bench.py's scaling_workload with a renderer that cannot start on rank 1 (and starts on rank 0): what every rank gets back."""
+    sys.path.insert(0, REPO)
+    import importlib.util
+    import json
+    import types
+    import torch
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Scene:
+        def __init__(self, blob): self.blob = blob
+        def close(self): pass
+
+    class FrameRenderer:
+        def __init__(self, api, scene, w, h, device, rank, world, tile, order):
+            if rank == 1:
+                raise RuntimeError("hipMalloc: out of memory (a GPU that cannot hold the scene)")
+            self.ctx = types.SimpleNamespace(set_option=lambda *a: None)
+        def render(self, spp, bounces): pass
+        def close(self): pass
+    api = types.SimpleNamespace(Scene=Scene, abi=types.SimpleNamespace(OPT_COUNTER_LEVEL=1))
+    render = types.SimpleNamespace(FrameRenderer=FrameRenderer)
+    got = bench.scaling_workload("cfg4", api, render, torch, dist, built_dir, rank, rank, world, device=torch.device("cpu"))
+    json.dump(got, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()          # (every rank is still in step with the others: the next collective of the bench — its closing barrier — goes through)
+    dist.destroy_process_group()
+
+
+def test_a_side_workload_that_fails_on_one_rank_fails_on_all_and_nobody_hangs(tmp_path):
+    """at N > 1 a failure inside a scaling object on ONE rank used to re-raise there and leave its peers in the next collective — taking the headline
+    line of that N with it. Now the ranks agree (all_ranks_ok) after every local phase; all of them return {"failed": ...} and carry on. bench.py also prints the
+    headline line before the scaling objects run (the same dict, marked provisional)."""
+    import json
+    import torch.multiprocessing as mp
+    built = tmp_path / "built"
+    built.mkdir()
+    (built / "cfg4_statues.blob").write_bytes(b"not a scene: the stand-in renderer never reads it")
+    mp.spawn(_failing_side_workload_worker, args=(2, _free_port(), str(built), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1))
+    assert "failed" in r0 and "another rank" in r0["failed"], r0
+    assert "failed" in r1 and "out of memory" in r1["failed"], r1
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert src.index('"provisional"') < src.index("scaling[key] = scaling_workload("), "the headline line must be printed before the scaling objects run"

@@ -1045,6 +1045,8 @@ static int uploadCompiled(crh_ctx *c, const CompiledScene &cs, const int32_t *pr
 	{ const crh_camera *cam = nullptr; rc = upload(c, &cs.camera, 1, &cam); if (rc) { freeScene(c); return rc; } d.camera = cam; }
 	c->d = d;
 	c->haveWide = !cs.wide.empty(); c->wideTlasRoot = cs.wide_tlas_root;
+	if (cs.want_wide && !c->haveWide && !cs.wide_refused.empty())          /* (not only under CRH_TRACE_UPLOAD — the frame would silently be the binary walk's) */
+		fprintf(stderr, "libcray_hip: CRH_WALK_WIDE4 was asked for, but this scene has no 4-ary copy (%s): the binary walk renders it\n", cs.wide_refused.c_str());
 	c->hasPrograms = cs.prog.size() > 1 || cs.has_volumes || getenv("CRH_FORCE_PROGRAMS") != nullptr;    /* the rare-features kernel variant */
 	c->hasVolumes = cs.has_volumes;
 	c->haveScene = true;
@@ -1117,14 +1119,19 @@ int crh_scene_upload(crh_ctx *c, const crh_scene_desc *scene) {
 	CompiledScene *const trash = compiled.release();
 	c->janitorGo = false;
 	c->janitorWaiting.store(true);
-	c->janitor = std::thread([c, trash]() {
-		{ std::unique_lock<std::mutex> lk(c->janitorMu); c->janitorCv.wait(lk, [c]() { return c->janitorGo; }); }
-		const auto t0 = std::chrono::steady_clock::now();
+	try {
+		c->janitor = std::thread([c, trash]() {
+			{ std::unique_lock<std::mutex> lk(c->janitorMu); c->janitorCv.wait(lk, [c]() { return c->janitorGo; }); }
+			const auto t0 = std::chrono::steady_clock::now();
+			delete trash;
+			if (getenv("CRH_TRACE_UPLOAD"))
+				fprintf(stderr, "crh_scene_upload trace: the compiled host arrays were released in %.1f ms (behind a dispatch, or at the next upload / the context's end)\n",
+						std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		});
+	} catch (const std::system_error &) {          /* no thread to be had: the scene IS resident — release the host arrays here and now, and say OK */
+		c->janitorWaiting.store(false);
 		delete trash;
-		if (getenv("CRH_TRACE_UPLOAD"))
-			fprintf(stderr, "crh_scene_upload trace: the compiled host arrays were released in %.1f ms (behind a dispatch, or at the next upload / the context's end)\n",
-					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-	});
+	}
 	return CRH_OK;
 	});
 }
@@ -1139,8 +1146,8 @@ struct crh_compiled_scene {
 
 int crh_scene_compile(const crh_scene_desc *scene, int walk, crh_compiled_scene **out) {
 	if (!scene || !out) return fail(CRH_ERR_INVALID, "crh_scene_compile: NULL argument");
+	*out = nullptr;          /* (before anything can fail: a caller that frees the handle on error must not free garbage) */
 	if (walk != CRH_WALK_BINARY && walk != CRH_WALK_WIDE4) return fail(CRH_ERR_INVALID, "crh_scene_compile: walk must be CRH_WALK_BINARY or CRH_WALK_WIDE4");
-	*out = nullptr;
 	return guarded("crh_scene_compile", [&]() -> int {
 		const auto t0 = std::chrono::steady_clock::now();
 		std::unique_ptr<crh_compiled_scene> h(new crh_compiled_scene);

@@ -200,6 +200,9 @@ static void *masterThread(void *arg) {
 }
 
 static void poolJoin(int device);
+/* (a stated limit: this handler covers the context MAKERS. A logr(error) -> exit() from inside renderFrame / renderInteractive while the frame's GPU threads have
+ * dispatches in flight is not waited for here — those threads block in crh_synchronize for the length of a frame, and exit() would hang as long; the reference's own worker
+ * threads are not joined on that path either: renderer.c:96-117 —, and a maker that hangs inside hipMalloc holds exit() up with it.) */
 /* the process never exits with HIP calls in flight (logr(error) exit()s on a scene the parser rejects, while the makers may be inside hipMalloc or a code-object
  * load — ROCm's teardown is known to crash then): exit() waits for the makers here; the contexts themselves are left to the process's end */
 static void poolAtExit(void) {
@@ -296,7 +299,8 @@ static void *gpuThread(void *arg) {
 	 * counter level 1: this host reports rays only (the detailed counters cost ~20 % of the kernel's time) */
 	w->ctx = poolAcquire(w->device);
 	const long preparedUs = getUs(phase);
-	int ok = w->ctx != NULL && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
+	/* (a pooled context has rendered before in this process: the frame's ray count starts at zero — ADVICE r05) */
+	int ok = w->ctx != NULL && crh_counters_reset(w->ctx) == CRH_OK && crh_framebuffer_alloc(w->ctx, W, H, &w->fb) == CRH_OK;
 	if (getenv("CRH_TRACE_UPLOAD"))
 		fprintf(stderr, "gpuThread trace: GPU %d has its context (pool, or created + code objects + per-wave buffers) after %.1f ms, its framebuffer after %.1f ms\n",
 				w->device, preparedUs / 1e3, getUs(phase) / 1e3);
@@ -401,7 +405,7 @@ static uint64_t renderInteractive(struct renderer *r, struct texture *output, co
 	if (gpus > 1 && crh_scene_compile(scene, frameWalk(), &compiled) != CRH_OK) logr(error, "c-ray-hip: %s\n", crh_last_error());          /* (the pooled contexts' CRH_OPT_WALK; the Halton sampler keeps the binary walk either way) */
 	for (int g = 0; g < gpus; ++g) {
 		ctx[g] = poolAcquire(g);
-		if (!ctx[g] || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
+		if (!ctx[g] || crh_counters_reset(ctx[g]) != CRH_OK || crh_set_option(ctx[g], CRH_OPT_SAMPLER, CRH_SAMPLER_HALTON) != CRH_OK ||
 			crh_set_option(ctx[g], CRH_OPT_COUNTER_LEVEL, 1) != CRH_OK || (compiled ? crh_scene_upload_compiled(ctx[g], compiled) : crh_scene_upload(ctx[g], scene)) != CRH_OK ||
 			crh_framebuffer_alloc(ctx[g], W, H, &fb[g]) != CRH_OK)
 			logr(error, "c-ray-hip: GPU %i: %s\n", g, crh_last_error());

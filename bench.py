@@ -41,11 +41,12 @@ WORKLOADS["soup10m"] = {"scene": None, "blob": "soup_10m", "width": 2560, "heigh
                         "what": "synthetic 10 M-triangle soup {W}x{H}, {SPP} spp, {B} bounces (BASELINE.json configs[4] at its real size; the 1.04 GB scene is built on this box by "
                                 "tools/make_soup_blob.py: gen_soup's triangles as the reference's loader reads them + the GPU BVH builder, the reference's tree)"}
 WORKLOAD = WORKLOADS["cfg2"]
-# what `other_workloads` measures beside the headline: (workload, spp of the measured dispatch, spp of a second, short dispatch kept for continuity with rounds 1-4).
-# Round 5: configs[2] and both soups at BASELINE's own sample counts — a frame is ONE dispatch of 1.7-3.7 s —, configs[3] at 256 of its 2048 passes
-# (the full frame is 25 s of one GPU; its rate no longer moves from 128 passes on: DESIGN.md section 3). The seed of a (pixel, pass) depends on the sample count
-# (sampler.c:42) and so does the path mix: the reduced figures understate (statues: 2.07 Gray/s at 4 spp, 2.34 at 16).
-OTHER_WORKLOADS = (("cfg3", 1024, 32), ("cfg4", 256, 4), ("soup", 512, 16), ("soup10m", 512, 8))
+# what `other_workloads` measures beside the headline: (workload, spp of the timed dispatch = BASELINE's own, spp of the counting dispatch, spp of a short dispatch kept for
+# continuity with rounds 1-4). Round 6: configs[3] is timed ONCE at its own 2048 passes too (24 s of one GPU; the seed of a (pixel, pass) depends on the
+# sample count, sampler.c:42, and so does the path mix) — its counters come from a 256-pass counting dispatch (bytes per ray carried over: stated in the object), and the
+# 256-pass rate of round 5's line stays beside it (`at_256_spp`).
+OTHER_WORKLOADS = (("cfg3", 1024, 1024, 32), ("cfg4", 2048, 256, 4), ("soup", 512, 512, 16), ("soup10m", 512, 512, 8))
+WIDE4_WORKLOADS = ("cfg3", "cfg4", "soup")          # the 4-ary walk (CRH_OPT_WALK = WIDE4: an option, not bit-exact at near ties) timed beside the contract's walk: `wide4_mrays`
 
 
 def workload_blob(key, built_dir):
@@ -231,12 +232,13 @@ def fractions(alg_bytes, traffic_bytes, ms, traffic_upper=None):
 
 
 def measure_other_workloads(api, abi, built_dir):
-    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region, at the sample counts of OTHER_WORKLOADS (BASELINE's own for configs[2] and the soups):
-    one counting dispatch and one timed dispatch of the full frame each (a dispatch of seconds needs no median), then three short dispatches at the reduced sample count
-    of rounds 1-4 (`reduced`). Mray/s, algorithmic bytes and fraction of the HBM roofline per workload; `traffic` where profiles/ holds a PMC measurement of
-    that workload on this device code (per dispatch of the spp it names, scaled to this dispatch's rays)."""
+    """BASELINE.json configs[2..4] beside the headline, OUTSIDE the timed region, at BASELINE's own sample counts (OTHER_WORKLOADS): one counting dispatch and one timed
+    dispatch of the full frame each (a dispatch of seconds needs no median), then three short dispatches at the reduced sample count of rounds 1-4 (`reduced`). Mray/s,
+    algorithmic bytes and fraction of the HBM roofline per workload; `traffic` = the PMC measurement of THAT dispatch (same workload, same sample count, this device code:
+    profiles/hbm_traffic_<workload>.json) — a record taken at another sample count is quoted per ray and says so (`traffic_from_spp`); `wide4_mrays` = the same frame with
+    the 4-ary walk (CRH_OPT_WALK, an option)."""
     out = {}
-    for key, spp, spp_reduced in OTHER_WORKLOADS:
+    for key, spp, spp_count, spp_reduced in OTHER_WORKLOADS:
         wl = WORKLOADS[key]
         t0 = time.perf_counter()
         try:
@@ -249,43 +251,80 @@ def measure_other_workloads(api, abi, built_dir):
             ctx.upload(scene)
             w, h, b = wl["width"], wl["height"], wl["bounces"]
             fb = ctx.framebuffer(w, h)
+
+            def timed(n):
+                ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
+                ctx.reset_counters()
+                ctx.clear(fb, w, h)
+                ctx.render_region(fb, w, h, n, b)
+                ctx.synchronize()
+                return ctx.kernel_time_ms()[0], ctx.counters()["rays"]
             ctx.set_option(abi.OPT_COUNTER_LEVEL, 2)
             ctx.reset_counters()
-            ctx.render_region(fb, w, h, spp, b)
+            ctx.render_region(fb, w, h, spp_count, b)
             ctx.synchronize()
             full = ctx.counters()
-            ctx.set_option(abi.OPT_COUNTER_LEVEL, 1)
-            ctx.reset_counters()
-            ctx.clear(fb, w, h)
-            ctx.render_region(fb, w, h, spp, b)
-            ctx.synchronize()
-            ms = ctx.kernel_time_ms()[0]
-            assert ctx.counters()["rays"] == full["rays"], "the timed dispatch traced other rays than the counting one"
+            ms, rays = timed(spp)
+            spent = ms
+            extra = {}
+            if spp_count == spp:
+                assert rays == full["rays"], "the timed dispatch traced other rays than the counting one"
+            else:          # the counters are the shorter dispatch's: quantities per ray carry over, and the shorter dispatch is timed too
+                ms_c, rays_c = timed(spp_count)
+                spent += ms_c
+                assert rays_c == full["rays"], "the timed dispatch traced other rays than the counting one"
+                extra[f"at_{spp_count}_spp"] = {"mrays": round(rays_c / ms_c / 1e3, 1), "kernel_ms": round(ms_c, 2), "rays": rays_c,
+                                                "note": f"round 5's line quoted this dispatch; the counters of this object (tests per ray, bytes per ray) were taken at {spp_count} spp"}
             times = []
             for _ in range(3):
-                ctx.clear(fb, w, h); ctx.reset_counters()
-                ctx.render_region(fb, w, h, spp_reduced, b)
-                ctx.synchronize()
-                times.append(ctx.kernel_time_ms()[0])
-            reduced_rays = ctx.counters()["rays"]
-            alg = algorithmic_bytes(full, path_state=False)
+                m_, reduced_rays = timed(spp_reduced)
+                times.append(m_)
+            spent += sum(times)
+            alg = algorithmic_bytes(full, path_state=False) * (rays / max(full["rays"], 1))
             traffic = upper = None
+            traffic_note = {}
             try:
                 t = json.load(open(os.path.join(REPO, "profiles", f"hbm_traffic_{key}.json")))
                 if t.get("source_md5") == kernel_source_md5() and t.get("rays"):
                     lo, hi = calibrated_traffic(t)
-                    traffic, upper = lo * full["rays"] / t["rays"], hi * full["rays"] / t["rays"]          # measured at t["spp"]; bytes per ray carried to this dispatch
+                    if t.get("spp") == spp and t["rays"] == rays:
+                        traffic, upper = lo, hi          # the PMC run WAS this dispatch
+                    else:
+                        traffic, upper = lo * rays / t["rays"], hi * rays / t["rays"]
+                        traffic_note = {"traffic_from_spp": t.get("spp"), "traffic_note": "PMC run at another sample count: bytes per ray carried to this dispatch"}
             except Exception:
                 pass
+            wide = {}
+            if key in WIDE4_WORKLOADS:
+                try:
+                    cw = api.Context(0)
+                    cw.set_option(abi.OPT_WALK, abi.WALK_WIDE4)
+                    cw.set_option(abi.OPT_COUNTER_LEVEL, 1)
+                    cw.upload(scene)
+                    fbw = cw.framebuffer(w, h)
+                    n_w = spp_count if spp_count != spp else spp
+                    cw.render_region(fbw, w, h, min(n_w, 8), b); cw.synchronize(); cw.reset_counters(); cw.clear(fbw, w, h)
+                    cw.render_region(fbw, w, h, n_w, b)
+                    cw.synchronize()
+                    ms_w, rays_w = cw.kernel_time_ms()[0], cw.counters()["rays"]
+                    spent += ms_w
+                    base_ms, base_rays = (ms, rays) if n_w == spp else (ms_c, rays_c)
+                    wide = {"wide4_mrays": round(rays_w / ms_w / 1e3, 1), "wide4": {"spp": n_w, "kernel_ms": round(ms_w, 2), "rays": rays_w, "kernel": cw.last_kernel_name(),
+                                                                                     "vs_binary_walk": round((rays_w / ms_w) / (base_rays / base_ms), 3),
+                                                                                     "note": "CRH_OPT_WALK = CRH_WALK_WIDE4 (an option; the binary walk is the bit-exact contract): same frame within "
+                                                                                             "SURVEY 8(c)'s gates — tests/test_gpu_parity.py::test_wide_walk_meets_the_tolerance_gates — but not bit for bit at near ties"}}
+                    cw.close()
+                except Exception as e:
+                    wide = {"wide4": {"failed": f"{type(e).__name__}: {e}"[:200]}}
             out[key] = {"workload": wl["what"].format(W=w, H=h, SPP=spp if spp == wl["samples"] else f"{spp} of {wl['samples']}", B=b), "spp": spp, "baseline_spp": wl["samples"],
-                        "mrays": round(full["rays"] / ms / 1e3, 1), "kernel_ms": round(ms, 2),
-                        "rays": full["rays"], "rays_per_path": round(full["rays"] / max(full["paths"], 1), 2),
+                        "mrays": round(rays / ms / 1e3, 1), "kernel_ms": round(ms, 2),
+                        "rays": rays, "rays_per_path": round(full["rays"] / max(full["paths"], 1), 2), "counters_from_spp": spp_count,
                         "node_tests_per_ray": round(full["node_tests"] / max(full["rays"], 1), 1), "tri_tests_per_ray": round(full["tri_tests"] / max(full["rays"], 1), 1),
-                        "bytes_per_ray": round(alg / max(full["rays"], 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1),
+                        "bytes_per_ray": round(alg / max(rays, 1), 1), "achieved_GBs": round(alg / ms / 1e6, 1),
                         **fractions(alg, traffic, ms, upper),
-                        "traffic": traffic,
+                        "traffic": traffic, **traffic_note, **extra, **wide,
                         "reduced": {"spp": spp_reduced, "mrays": round(reduced_rays / sorted(times)[1] / 1e3, 1), "kernel_ms": round(sorted(times)[1], 2), "note": "the sample count of rounds 1-4's lines (median of three dispatches)"},
-                        "setup_s": round(time.perf_counter() - t0 - (2 * ms + sum(times)) / 1e3, 2)}
+                        "setup_s": round(time.perf_counter() - t0 - spent / 1e3, 2)}
             ctx.close()
             scene.close()
         except Exception as e:      # a missing blob / failed build must not take the headline line with it
@@ -675,7 +714,10 @@ def main():
                                        "holds for 128-byte requests only: frac_measured_traffic_upper —, MALL hits included), frac_measured_traffic the same over time and HBM peak; both are "
                                        "null whenever profiles/hbm_traffic.json was not measured on this device code (fingerprint of the k_pathtrace* machine code) / this workload. "
                                        "frac_with_path_state adds 152 B/ray for the per-wave path table. What binds the kernel: `bound_evidence`",
-                         "valu": valu},
+                         "valu": valu,
+                         # the one number that says how far the kernel is from the machine: the share of the vector pipe's saturated issue rate it uses
+                         # x the share of a wave's 64 lanes that are active in what it issues
+                         "lane_fraction": round(sat * valu["lane_utilisation"], 4) if sat and (valu or {}).get("lane_utilisation") else None},
         }
         if world > 1:
             # the headline FIRST: the scaling objects below are the first time RCCL's grouped send / receive meets the 1 GB soup on N real GPUs — whatever

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/evidence_$TAG
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q -rfE --tb=short > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -2 $O/pytest_gpu.log
-timeout 600 python bench.py --steps 10 --warmup 2 > $O/bench_1gpu.log 2>&1; echo "bench rc $?"
+timeout 900 python bench.py --steps 10 --warmup 2 > $O/bench_1gpu.log 2>&1; echo "bench rc $?"
 timeout 400 tools/profile_round.sh $TAG cfg2 > $O/profile_cfg2.log 2>&1
 B=scenes/_built
 timeout 600 python tools/run_config.py --blob $B/cfg2_hdr.blob --width 1280 --height 720 --spp 256 --bounces 8 --parity-spp 256 --tag cfg2_hdr_full > $O/cfg2_hdr_full_parity.json 2> $O/cfg2.err
@@ -21,7 +21,7 @@ if [ -n "$SOUP10M" ]; then
 	timeout 300 python tools/bvh_bench.py --blob /tmp/crh_soup_10m.blob --tag soup_10m > $O/bvh_build_soup_10m.json 2>&1
 	CRH_BVH_TRACE=1 timeout 300 python tools/bvh_bench.py --blob /tmp/crh_soup_10m.blob --tag soup_10m --no-cpu 2>&1 | tail -20 > $O/bvh_trace_soup_10m.log
 fi
-timeout 900 bash tools/traffic_workloads.sh $TAG > $O/traffic_workloads.log 2>&1
+timeout 1500 bash tools/traffic_workloads.sh $TAG > $O/traffic_workloads.log 2>&1
 timeout 900 bash tools/pmc_deep.sh $TAG > $O/pmc_deep.log 2>&1
 CRH_BVH_TRACE=1 timeout 300 python tools/bvh_bench.py --blob $B/soup_1m.blob --tag soup_1m --no-cpu 2>&1 | tail -16 > $O/bvh_trace_soup_1m.log
 timeout 300 python tools/probe_exact.py > $O/probe_exact.log 2>&1

@@ -37,7 +37,8 @@ def emu_lib():
 GPU_TIER_JOBS = {     # name -> (files of the GPU tier, -k selection, number of tests that must run and pass)
     "trace_rays": (["test_gpu_parity.py"], "test_trace_rays_bit_exact and not baseline_configs", 6),
     "frames": (["test_gpu_parity.py"], "test_image_parity_vs_reference", 6),
-    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths or round_limit or upload_lifecycle or wide_walk_option or streaming_form", 14),
+    "schedules": (["test_gpu_parity.py"], "shade_class_batches or dispatch_decompositions or split_pixels or interactive_mode or edge_cases or zero_component or srgb8_matches or error_paths or round_limit or upload_lifecycle or wide_walk_option", 13),
+    "stream": (["test_gpu_parity.py"], "streaming_form or wide_walk_meets", 3),          # round 6: the streaming form (walk / shade + refill / fold kernels) against the rolling kernel and the fixtures; the 4-ary walk inside the tolerance gates
     "rare_and_wg": (["test_nodes.py", "test_volumes.py", "test_gpu_parity.py"], "test_gpu_node_zoo or test_gpu_volumes", 3),          # (test_gpu_volumes renders with both kernel forms;
     # test_workgroup_kernel_is_bit_identical_to_the_wave_kernel passes here too, but the lock's polling takes a minute of emulation)
     "bvh": (["test_bvh_build.py"], "not cfg2_hdr and not soup_1m", 8),
@@ -134,6 +135,12 @@ def test_schedules_decompositions_and_edge_cases_on_emulation(children):
     """Shade-class batches, tiles / pass chunks / unit sizes / taper levels, split pixels (pass segments folded behind the kernel), the Halton sampler, empty / ragged / single-pixel dispatches,
     bounces <= 0 (k_fold_black), degenerate rays, k_to_srgb8, the error paths of the C-ABI."""
     run_gpu_tier_on_emulation(children, "schedules")
+
+
+def test_streaming_form_on_emulation(children):
+    """CRH_KERNEL_STREAM (csrc/pathtrace_stream.h): the three kernels and the host loop that feeds them, bit-identical to the rolling kernel and to the reference's fixtures
+    for pool sizes from one cohort up; the 4-ary walk at SURVEY 8(c)'s gates on two BASELINE configs."""
+    run_gpu_tier_on_emulation(children, "stream")
 
 
 def test_node_programs_volumes_and_the_workgroup_kernel_on_emulation(children):

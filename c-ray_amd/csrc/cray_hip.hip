@@ -1487,7 +1487,7 @@ static int renderStream(crh_ctx *c, const crh_render_params *P, const crh_tile *
 	uint64_t npix64 = 0;
 	for (uint32_t i = 0; i < tile_count; ++i) {
 		crh_tile t = tiles[i];
-		if (t.x0 < 0 || t.y0 < 0 || t.x1 > P->image_width || t.y1 > P->image_height) return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");
+		if (t.x0 < 0 || t.y0 < 0 || t.x1 > P->image_width || t.y1 > P->image_height || t.x0 > t.x1 || t.y0 > t.y1) return fail(CRH_ERR_INVALID, "crh_render_tiles: tile outside the image");          /* (planWork's rule) */
 		if (t.x1 <= t.x0 || t.y1 <= t.y0) continue;
 		start.push_back((uint32_t)npix64);
 		work.push_back(t);

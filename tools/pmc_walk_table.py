@@ -14,7 +14,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         seen = {}
         for r in c.execute("select * from counters_collection"):
             k = str(r[ki])
-            if "k_walk_probe" not in k and "k_pathtrace" not in k:
+            if "k_walk_probe" not in k and "k_pathtrace" not in k and "k_stream" not in k:
                 continue
             k = re.sub(r"^void ", "", re.sub(r"\(.*", "", k))
             e = per.setdefault(k, {}).setdefault(r[ci], [0.0, set()])

@@ -228,77 +228,6 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 		if (lane == 0) { wq[RQ_HITS] = hq; wq[RQ_MISSES] = mq; wq[RQ_RAYS] = rq; }
 		__threadfence_block();
 	};
-#ifdef CRH_EXP_COOP_TRI
-	/* EXPERIMENT (round 6; variant builds only: tools/build_variant.sh coop -DCRH_EXP_COOP_TRI): a leaf step for all 64 lanes. The lanes at a leaf
-	 * (PH_TRI) pool their pending triangles — left range then right range, bvh.c:449-458 — and the wave's 64 lanes take one (owner, triangle) pair each, in owner order:
-	 * a lane fetches its owner's ray and entry distance through ds_bpermute, tests ONE triangle (poly.c:17-36) against that ENTRY distance, and a segmented min-scan hands
-	 * every owner the smallest accepted distance of its pairs, the FIRST of equals — which is what the reference's sequential strict `t < isect->distance` leaves: a later
-	 * triangle is accepted only below everything accepted before it, so the survivor is the minimum and, among equal distances, the one tested first; nothing else reads the
-	 * distance inside a leaf. Pairs beyond the 64th wait for the next step (their owners stay at the leaf with the ranges advanced). The 64 bytes of LDS per wave are the
-	 * shade-class table's, which is idle unless CRH_OPT_SHADE_SORT is on (the variant refuses that option). */
-	auto coopTriStep = [&]() __attribute__((always_inline)) {
-		const bool isT = w.phase == PH_TRI;
-		const uint32_t nA = isT ? w.pAe - w.pA : 0u, nB = isT ? w.pBe - w.pB : 0u, n = nA + nB;
-		uint32_t incl = n;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, (unsigned)d); if ((int)lane >= d) incl += o; }
-		const uint32_t excl = incl - n;
-		const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
-		const uint32_t served = excl >= 64u ? 0u : (n < 64u - excl ? n : 64u - excl);
-		lds_u8 *const own = (lds_u8 *)&s_cls[(threadIdx.x >> 6) * 64u];
-		for (uint32_t k = 0; k < served; ++k) own[excl + k] = (uint8_t)lane;
-		CRH_LOCKSTEP();
-		const bool act = lane < (total < 64u ? total : 64u);
-		const int o = act ? (int)own[lane] : (int)lane;
-		CRH_LOCKSTEP();
-		/* the owner's ranges first (the triangle's address needs nothing else), then — with the triangle's three quarters in flight — its ray */
-		const uint32_t oExcl = __shfl(excl, o), oPA = __shfl(w.pA, o), oNA = __shfl(nA, o), oPB = __shfl(w.pB, o);
-		const uint32_t k = lane - oExcl;
-		const uint32_t slot = k < oNA ? oPA + k : oPB + (k - oNA);
-		f4 t0 = f4{0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0, t2 = t0;
-		if (act) { const char *rec = (const char *)S.nodes + (trisOff + slot * 48u); t0 = *(const f4 *)rec; t1 = *(const f4 *)(rec + 16); t2 = *(const f4 *)(rec + 32); }
-		const v3 ro = v3{__shfl(w.k.o.x, o), __shfl(w.k.o.y, o), __shfl(w.k.o.z, o)}, rd = v3{__shfl(w.k.d.x, o), __shfl(w.k.d.y, o), __shfl(w.k.d.z, o)};
-		const float tEntry = __shfl(w.hit.t, o);
-		float key = __builtin_inff(), tu = 0.0f, tv = 0.0f;
-		if (act) {          /* poly.c:17-36 on the prepared record, operand for operand (testTriangle) */
-			const v3 v0 = v3{t0.x, t0.y, t0.z}, e1 = v3{t0.w, t1.x, t1.y}, e2 = v3{t1.z, t1.w, t2.x}, nn = v3{t2.y, t2.z, t2.w};
-			const v3 c = vsub(v0, ro);
-			const v3 r = vcross(rd, c);
-			const float invDet = 1.0f / vdot(nn, rd);
-			const float u = vdot(r, e2) * invDet;
-			const float v = vdot(r, e1) * invDet;
-			if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
-				const float t = vdot(nn, c) * invDet;
-				if (t >= 0.0f && t < tEntry) { key = t; tu = u; tv = v; }
-			}
-		}
-		/* inclusive segmented min-scan, left to right: (distance, pair) of the best pair of this lane's owner up to this lane; of equal distances the left (earlier) one stays */
-		uint32_t best = lane;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const float pk = __shfl_up(key, (unsigned)d);
-			const uint32_t pb = __shfl_up(best, (unsigned)d);
-			if ((int)lane >= d && lane - (uint32_t)d >= oExcl && pk <= key) { key = pk; best = pb; }
-		}
-		/* every owner: the scan's value at its last served pair */
-		const int last = (int)((excl + (served ? served : 1u) - 1u) & 63u);
-		const float bKey = __shfl(key, last);
-		const int bLane = (int)(__shfl(best, last) & 63u);
-		const float bu = __shfl(tu, bLane), bv = __shfl(tv, bLane);
-		if (isT && served) {
-			CRH_COUNT(cnt, tri_tests, served);
-			if (bKey < w.hit.t) {
-				const uint32_t bk = (uint32_t)bLane - excl;
-				w.hit.t = bKey; w.hit.u = bu; w.hit.v = bv; w.hit.slot = (int32_t)(bk < nA ? w.pA + bk : w.pB + (bk - nA)); w.instFound = 1;
-			}
-			const uint32_t cA = served < nA ? served : nA;
-			w.pA += cA; w.pB += served - cA;
-			if (w.pA == w.pAe) { w.pA = w.pB; w.pAe = w.pBe; w.pB = w.pBe = 0; }
-			TablePort<SAMP> port2{ptab + myPath * CRH_PATH_F4};
-			walkAdvance(S, w, stk, cnt, port2);
-		}
-	};
-#endif
 	uint32_t guard = (uint32_t)K.roundLimit;
 	for (;;) {
 		if (--guard == 0u) { if (lane == 0) atomicOr(errFlag, CRH_ERRFLAG_ROUND_LIMIT); break; }
@@ -378,11 +307,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 				do {
 					const bool isN = w.phase == PH_NODE;
 					const int nTw = (int)__popcll(__ballot(w.phase == PH_TRI));
-#ifdef CRH_EXP_COOP_TRI
-					const bool isT = false;          /* (the leaf lanes are served cooperatively, behind the node step) */
-#else
 					const bool isT = nTw >= K.triInRun && w.phase == PH_TRI;
-#endif
 					if constexpr (LEVEL >= 2) {
 						if (lane == 0) { CRH_WCTR(11, 1); CRH_WCTR(17, now); }
 #ifdef CRH_CENSUS          /* the node-run census (tools/emu_sched_stats.py: who sits a node step out, and why): six more per-lane counters, which the kernel emulation can afford and the
@@ -404,9 +329,6 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 					else
 					if (isN) stepNodeLoaded<true>(S, w, stk, cnt, port, q0, q1, q2, q3);
 					if (isT) stepTriLoaded(S, w, stk, cnt, port, q0, q1, q2, q3, q4, q5);
-#ifdef CRH_EXP_COOP_TRI
-					if ((int)__popcll(__ballot(w.phase == PH_TRI)) >= K.triInRun) coopTriStep();
-#endif
 					if ((int)__popcll(__ballot(w.phase == PH_CTRL)) >= K.ctrlInRun) {
 #ifdef CRH_CENSUS
 						if constexpr (LEVEL >= 2) { const uint32_t n2 = (uint32_t)__popcll(__ballot(w.phase == PH_CTRL)); if (lane == 0) { CRH_WCTR(28, 1); CRH_WCTR(29, n2); } }
@@ -432,11 +354,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_WPS_OVERRIDE) void k_pathtrace_roll(
 			case ST_TRI: {
 				int now = nT;
 				do {
-#ifdef CRH_EXP_COOP_TRI
-					coopTriStep();
-#else
 					if (w.phase == PH_TRI) stepTri(S, w, stk, cnt, port);
-#endif
 					if constexpr (LEVEL >= 2) { if (lane == 0) { CRH_WCTR(12, 1); CRH_WCTR(24, now); } }
 					now = __popcll(__ballot(w.phase == PH_TRI));
 				} while (now * 8 >= nT * K.runNum);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""emu_coop_tri_check.py — dev: the cooperative leaf step (-DCRH_EXP_COOP_TRI, csrc/pathtrace_roll.h: coopTriStep; round 6) against the shipped two-triangle
+"""emu_coop_tri_check.py — dev: the cooperative leaf step (profiles/r06g_exp_coop_tri.patch: -DCRH_EXP_COOP_TRI, pathtrace_roll.h: coopTriStep; round 6; a
+measured negative, so the product source does not carry it: `git apply profiles/r06g_exp_coop_tri.patch` first) against the shipped two-triangle
 step in the kernel emulation: same frame and the same eight counters (tri_tests among them) required. Builds nothing: first
     cd tests/emu && g++ -std=c++17 -O1 -march=x86-64-v3 -ffp-contract=off -fPIC -pthread -Wno-attributes -Wno-unknown-pragmas -Ihipemu -I../../include -I../../c-ray_amd/csrc \
         -DCRH_DEV_ONLY_BENCH_VARIANT -DCRH_DEV_ONLY_LEVEL2 -DCRH_EXP_COOP_TRI -c kernel_emu.cpp -o _obj/kernel_emu_coop.o && \

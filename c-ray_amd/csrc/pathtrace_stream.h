@@ -12,7 +12,7 @@
  *   k_stream_shade  one workgroup per cohort (persistent, cohorts from a counter): sorts the cohort's slots into surface hits and misses (an ordered list in LDS), runs
  *                   shadeCore (pathtrace.c:39-57) on full waves of hits, then of misses; a path that continues goes — with its next ray — to the next free slot at the
  *                   front of the SAME cohort of the other pool, a path that ends stages its sample. The slots that stay free are REFILLED in place with new camera rays
- *                   (renderer.c:280-284: the next items of the dispatch, handed out by one compare-and-swap per cohort), so every cohort stays full until the dispatch
+ *                   (renderer.c:280-284: the next items of the dispatch, handed out by one fetch-and-add per cohort), so every cohort stays full until the dispatch
  *                   runs out of items: no global compaction, no global queue.
  *   k_stream_fold   the running mean (renderer.c:288-291) in pass order: the dispatch's passes are cut into CHUNKS (all pixels x a few passes); a chunk's samples wait in one
  *                   slot of a ring of slabs, a counter per slot says how many are still missing, and the chunk that is complete — and next in order — is folded
@@ -21,6 +21,12 @@
  *
  * Every step of a path is the one the other kernel forms run (same lane code, same arithmetic): the frame is the same bit for bit (tests/test_gpu_parity.py,
  * tests/test_kernel_emu.py), whatever the pool size, the chunk size or the order in which cohorts are served.
+ *
+ * MEASURED (MI355X, profiles/r06f_ab_stream_long.log, r06e_stream_trace.txt, r06j_pmc_stream_statues.txt): the walk kernel runs at the probe's rate — 16.8 M rays
+ * in 5.5 ms on statues.json (3.0 Gray/s; the megakernel's walk: 2.6), 1.25 ms on hdr.json — and the FRAME is slower than the megakernel's: 0.82 x statues, 0.72 x / 0.77 x
+ * the soups, 0.51 x hdr.json, because the shade pass (2.3 ms per 16.8 M paths, parked on memory 86 % of its cycles behind HBM-latency chains) is serial with the walk and the
+ * occupancy it buys the walk is 0-24 %. This form is an OPTION (CRH_OPT_KERNEL = CRH_KERNEL_STREAM, env CRH_KERNEL=stream), not the default; it is kept because it is the
+ * measured answer to "what does the walk do at more than four waves per SIMD", bit-identical and tested.
  */
 #pragma once
 
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(CRH_BLOCK, 4) void k_stream_shade(const DScene Sarg
 			}
 		}
 		__syncthreads();
-		/* the slots that stay free take the dispatch's next items (renderer.c:280-284): one compare-and-swap per cohort hands them out */
+		/* the slots that stay free take the dispatch's next items (renderer.c:280-284): one fetch-and-add per cohort hands them out */
 		const uint32_t nOut = sw[SW_OUT];
 		if (threadIdx.x == 0) {
 			/* (a fetch-and-add, not a compare-and-swap: a thousand workgroups retrying against each other took 60 ms per iteration. The counter may run past the limit — the

@@ -66,6 +66,7 @@ def children(emu_lib):
     start("roll", [sys.executable, os.path.join(EMU_DIR, "render_fixture.py"), "0", *ROLL_FIXTURES])
     start("steps", [sys.executable, os.path.join(EMU_DIR, "sched_counts.py"), *PINNED_STEPS])
     start("fuzz", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:9"])
+    start("fuzz_stream", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz.py"), "--seeds", "0:4", "--fixtures", "fence,refraction,glowmetal,volumes"], FUZZ_KERNEL="3")
     start("fuzz_split", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_split.py"), "--seeds", "0:8"])
     start("fuzz_bvh", [sys.executable, os.path.join(REPO, "tools", "emu_fuzz_bvh.py"), "--seeds", "0:19"])
     # the top levels' path (per-chunk bin rows + k_fold_bins instead of global atomics) is taken from 64 chunks per node on: CRH_BVH_FOLD_MIN_CHUNKS=1 sends these small meshes through it
@@ -212,6 +213,15 @@ def test_schedule_fuzz_on_emulation(children):
     rc, text = children("fuzz")
     assert rc == 0, text[-4000:]
     assert text.count('"ok": true') == 9, text[-4000:]
+
+
+def test_streaming_form_fuzz_on_emulation(children):
+    """tools/emu_fuzz.py with the streaming form (CRH_KERNEL_STREAM, round 6): four seeded cases — random pool sizes (a few cohorts: many iterations), device sizes, walk
+    scheduler parameters, tile covers (rectangles narrower than the 8 x 8 pixel order's blocks) and pass splits; the volumes fixture is served by the rolling kernel behind
+    the same option. 72 cases ran when the form was built (profiles/r06k_emu_fuzz_stream.log)."""
+    rc, text = children("fuzz_stream")
+    assert rc == 0, text[-4000:]
+    assert text.count('"ok": true') == 4, text[-4000:]
 
 
 def test_split_pixel_fuzz_on_emulation(children):

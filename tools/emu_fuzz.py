@@ -2,7 +2,7 @@
 """emu_fuzz.py — dev / test: schedule fuzzing of the REAL kernels on the kernel emulation (tests/emu/libcray_hip_emu.so). Every result is
 independent of how a frame is dispatched and scheduled — so random work plans (unit size, units per wave, pass chunk, taper), scheduler
 parameters (weights, run lengths, in-run thresholds, paths in flight, shade batch size), kernel forms (wave / workgroup / rolling
-units), device sizes (CUs, blocks per CU), tile decompositions and pass splits must all give the reference's frame bit for bit, with the
+units / 3 = the streaming form of round 6 with a random pool size), device sizes (CUs, blocks per CU), tile decompositions and pass splits must all give the reference's frame bit for bit, with the
 reference's ray count. Seeds are deterministic; a failing case prints its full configuration.
 
     python tools/emu_fuzz.py [--seeds A:B] [--fixtures fence,refraction,...] [--kernels 0,1,2]      (one JSON line per case)
@@ -52,6 +52,7 @@ for seed in range(lo, hi):
     cfg["tiles"] = len(rects); cfg["pass_cuts"] = cuts
     cfg["tail_split"] = rng.choice([0, 1, 4, 64])          # (the rolling kernel's 64-path units at the end of the queue; pass segments of split pixels: tools/emu_fuzz_split.py)
     cfg["swap_in_run"] = rng.choice([1, 4, 20, 33, 65])          # (drawn after everything else: the earlier fields of a seed stay what they were)
+    cfg["stream_cohorts"] = rng.choice([1, 2, 5, 37, 16384])          # (round 6: the pool size of the streaming form, kernel == 3 — one cohort: hundreds of iterations and a turning sample ring)
     os.environ["HIPEMU_CUS"] = str(cfg["cus"])
     pkg = load_package(); api, abi = pkg.api, pkg.abi
     t0 = time.time()
@@ -69,6 +70,7 @@ for seed in range(lo, hi):
                   tri_in_run=cfg["tri_in_run"], ctrl_in_run=cfg["ctrl_in_run"], shade_min=cfg["shade_min"], swap_in_run=cfg["swap_in_run"])
     ctx.set_option(abi.OPT_SHADE_SORT, cfg["sort_from"])
     ctx.set_option(abi.OPT_TAIL_SPLIT, cfg["tail_split"])
+    ctx.set_option(abi.OPT_STREAM_COHORTS, cfg["stream_cohorts"])
     if cfg["kernel"] == 1:
         ctx.set_sched_wg(linger=cfg["wg_linger"], drain_at=cfg["wg_drain_at"], max_drainers=cfg["wg_max_drainers"], partial_min=cfg["wg_partial_min"],
                          walk_min=cfg["wg_walk_min"], fill_to=cfg["wg_fill_to"])

@@ -597,7 +597,10 @@ struct Compiler {
 		assignShadeClasses();
 		if (getenv("CRH_TRACE_UPLOAD")) fprintf(stderr, "compile_scene trace: TLAS + instances + classes %.1f ms\n", lap());
 		if (out.nodes.empty()) out.nodes.resize(4, f4{0, 0, 0, 0});
-		if (out.want_wide) {
+		/*  a scene with node programs or volumes is rendered by the rare-features kernel, which has no wide instantiation (cray_hip.hip: wideWalk): no copy is
+		 * built or uploaded for it — the binary walk renders it, as it did, and the context says so */
+		if (out.want_wide && (out.prog.size() > 1 || out.has_volumes)) out.wide_refused = "node programs / volumes: the rare-features kernel walks the binary tree";
+		else if (out.want_wide) {
 			try {
 				std::vector<uint32_t> wideRoot(s->mesh_count, CRH_NONE);
 				uint32_t blasDepth = 0;

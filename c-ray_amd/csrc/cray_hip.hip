@@ -1583,7 +1583,7 @@ static int renderStream(crh_ctx *c, const crh_render_params *P, const crh_tile *
 	hipLaunchKernelGGL(k_stream_init, dim3(std::min<uint32_t>(64u, (cohorts + 255u) / 256u)), dim3(256), 0, c->stream, Pl, pool[0].count, pool[1].count, c->dStreamCtl,
 	                   (const uint32_t *)hostView, (uint32_t *)ts.dev, (uint32_t)((tileBytes + startBytes) / 4));
 	hipError_t e = hipGetLastError();
-	const uint32_t shadeGrid = std::min<uint32_t>((uint32_t)c->cuCount * 4u, cohorts);
+	const uint32_t shadeGrid = std::min<uint32_t>((uint32_t)c->cuCount * (uint32_t)CRH_STREAM_SHADE_WPS, cohorts);
 	const uint32_t foldGrid = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)c->cuCount * 4u, (npix + CRH_BLOCK - 1u) / CRH_BLOCK));
 	snprintf(c->lastKernel, sizeof(c->lastKernel), "k_stream<%d,%s> walk<%d,%d>", c->counterLevel >= 2 ? 2 : 1, c->hasPrograms ? "true" : "false",
 	         deepStack ? CRH_STREAM_WALK_B_WPS : CRH_STREAM_WALK_A_WPS, deepStack ? CRH_STREAM_WALK_B_NLDS : CRH_STREAM_WALK_A_NLDS);

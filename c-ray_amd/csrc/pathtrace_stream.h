@@ -30,6 +30,9 @@
  */
 #pragma once
 
+#ifndef CRH_STREAM_SHADE_WPS
+#define CRH_STREAM_SHADE_WPS 4         /* workgroups of k_stream_shade per CU the register allocator leaves room for (97 VGPRs as it is; 5 was measured: see DESIGN.md section 3) */
+#endif
 #define CRH_SF_COHORT 1024u            /* slots per cohort (= what one workgroup of k_stream_shade sorts in LDS: 16-bit indices) */
 #define CRH_SF_UNIT 128u               /* slots per unit of the walk kernel's work counter */
 #define CRH_SF_COUNTERS 16u            /* unit counters of the walk kernel (a power of two) ... */
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(CRH_BLOCK, WPS) void k_stream_walk(const DScene Sar
 
 /* SHADE + REFILL: pathtrace.c:39-57 on the walked paths of one pool, their continuations and the camera rays that take the freed slots into the other pool */
 template <int LEVEL, bool PROG, int SAMP>
-__global__ __launch_bounds__(CRH_BLOCK, 4) void k_stream_shade(const DScene Sarg, const crh_render_params P, const StreamPlan Pl, const StreamPool in, const StreamPool out, StreamCtl *ctlArg,
+__global__ __launch_bounds__(CRH_BLOCK, CRH_STREAM_SHADE_WPS) void k_stream_shade(const DScene Sarg, const crh_render_params P, const StreamPlan Pl, const StreamPool in, const StreamPool out, StreamCtl *ctlArg,
                                                                unsigned long long *counters) {
 	__shared__ uint16_t s_list[CRH_SF_COHORT];            /* slot indices inside the cohort: surface hits from the front, misses from the back, both in slot order */
 	__shared__ uint32_t s_seg[2][16];                     /* hits / misses per (pass, wave) segment of the classification */

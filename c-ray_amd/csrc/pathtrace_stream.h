@@ -280,12 +280,20 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_STREAM_SHADE_WPS) void k_stream_shad
 	typedef volatile __attribute__((address_space(3))) uint32_t lds_word;
 	lds_word *const sw = (lds_word *)s_word;
 	lds_word *const fin = (lds_word *)s_fin;
+#ifdef CRH_STREAM_CLOCKS          /* dev (tools/probe_stream_clocks.py): where a workgroup's time goes, in 100 MHz ticks summed over workgroups: counters[8 + phase] */
+	unsigned long long tPh = wall_clock64();
+#define CRH_SCLK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&counters[8 + (k)], t_ - tPh); tPh = t_; } } while (0)
+#else
+#define CRH_SCLK(k) do { } while (0)
+#endif
 	for (;;) {
 		__syncthreads();                      /* every thread is through with the last cohort's words */
+		CRH_SCLK(5);
 		if (threadIdx.x == 0) { s_word[SW_COHORT] = atomicAdd((uint32_t *)&ctl->shadeCtr, 1u); s_word[SW_OUT] = 0u; s_word[SW_NEW] = 0u; }
 		if (threadIdx.x < CRH_SF_RING) s_fin[threadIdx.x] = 0u;
 		__syncthreads();
 		const uint32_t t = sw[SW_COHORT];
+		CRH_SCLK(0);
 		if (t >= Pl.cohorts) break;
 		const uint32_t base = t * CRH_SF_COHORT;
 		const uint32_t nIn = liveIn ? asGlobal(in.count)[t] : 0u;          /* (a pool nobody wrote last iteration holds nothing) */
@@ -323,6 +331,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_STREAM_SHADE_WPS) void k_stream_shad
 			}
 			__syncthreads();
 		}
+		CRH_SCLK(1);
 		/* surface hits, a wave's 64 at a time: pathtrace.c:43-57 */
 		for (uint32_t jb = wv * 64u; jb < nHit; jb += CRH_BLOCK) {
 			const uint32_t j = jb + lane;
@@ -374,6 +383,10 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_STREAM_SHADE_WPS) void k_stream_shad
 				dm &= ~sm;
 			}
 		}
+#ifdef CRH_STREAM_CLOCKS
+		__syncthreads();
+#endif
+		CRH_SCLK(2);
 		/* misses: the background (pathtrace.c:39-42); every one of these paths ends */
 		for (uint32_t jb = wv * 64u; jb < nMiss; jb += CRH_BLOCK) {
 			const uint32_t j = jb + lane;
@@ -403,6 +416,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_STREAM_SHADE_WPS) void k_stream_shad
 			}
 		}
 		__syncthreads();
+		CRH_SCLK(3);
 		/* the slots that stay free take the dispatch's next items (renderer.c:280-284): one fetch-and-add per cohort hands them out */
 		const uint32_t nOut = sw[SW_OUT];
 		if (threadIdx.x == 0) {
@@ -422,6 +436,7 @@ __global__ __launch_bounds__(CRH_BLOCK, CRH_STREAM_SHADE_WPS) void k_stream_shad
 		}
 		if (threadIdx.x < CRH_SF_RING) { const uint32_t f = fin[threadIdx.x]; if (f) atomicAdd((uint32_t *)&ctl->left[threadIdx.x], 0u - f); }
 		__syncthreads();
+		CRH_SCLK(4);
 		const uint32_t nNew = sw[SW_NEW];
 		if (nNew) {
 			const uint32_t c0 = sw[SW_G0_CHUNK], idx0 = sw[SW_G0_IDX];

@@ -33,6 +33,8 @@ extern "C" {
 /* 2 (round 4): crh_debug_plan_units writes EIGHT ints per unit (six in version 1), crh_frames_gather / crh_frames_prepare / crh_context_prepare exist,
  * CRH_OPT_ROUND_LIMIT / CRH_OPT_RENDER_SLABS exist, CRH_KERNEL_WAVE / CRH_KERNEL_WG are refused by the product build.
  * 3 (round 5): crh_scene_compile / crh_scene_upload_compiled / crh_compiled_scene_free (one layout compile for the contexts of a multi-GPU frame) and CRH_OPT_WALK exist.
+ * (round 6 adds values, not entry points — CRH_KERNEL_STREAM for CRH_OPT_KERNEL, CRH_OPT_STREAM_COHORTS, and the debug entries crh_debug_ray_dump* / crh_debug_walk_probe* of the
+ * walk-only probe —: a version-3 host is unaffected, the version stays 3.)
  * A host checks crh_abi_version() == CRH_ABI_VERSION. */
 #define CRH_ABI_VERSION 3
 /* layout version of crh_scene_desc and of the scene blobs (crh_blob_save / crh_blob_load): the records have not changed since round 1 */
